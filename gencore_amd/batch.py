@@ -1,0 +1,207 @@
+"""ReadBatch: the struct-of-arrays form of a coordinate-sorted stream of BAM records (host side, numpy).
+
+Layout == gce_batch in include/gencore_amd.h.  Helpers to build a batch from SAM-like python records (for the
+hand-written adversarial cases), to decode records back, and to canonicalise an engine/oracle result table
+into comparable python objects.
+"""
+import ctypes as C
+import re
+
+import numpy as np
+
+from .capi import CORE_DTYPE, GCE_NONE, UINT64_MAX, GceBatch
+
+_CIGAR_OPS = "MIDNSHP=X"
+_BASE2NIB = {"=": 0, "A": 1, "C": 2, "M": 3, "G": 4, "R": 5, "S": 6, "V": 7, "T": 8, "W": 9, "Y": 10, "H": 11,
+             "K": 12, "D": 13, "B": 14, "N": 15}
+_NIB2BASE = "=ACMGRSVTWYHKDBN"
+
+
+def parse_cigar(s):
+    if s in ("*", ""):
+        return []
+    return [(int(n) << 4) | _CIGAR_OPS.index(op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", s)]
+
+
+def cigar_string(words):
+    return "".join("%d%s" % (w >> 4, _CIGAR_OPS[w & 0xF]) for w in words) or "*"
+
+
+def pack_seq(s):
+    n = len(s)
+    out = np.zeros((n + 1) // 2, dtype=np.uint8)
+    for i, ch in enumerate(s):
+        v = _BASE2NIB[ch]
+        out[i // 2] |= (v << 4) if i % 2 == 0 else v
+    return out
+
+
+def unpack_seq(buf, n):
+    return "".join(_NIB2BASE[(buf[i // 2] >> 4) & 0xF if i % 2 == 0 else buf[i // 2] & 0xF] for i in range(n))
+
+
+class ReadBatch:
+    """Host arrays of one stream.  Field names follow gce_batch."""
+
+    FIELDS = ("core", "qname_off", "qname", "cigar_off", "cigar", "seq_off", "seq", "qual_off", "qual", "nm",
+              "nm_type", "mi_off", "mi")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw.get(f))
+        self.n = int(len(self.core))
+        self._check()
+
+    def _check(self):
+        assert self.core.dtype == CORE_DTYPE
+        for f, dt in (("qname_off", np.uint64), ("cigar_off", np.uint64), ("seq_off", np.uint64), ("qual_off", np.uint64),
+                      ("qname", np.uint8), ("cigar", np.uint32), ("seq", np.uint8), ("qual", np.uint8), ("nm", np.int32),
+                      ("nm_type", np.uint8)):
+            a = getattr(self, f)
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"], f
+
+    def copy(self):
+        return ReadBatch(**{f: (None if getattr(self, f) is None else getattr(self, f).copy()) for f in self.FIELDS})
+
+    def as_struct(self):
+        """ctypes gce_batch pointing at the numpy buffers (keep `self` alive while it is used)."""
+        b = GceBatch()
+        b.n_reads = self.n
+        for f in self.FIELDS:
+            a = getattr(self, f)
+            setattr(b, f, None if a is None or a.size == 0 and f in ("mi", "mi_off") else a.ctypes.data)
+        b.qname_bytes, b.cigar_words, b.seq_bytes, b.qual_bytes = self.qname.size, self.cigar.size, self.seq.size, self.qual.size
+        b.mi_bytes = 0 if self.mi is None else self.mi.size
+        return b
+
+    # ------------------------------------------------------------------ construction from python records
+    @staticmethod
+    def from_records(recs):
+        """recs: list of dicts with qname, flag, tid, pos, cigar (str), mtid, mpos, isize, seq (str),
+        qual (list[int] or str of phred+33), optional nm (int or None), nm_type (default 'C'), mi (str)."""
+        n = len(recs)
+        core = np.zeros(n, dtype=CORE_DTYPE)
+        qn, cg, sq, ql = [], [], [], []
+        qoff, coff, soff, loff = [], [], [], []
+        nm = np.zeros(n, dtype=np.int32)
+        nmt = np.zeros(n, dtype=np.uint8)
+        mi_off = np.full(n, UINT64_MAX, dtype=np.uint64)
+        mi = bytearray()
+        qpos = cpos = spos = lpos = 0
+        for i, r in enumerate(recs):
+            name = r["qname"].encode() + b"\0"
+            words = parse_cigar(r.get("cigar", "*"))
+            seq = r["seq"]
+            qual = r["qual"]
+            if isinstance(qual, str):
+                qual = [ord(ch) - 33 for ch in qual]
+            assert len(qual) == len(seq)
+            c = core[i]
+            c["tid"], c["pos"], c["l_qname"], c["mapq"] = r["tid"], r["pos"], len(name), r.get("mapq", 60)
+            c["n_cigar"], c["flag"], c["l_qseq"] = len(words), r["flag"], len(seq)
+            c["mtid"], c["mpos"], c["isize"] = r["mtid"], r["mpos"], r["isize"]
+            qoff.append(qpos); qn.append(name); qpos += len(name)
+            coff.append(cpos); cg.extend(words); cpos += len(words)
+            ps = pack_seq(seq)
+            soff.append(spos); sq.append(ps); spos += len(ps)
+            loff.append(lpos); ql.append(np.asarray(qual, dtype=np.uint8)); lpos += len(qual)
+            if r.get("nm") is not None:
+                nm[i] = r["nm"]
+                nmt[i] = ord(r.get("nm_type", "C"))
+            if r.get("mi") is not None:
+                mi_off[i] = len(mi)
+                mi += r["mi"].encode() + b"\0"
+        cat = lambda parts, dt: (np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt))
+        return ReadBatch(
+            core=core, qname_off=np.asarray(qoff, np.uint64), qname=np.frombuffer(b"".join(qn), np.uint8).copy(),
+            cigar_off=np.asarray(coff, np.uint64), cigar=np.asarray(cg, np.uint32),
+            seq_off=np.asarray(soff, np.uint64), seq=cat(sq, np.uint8),
+            qual_off=np.asarray(loff, np.uint64), qual=cat(ql, np.uint8), nm=nm, nm_type=nmt,
+            mi_off=mi_off if len(mi) else None, mi=np.frombuffer(bytes(mi), np.uint8).copy() if len(mi) else None)
+
+    # ------------------------------------------------------------------ decoding
+    def qname_of(self, i):
+        o = int(self.qname_off[i])
+        e = o
+        q = self.qname
+        while q[e] != 0:
+            e += 1
+        return bytes(q[o:e]).decode()
+
+    def cigar_of(self, i):
+        o = int(self.cigar_off[i])
+        return cigar_string(self.cigar[o:o + int(self.core["n_cigar"][i])])
+
+    def seq_of(self, i, seq=None):
+        s = self.seq if seq is None else seq
+        o, n = int(self.seq_off[i]), int(self.core["l_qseq"][i])
+        return unpack_seq(s[o:o + (n + 1) // 2], n)
+
+    def qual_of(self, i, qual=None):
+        q = self.qual if qual is None else qual
+        o, n = int(self.qual_off[i]), int(self.core["l_qseq"][i])
+        return q[o:o + n].copy()
+
+
+class ResultTable:
+    """Per-read result arrays (gce_result / orc_result) as numpy, plus the mutated seq/qual blobs."""
+
+    def __init__(self, out_flag, qname_src, nm_new, fr, rr, mate, seq, qual, pre, post, status=0, message=""):
+        self.out_flag, self.qname_src, self.nm_new, self.fr, self.rr, self.mate = out_flag, qname_src, nm_new, fr, rr, mate
+        self.seq, self.qual, self.pre, self.post = seq, qual, pre, post
+        self.status, self.message = status, message
+
+    def emitted(self):
+        return np.nonzero(self.out_flag)[0]
+
+    def records(self, batch):
+        """Decoded output records, canonically ordered (quirk Q3: the reference's own order has pointer ties)."""
+        out = []
+        for i in self.emitted():
+            i = int(i)
+            c = batch.core[i]
+            out.append(dict(
+                src=i, qname=batch.qname_of(int(self.qname_src[i])), flag=int(c["flag"]), tid=int(c["tid"]), pos=int(c["pos"]),
+                mtid=int(c["mtid"]), mpos=int(c["mpos"]), isize=int(c["isize"]), cigar=batch.cigar_of(i),
+                seq=batch.seq_of(i, self.seq), qual=batch.qual_of(i, self.qual).tolist(),
+                nm=(int(self.nm_new[i]) if self.nm_new[i] >= 0 else (int(batch.nm[i]) if batch.nm_type[i] else None)),
+                fr=int(self.fr[i]), rr=int(self.rr[i]), kind=int(self.out_flag[i]),
+                mate=(None if self.mate[i] == GCE_NONE else int(self.mate[i]))))
+        return out
+
+
+def diff_results(batch, a, b, max_report=5):
+    """Bit-exact comparison of two ResultTables over the same batch.  Returns a list of difference strings."""
+    diffs = []
+    for name in ("out_flag", "qname_src", "nm_new", "fr", "rr", "mate"):
+        x, y = getattr(a, name), getattr(b, name)
+        em = (a.out_flag != 0) | (b.out_flag != 0) if name != "out_flag" else np.ones(len(x), bool)
+        bad = np.nonzero((x != y) & em)[0]
+        if len(bad):
+            diffs.append("%s differs at %d reads, first %s: %s vs %s" % (name, len(bad), bad[:max_report].tolist(),
+                                                                       x[bad[:max_report]].tolist(), y[bad[:max_report]].tolist()))
+    both = np.nonzero((a.out_flag != 0) & (b.out_flag != 0))[0]
+    nbad = 0
+    for i in both:
+        i = int(i)
+        so, n = int(batch.seq_off[i]), int(batch.core["l_qseq"][i])
+        qo = int(batch.qual_off[i])
+        # compare nibble-exact (ignore the pad nibble of an odd-length read)
+        sa, sb = a.seq[so:so + (n + 1) // 2].copy(), b.seq[so:so + (n + 1) // 2].copy()
+        if n % 2:
+            sa[-1] &= 0xF0; sb[-1] &= 0xF0
+        if not np.array_equal(sa, sb) or not np.array_equal(a.qual[qo:qo + n], b.qual[qo:qo + n]):
+            nbad += 1
+            if nbad <= max_report:
+                diffs.append("read %d seq/qual differ: %s | %s ; q %s | %s" % (
+                    i, batch.seq_of(i, a.seq), batch.seq_of(i, b.seq),
+                    a.qual[qo:qo + n].tolist(), b.qual[qo:qo + n].tolist()))
+    if nbad > max_report:
+        diffs.append("... %d emitted reads differ in seq/qual" % nbad)
+    pa, pb = a.pre.as_array(), b.pre.as_array()
+    if not np.array_equal(pa, pb):
+        diffs.append("pre stats differ: %s vs %s" % (a.pre.as_dict(), b.pre.as_dict()))
+    pa, pb = a.post.as_array(), b.post.as_array()
+    if not np.array_equal(pa, pb):
+        diffs.append("post stats differ: %s vs %s" % (a.post.as_dict(), b.post.as_dict()))
+    return diffs

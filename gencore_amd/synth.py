@@ -1,0 +1,335 @@
+"""Deterministic synthetic read-cluster generator — runs on CPU or on the GPU (torch tensors).
+
+Counter-based RNG (splitmix64 finaliser over int64 tensors, wrap-around arithmetic), so the same (seed, config)
+yields bit-identical data on CPU and on the MI355X.  Output is a coordinate-sorted stream in the gce_batch
+struct-of-arrays layout plus the reference contigs in FastaReader's 4-bit code.
+
+Workloads (BASELINE.json `configs`):
+  cfg1s : plumbing substitute for configs[0] (2k pairs, depth 2, no UMI, 1 contig)
+  cfg2  : 1 M pairs, 150 bp, no UMI, mean depth 4, single 10 Mb contig, -s 1
+  cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean depth 8, 24 contigs / 300 Mb, -s 2
+  cfg4s : per-GPU shard of configs[3] (12.5 M pairs, UMI, depth 16)
+  cfg5  : ultra-deep hotspots, 250 bp, duplex UMIs AAAA_BBBB, depth U[500,2000]
+Every size can be scaled with `n_pairs=`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .batch import ReadBatch
+from .capi import CORE_DTYPE
+
+SEED0 = 0x67656E63  # "genc"
+_M64 = (1 << 64) - 1
+
+
+def _s64(x):
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+_K1, _K2, _K3 = _s64(0x9E3779B97F4A7C15), _s64(0xBF58476D1CE4E5B9), _s64(0x94D049BB133111EB)
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix(x):
+    x = (x ^ _lsr(x, 30)) * _K2
+    x = (x ^ _lsr(x, 27)) * _K3
+    return x ^ _lsr(x, 31)
+
+
+def rnd(seed, stream, idx):
+    """64 random bits per element of idx (int64 tensor); pure function of (seed, stream, idx)."""
+    return _mix(idx * _K1 + _s64((seed * 0x100000001B3 + stream * 0xD6E8FEB86659FD93) & _M64))
+
+
+def rnd_u(seed, stream, idx, n):
+    """uniform integer in [0, n)."""
+    return (_lsr(rnd(seed, stream, idx), 11) % n)
+
+
+def rnd_f(seed, stream, idx):
+    return _lsr(rnd(seed, stream, idx), 11).to(torch.float64) * (1.0 / (1 << 53))
+
+
+CONFIGS = {
+    "cfg1s": dict(n_pairs=2000, L=150, umi=0, duplex=False, mean_depth=2, contigs=[200_000], ins_mu=300, ins_sd=30, ins_max=600,
+                  supporting_reads=1),
+    "cfg2": dict(n_pairs=1_000_000, L=150, umi=0, duplex=False, mean_depth=4, contigs=[10_000_000], ins_mu=300, ins_sd=30,
+                 ins_max=600, supporting_reads=1),
+    "cfg3": dict(n_pairs=10_000_000, L=150, umi=8, duplex=False, mean_depth=8,
+                 contigs=[int(300e6 * w / 3036.0) for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
+                                                            90, 81, 78, 59, 63, 48, 51, 155, 59)],
+                 ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),
+    "cfg4s": dict(n_pairs=12_500_000, L=150, umi=8, duplex=False, mean_depth=16, contigs=[125_000_000] * 3, ins_mu=300, ins_sd=30,
+                  ins_max=600, supporting_reads=2),
+    "cfg5": dict(n_pairs=0, n_molecules=1250, L=250, umi=4, duplex=True, depth_lo=500, depth_hi=2000, contigs=[50_000_000],
+                 ins_mu=450, ins_sd=50, ins_max=900, supporting_reads=1),
+}
+
+
+def _poisson_table(lam, kmax=96):
+    """CDF of 1 + Poisson(lam) for inverse-transform sampling."""
+    p = [math.exp(-lam)]
+    for k in range(1, kmax):
+        p.append(p[-1] * lam / k)
+    return np.cumsum(p)
+
+
+class SynthData:
+    """tensors: dict name -> torch tensor (gce_batch fields, `core` as int32 [n,8]); reference: list of (nibbles, n_bases)."""
+
+    def __init__(self, tensors, reference, target_len, cfg, info):
+        self.t, self.reference, self.target_len, self.cfg, self.info = tensors, reference, target_len, cfg, info
+
+    @property
+    def n_reads(self):
+        return int(self.t["core"].shape[0])
+
+    def to_batch(self):
+        t = {k: v.cpu().numpy() for k, v in self.t.items()}
+        core = np.ascontiguousarray(t["core"]).view(CORE_DTYPE).reshape(-1)
+        return ReadBatch(core=core, qname_off=t["qname_off"].astype(np.uint64), qname=t["qname"],
+                         cigar_off=t["cigar_off"].astype(np.uint64), cigar=t["cigar"].view(np.uint32),
+                         seq_off=t["seq_off"].astype(np.uint64), seq=t["seq"], qual_off=t["qual_off"].astype(np.uint64),
+                         qual=t["qual"], nm=t["nm"], nm_type=t["nm_type"], mi_off=None, mi=None)
+
+    def reference_host(self):
+        return [(r.cpu().numpy(), n) for r, n in self.reference]
+
+
+def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, **over):
+    cfg = dict(CONFIGS[name])
+    cfg.update(over)
+    if n_pairs is not None:
+        cfg["n_pairs"] = int(n_pairs)
+    seed = SEED0 + 1000003 * list(CONFIGS).index(name) + seed
+    dev = torch.device(device)
+    L = cfg["L"]
+    i64 = dict(dtype=torch.int64, device=dev)
+    contigs = list(cfg["contigs"])
+    ncont = len(contigs)
+
+    # ---------------------------------------------------------------- molecules and their duplicate counts
+    if cfg.get("duplex") and cfg.get("n_molecules"):
+        M = int(cfg["n_molecules"]) if n_pairs is None else max(1, int(n_pairs) // ((cfg["depth_lo"] + cfg["depth_hi"]) // 2))
+        mid = torch.arange(M, **i64)
+        depth = cfg["depth_lo"] + rnd_u(seed, 1, mid, cfg["depth_hi"] - cfg["depth_lo"] + 1)
+    else:
+        M = max(1, int(round(cfg["n_pairs"] / cfg["mean_depth"])))
+        mid = torch.arange(M, **i64)
+        cdf = torch.tensor(_poisson_table(cfg["mean_depth"] - 1.0), dtype=torch.float64, device=dev)
+        depth = 1 + torch.searchsorted(cdf, rnd_f(seed, 1, mid)).to(torch.int64)
+    P = int(depth.sum().item())                              # total pairs (~ n_pairs)
+    clen = torch.tensor(contigs, **i64)
+    cum = torch.cumsum(clen, 0)
+    total = int(cum[-1].item())
+    # insert size ~ N(mu, sd) via Irwin-Hall(12), clipped to [L, ins_max]
+    z = sum(rnd_f(seed, 10 + k, mid) for k in range(12)) - 6.0
+    ins = torch.clamp((cfg["ins_mu"] + cfg["ins_sd"] * z).round().to(torch.int64), L, cfg["ins_max"])
+    g = rnd_u(seed, 2, mid, total)                           # global start, then mapped to (contig, offset)
+    m_tid = torch.searchsorted(cum, g, right=True)
+    m_start = g - (cum[m_tid] - clen[m_tid])
+    m_start = torch.minimum(m_start, clen[m_tid] - ins - 16).clamp_(min=8)
+    m_strand = rnd_u(seed, 3, mid, 2)
+    U = int(cfg["umi"])
+    Utot = 2 * U if cfg["duplex"] else U
+
+    # ---------------------------------------------------------------- duplicates (pairs)
+    pid = torch.arange(P, **i64)
+    mol = torch.repeat_interleave(mid, depth)
+    p_tid, p_start, p_ins = m_tid[mol], m_start[mol], ins[mol]
+    if cfg["duplex"]:
+        strand = rnd_u(seed, 4, pid, 2)
+    else:
+        strand = m_strand[mol]
+    # alignment variant per read: 0 = LM (97%), 1 = leading S, 2 = trailing S (2%), 3 = I, 4 = D (1%)
+    def variant(stream):
+        r = rnd_u(seed, stream, pid, 1000)
+        kind = torch.zeros(P, **i64)
+        kind = torch.where(r >= 970, 1 + (r & 1), kind)
+        kind = torch.where(r >= 990, 3 + (r & 1), kind)
+        k = torch.where((kind == 1) | (kind == 2), 3 + rnd_u(seed, stream + 1, pid, 8), 1 + rnd_u(seed, stream + 1, pid, 3))
+        k = torch.where(kind == 0, torch.zeros_like(k), k)
+        a = 20 + rnd_u(seed, stream + 2, pid, L - 60)       # split point for I/D
+        return kind, k, a
+    fk, fklen, fa = variant(20)
+    rk, rklen, ra = variant(30)
+    f_pos = p_start + torch.where(fk == 1, fklen, torch.zeros_like(fklen))
+    r0 = p_start + p_ins - L
+    r_pos = r0 + torch.where(rk == 1, rklen, torch.zeros_like(rklen))
+
+    def ref_span(kind, k):
+        return torch.where(kind == 0, torch.full_like(k, L), torch.where((kind == 1) | (kind == 2), L - k, torch.where(kind == 3, L - k, L + k)))
+    f_end = f_pos + ref_span(fk, fklen)
+    r_end = r_pos + ref_span(rk, rklen)
+    tlen = torch.maximum(f_end, r_end) - torch.minimum(f_pos, r_pos)
+    f_is_left = f_pos <= r_pos
+    f_isize = torch.where(f_is_left, tlen, -tlen)
+    r_isize = -f_isize
+
+    # ---------------------------------------------------------------- reads = 2 per pair, sorted by (tid, pos)
+    N = 2 * P
+    rd_pair = torch.cat([pid, pid])
+    rd_rev = torch.cat([torch.zeros(P, **i64), torch.ones(P, **i64)])
+    rd_pos = torch.cat([f_pos, r_pos])
+    rd_tid = torch.cat([p_tid, p_tid])
+    # tie order inside one (tid,pos): a scrambled pair id, like an aligner's arbitrary order
+    key = (rd_tid << 40) | rd_pos
+    tie = rnd_u(seed, 5, rd_pair * 2 + rd_rev, 1 << 20)
+    order = torch.argsort(tie, stable=True)
+    order = order[torch.argsort(key[order], stable=True)]
+    rd_pair, rd_rev = rd_pair[order], rd_rev[order]
+    isrev = rd_rev == 1
+    pos = torch.where(isrev, r_pos[rd_pair], f_pos[rd_pair])
+    mpos = torch.where(isrev, f_pos[rd_pair], r_pos[rd_pair])
+    tid = p_tid[rd_pair]
+    isize = torch.where(isrev, r_isize[rd_pair], f_isize[rd_pair])
+    kind = torch.where(isrev, rk[rd_pair], fk[rd_pair])
+    klen = torch.where(isrev, rklen[rd_pair], fklen[rd_pair])
+    asplit = torch.where(isrev, ra[rd_pair], fa[rd_pair])
+    st = strand[rd_pair]
+    # flags: top strand -> read1 forward (99) / read2 reverse (147); bottom strand -> read1 reverse (83) / read2 forward (163)
+    flag = torch.where(st == 0, torch.where(isrev, torch.full_like(st, 147), torch.full_like(st, 99)),
+                       torch.where(isrev, torch.full_like(st, 83), torch.full_like(st, 163)))
+    # query start on the reference for column 0 of the M block(s)
+    ref0 = torch.where(isrev, r0[rd_pair], p_start[rd_pair])
+
+    # CIGAR: up to 3 ops
+    M_, I_, D_, S_ = 0, 1, 2, 4
+    ncig = torch.where(kind == 0, torch.ones_like(kind), torch.where(kind <= 2, torch.full_like(kind, 2), torch.full_like(kind, 3)))
+    w0 = torch.where(kind == 0, torch.full_like(kind, (L << 4) | M_),
+                     torch.where(kind == 1, (klen << 4) | S_, torch.where(kind == 2, ((L - klen) << 4) | M_, (asplit << 4) | M_)))
+    w1 = torch.where(kind == 1, ((L - klen) << 4) | M_, torch.where(kind == 2, (klen << 4) | S_,
+                     torch.where(kind == 3, (klen << 4) | I_, (klen << 4) | D_)))
+    w2 = torch.where(kind == 3, ((L - asplit - klen) << 4) | M_, ((L - asplit) << 4) | M_)
+    cigar_off = torch.cumsum(ncig, 0) - ncig
+    cigar = torch.zeros(int(ncig.sum().item()), **i64)
+    cigar[cigar_off] = w0
+    m1 = ncig >= 2
+    cigar[cigar_off[m1] + 1] = w1[m1]
+    m2 = ncig >= 3
+    cigar[cigar_off[m2] + 2] = w2[m2]
+
+    # ---------------------------------------------------------------- reference contigs (random ACGT), FASTA 4-bit code
+    reference, ref_codes = [], []
+    fcode = torch.tensor([1, 3, 4, 2], dtype=torch.uint8, device=dev)     # our base index 0..3 = A,C,G,T -> FastaReader code
+    for ci, ln in enumerate(contigs):
+        b = (rnd(seed, 100 + ci, torch.arange(ln, **i64)) & 3).to(torch.uint8)   # 0..3 = A,C,G,T
+        ref_codes.append(b)
+        fc = fcode[b.long()]
+        if ln % 2:
+            fc = torch.cat([fc, torch.zeros(1, dtype=torch.uint8, device=dev)])
+        reference.append(((fc[0::2] | (fc[1::2] << 4)).contiguous(), ln))
+    ref_base_off = torch.tensor([0] + list(np.cumsum(contigs)[:-1]), **i64)
+    ref_all = torch.cat(ref_codes)
+    del ref_codes
+
+    # ---------------------------------------------------------------- per-base data, chunked over reads
+    SB = (L + 1) // 2
+    seq = torch.empty(N * SB, dtype=torch.uint8, device=dev)
+    qual = torch.empty(N * L, dtype=torch.uint8, device=dev)
+    nm = torch.empty(N, dtype=torch.int32, device=dev)
+    bam_nib = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev)
+    j = torch.arange(L, **i64).unsqueeze(0)
+    err_thr = int(0.005 * (1 << 20))
+    for s in range(0, N, chunk_reads):
+        e = min(N, s + chunk_reads)
+        kd, kl, a = kind[s:e, None], klen[s:e, None], asplit[s:e, None]
+        # reference offset of query column j (or -1 for inserted / clipped bases)
+        roff = torch.where(kd == 0, j.expand(e - s, L),
+               torch.where(kd == 1, torch.where(j >= kl, j, torch.full_like(j, -1)),    # ref0 is the unclipped start
+               torch.where(kd == 2, torch.where(j < L - kl, j, torch.full_like(j, -1)),
+               torch.where(kd == 3, torch.where(j < a, j, torch.where(j < a + kl, torch.full_like(j, -1), j - kl)),
+                           torch.where(j < a, j, j + kl)))))
+        rid = torch.arange(s, e, **i64)
+        # per-base randomness must belong to the MOLECULE's duplicate, not the sorted position: key on (pair, mate)
+        bkey = ((rd_pair[s:e] * 2 + rd_rev[s:e]) * 1024)[:, None] + j
+        h = rnd(seed, 6, bkey)
+        gpos = (ref_base_off[tid[s:e]] + ref0[s:e])[:, None] + roff.clamp(min=0)
+        rb = ref_all[gpos.clamp(max=ref_all.numel() - 1)].long()
+        is_err = (h & 0xFFFFF) < err_thr
+        sub = (rb + 1 + (_lsr(h, 20) & 0xFF) % 3) & 3
+        rand_b = _lsr(h, 28) & 3
+        base = torch.where(roff < 0, rand_b, torch.where(is_err, sub, rb))
+        qsel = _lsr(h, 32) % 100
+        q = torch.where(qsel < 80, torch.full_like(qsel, 37), torch.where(qsel < 92, torch.full_like(qsel, 25), torch.full_like(qsel, 11)))
+        mism = ((roff >= 0) & (base != rb)).sum(1)
+        nm[s:e] = (mism + torch.where((kind[s:e] == 3) | (kind[s:e] == 4), klen[s:e], torch.zeros_like(mism))).to(torch.int32)
+        nibs = bam_nib[base]
+        if L % 2:
+            nibs = torch.cat([nibs, torch.zeros(e - s, 1, dtype=torch.uint8, device=dev)], 1)
+        seq[s * SB:e * SB] = ((nibs[:, 0::2] << 4) | nibs[:, 1::2]).reshape(-1)
+        qual[s * L:e * L] = q.to(torch.uint8).reshape(-1)
+        del roff, h, gpos, rb, base, nibs, q, bkey, rid
+
+    # ---------------------------------------------------------------- qnames: SIM:<lane>:<tile>:<x>:<y>[:UMI_<umi>]
+    W = 4 + 2 + 5 + 6 + 6 + (5 + Utot + (1 if cfg["duplex"] else 0) if U else 0) + 1
+    scr = (pid * 0x9E3779B1 + 12345) & 0xFFFFFFFF            # bijection on 32 bits => unique (x, y)
+    lane = 1 + (scr % 8)
+    tile = 1101 + ((scr >> 3) % 96)
+    x = (scr >> 16) & 0xFFFF
+    y = scr & 0xFFFF
+    cols = []
+    SKIP = 255
+
+    def lit(sx):
+        return [torch.full((P,), ord(ch), dtype=torch.uint8, device=dev) for ch in sx]
+
+    def digits(v, width):
+        out, started = [], torch.zeros(P, dtype=torch.bool, device=dev)
+        for k in range(width - 1, -1, -1):
+            d = (v // (10 ** k)) % 10
+            started = started | (d > 0) | (k == 0)
+            out.append(torch.where(started, (48 + d).to(torch.uint8), torch.full((P,), SKIP, dtype=torch.uint8, device=dev)))
+        return out
+    cols += lit("SIM:") + digits(lane, 1) + lit(":") + digits(tile, 4) + lit(":") + digits(x, 5) + lit(":") + digits(y, 5)
+    if U:
+        ub = torch.tensor([ord(ch) for ch in "ACGT"], dtype=torch.uint8, device=dev)
+        cols += lit(":UMI_")
+        um = (rnd(seed, 7, mol[:, None] * 64 + torch.arange(Utot, **i64)[None, :]) & 3)
+        ue = rnd(seed, 8, pid[:, None] * 64 + torch.arange(Utot, **i64)[None, :])
+        uerr = (ue & 0xFFFF) < int(0.01 * 65536)
+        um = torch.where(uerr, (um + 1 + (_lsr(ue, 16) & 0xFF) % 3) & 3, um)
+        if cfg["duplex"]:
+            # top strand carries A_B, bottom strand B_A
+            A, B = um[:, :U], um[:, U:]
+            first = torch.where((strand == 0)[:, None], A, B)
+            second = torch.where((strand == 0)[:, None], B, A)
+            cols += [ub[first[:, k]] for k in range(U)] + lit("_") + [ub[second[:, k]] for k in range(U)]
+        else:
+            cols += [ub[um[:, k]] for k in range(U)]
+    cols += [torch.zeros(P, dtype=torch.uint8, device=dev)]
+    mat = torch.stack(cols, 1)
+    assert mat.shape[1] <= W + 8
+    keepm = mat != SKIP
+    plen = keepm.sum(1)
+    # per READ names (both mates carry the same name), laid out in sorted read order
+    rlen = plen[rd_pair]
+    qname_off = torch.cumsum(rlen, 0) - rlen
+    rmat = mat[rd_pair]
+    qname = rmat[rmat != SKIP].contiguous()
+    del rmat, mat
+
+    core = torch.zeros(N, 8, dtype=torch.int32, device=dev)
+    core[:, 0] = tid.to(torch.int32)
+    core[:, 1] = pos.to(torch.int32)
+    # word 2: l_qname u8 | mapq u8 << 8 | bin u16 << 16 ; word 3: n_cigar u16 | flag u16 << 16
+    core[:, 2] = (rlen | (60 << 8)).to(torch.int32)
+    core[:, 3] = (ncig | (flag << 16)).to(torch.int32)
+    core[:, 4] = L
+    core[:, 5] = tid.to(torch.int32)
+    core[:, 6] = mpos.to(torch.int32)
+    core[:, 7] = isize.to(torch.int32)
+
+    rid = torch.arange(N, **i64)
+    tensors = dict(core=core, qname_off=qname_off, qname=qname, cigar_off=cigar_off, cigar=cigar.to(torch.int32),
+                   seq_off=rid * SB, seq=seq, qual_off=rid * L, qual=qual, nm=nm,
+                   nm_type=torch.full((N,), ord("C"), dtype=torch.uint8, device=dev))
+    info = dict(name=name, n_pairs=P, n_reads=N, n_molecules=M, read_len=L, umi_len=Utot,
+                umi_prefix="UMI" if U else "", supporting_reads=cfg["supporting_reads"])
+    return SynthData(tensors, reference, contigs, cfg, info)
