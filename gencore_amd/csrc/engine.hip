@@ -1,0 +1,444 @@
+// engine.hip — C-ABI implementation (include/gencore_amd.h) of the MI355X consensus engine.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip -o libgencore_amd.so
+// No CPU fallback: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gce_kernels.hpp"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+enum { EV_START = 0, EV_PRESCAN, EV_CLUSTER, EV_CSR, EV_PAIRING, EV_SCORE, EV_CONSENSUS, EV_FINISH, EV_COUNT };
+
+}  // namespace
+
+struct gce_engine {
+    gce_params prm{};
+    std::vector<uint32_t> target_len;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT]{};
+    // reference
+    std::vector<DevBuf> ref_buf; std::vector<const uint8_t *> ref_ptr; std::vector<int64_t> ref_len;
+    DevBuf d_ref_ptr, d_ref_len, d_target_len;
+    // host staging (gce_submit)
+    std::vector<gce_core> h_core; std::vector<uint64_t> h_qoff, h_coff, h_soff, h_loff, h_mioff;
+    std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm;
+    bool have_mi = false, host_mode = false, device_mode = false, processed = false;
+    gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
+    DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi;
+    // work buffers
+    DevBuf cls, umi_ptr, umi_len, has_mi, slot, rank, score, out_flag, qname_src, nm_new, fr, rr, mate, out_index;
+    DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
+    DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
+    DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster;
+    DevBuf rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    StreamInfo h_si{};
+    gce_timing timing{};
+    int64_t n = 0;
+    // host result copies
+    std::vector<uint8_t> r_flag, r_seq, r_qual; std::vector<uint32_t> r_qsrc, r_mate, r_oidx; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
+};
+
+static int fail(gce_engine *e, int code, const std::string &msg) { if (e) e->err = msg; return code; }
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(e, _e == hipErrorOutOfMemory ? GCE_ERR_OOM : GCE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } while (0)
+
+extern "C" {
+
+int gce_abi_version(void) { return GCE_ABI_VERSION; }
+
+void gce_params_default(gce_params *p) {          // src/options.cpp:4-40
+    memset(p, 0, sizeof *p);
+    p->abi_version = GCE_ABI_VERSION;
+    p->proper_umi_diff_threshold = 1; p->unproper_umi_diff_threshold = 0; p->duplex_mismatch_threshold = 2;
+    p->cluster_size_req = 1; p->base_score_req = 6; p->high_quality = 30; p->moderate_quality = 20; p->low_quality = 15;
+    p->score_high = 8; p->score_moderate = 6; p->score_low = 4; p->score_bad = 2;
+    p->skip_low_complexity_cluster_threshold = 1000; p->flush_period = 10000; p->score_percent_req = 0.8;
+}
+
+void gce_detect_umi_prefix(const char *q, char out[32]) {      // src/gencore.cpp:207-216
+    memset(out, 0, 32);
+    if (strstr(q, "umi_")) strcpy(out, "umi");
+    else if (strstr(q, "UMI_")) strcpy(out, "UMI");
+}
+
+const char *gce_status_message(int s) {
+    switch (s) {
+    case GCE_OK: return "ok";
+    case GCE_ERR_INVALID: return "invalid argument or call order";
+    case GCE_ERR_NO_DEVICE: return "no HIP device available (this engine has no CPU fallback)";
+    case GCE_ERR_HIP: return "HIP runtime error";
+    case GCE_ERR_OOM: return "out of device memory";
+    case GCE_ERR_UNSORTED: return "ERROR: the input is unsorted. Please sort the input first.";
+    case GCE_ERR_UMI_MISMATCH: return "The UMI of a read pair should be identical";
+    case GCE_ERR_NM_MISSING: return "NM tag missing on a consensus template whose mismatch count changed";
+    case GCE_ERR_UMI_PARSE: return "UMI parse: substr start beyond the end of the read name";
+    case GCE_ERR_QNAME_SHORT: return "copyQName ERROR: desitination qname is shorter";
+    default: return "unknown status";
+    }
+}
+
+const char *gce_last_error(const gce_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int gce_create(const gce_params *params, gce_engine **out) {
+    if (!params || !out || params->abi_version != GCE_ABI_VERSION) return GCE_ERR_INVALID;
+    if (params->proper_umi_diff_threshold < 0 || params->unproper_umi_diff_threshold < 0 || params->flush_period < 0) return GCE_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || params->device >= ndev) return GCE_ERR_NO_DEVICE;
+    gce_engine *e = new gce_engine();
+    e->prm = *params;
+    if (e->prm.flush_period == 0) e->prm.flush_period = 10000;
+    if (params->n_targets > 0 && params->target_len) e->target_len.assign(params->target_len, params->target_len + params->n_targets);
+    e->prm.target_len = nullptr;
+    if (hipSetDevice(params->device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess) { delete e; return GCE_ERR_HIP; }
+    for (auto &v : e->ev) (void)hipEventCreate(&v);
+    *out = e;
+    return GCE_OK;
+}
+
+void gce_destroy(gce_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->prm.device);
+    (void)hipStreamSynchronize(e->stream);
+    DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
+                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi,
+                     &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
+                     &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
+                     &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
+    for (auto *b : all) b->release();
+    for (auto &b : e->ref_buf) b.release();
+    for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+void gce_pack_reference(const char *bases, int64_t n, uint8_t *out) {      // FastaReader::to4bits, src/fastareader.cpp:139-152
+    memset(out, 0, (size_t)((n + 1) / 2));
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t code;
+        switch (bases[i]) { case 'A': code = 1; break; case 'T': code = 2; break; case 'C': code = 3; break; case 'G': code = 4; break; default: code = 0; }
+        out[i >> 1] |= (i & 1) ? (uint8_t)(code << 4) : code;
+    }
+}
+
+int gce_set_reference(gce_engine *e, int32_t tid, const uint8_t *nibbles, int64_t n_bases) {
+    if (!e || tid < 0 || n_bases < 0) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if ((size_t)tid >= e->ref_buf.size()) { e->ref_buf.resize(tid + 1); e->ref_ptr.resize(tid + 1, nullptr); e->ref_len.resize(tid + 1, 0); }
+    if (!nibbles) { e->ref_ptr[tid] = nullptr; e->ref_len[tid] = 0; return GCE_OK; }
+    size_t bytes = (size_t)((n_bases + 1) / 2);
+    HIPCHK(e->ref_buf[tid].ensure(bytes + 16));
+    hipPointerAttribute_t attr; bool is_dev = hipPointerGetAttributes(&attr, nibbles) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    HIPCHK(hipMemcpyAsync(e->ref_buf[tid].p, nibbles, bytes, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ref_ptr[tid] = e->ref_buf[tid].as<uint8_t>(); e->ref_len[tid] = n_bases;
+    return GCE_OK;
+}
+
+int gce_reset(gce_engine *e) {
+    if (!e) return GCE_ERR_INVALID;
+    e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear();
+    e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
+    e->have_mi = e->host_mode = e->device_mode = e->processed = false; e->n = 0;
+    return GCE_OK;
+}
+
+// Gencore::addToCluster for a whole batch (src/gencore.cpp:272,469): host buffers are staged, then uploaded by gce_process.
+int gce_submit(gce_engine *e, const gce_batch *b) {
+    if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
+    if (e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
+    if (e->processed) gce_reset(e);
+    e->host_mode = true;
+    const int64_t n = b->n_reads;
+    if (n == 0) return GCE_OK;
+    if (!b->core || !b->qname_off || !b->qname || !b->cigar_off || !b->seq_off || !b->seq || !b->qual_off || !b->qual || !b->nm || !b->nm_type)
+        return fail(e, GCE_ERR_INVALID, "null array in gce_batch");
+    const uint64_t q0 = e->h_qname.size(), c0 = e->h_cigar.size(), s0 = e->h_seq.size(), l0 = e->h_qual.size(), m0 = e->h_mi.size();
+    const size_t old = e->h_core.size();
+    e->h_core.insert(e->h_core.end(), b->core, b->core + n);
+    e->h_nm.insert(e->h_nm.end(), b->nm, b->nm + n);
+    e->h_nmt.insert(e->h_nmt.end(), b->nm_type, b->nm_type + n);
+    e->h_qname.insert(e->h_qname.end(), b->qname, b->qname + b->qname_bytes);
+    if (b->cigar_words) e->h_cigar.insert(e->h_cigar.end(), b->cigar, b->cigar + b->cigar_words);
+    e->h_seq.insert(e->h_seq.end(), b->seq, b->seq + b->seq_bytes);
+    e->h_qual.insert(e->h_qual.end(), b->qual, b->qual + b->qual_bytes);
+    bool mi = b->mi && b->mi_off;
+    if (mi && !e->have_mi) { e->h_mioff.assign(old, UINT64_MAX); e->have_mi = true; }
+    if (mi) e->h_mi.insert(e->h_mi.end(), b->mi, b->mi + b->mi_bytes);
+    for (int64_t i = 0; i < n; i++) {
+        e->h_qoff.push_back(b->qname_off[i] + q0); e->h_coff.push_back(b->cigar_off[i] + c0);
+        e->h_soff.push_back(b->seq_off[i] + s0); e->h_loff.push_back(b->qual_off[i] + l0);
+        if (e->have_mi) e->h_mioff.push_back(mi && b->mi_off[i] != UINT64_MAX ? b->mi_off[i] + m0 : UINT64_MAX);
+    }
+    return GCE_OK;
+}
+
+int gce_submit_device(gce_engine *e, const gce_batch *b) {
+    if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
+    if (e->processed) gce_reset(e);
+    if (e->host_mode || e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_submit_device takes exactly one batch per gce_process");
+    e->device_mode = true;
+    e->dev_batch = *b;
+    return GCE_OK;
+}
+
+static int upload(gce_engine *e) {
+    struct { DevBuf *d; const void *src; size_t bytes; const void **dst; } items[] = {
+        {&e->b_core, e->h_core.data(), e->h_core.size() * sizeof(gce_core), (const void **)&e->dev_batch.core},
+        {&e->b_qoff, e->h_qoff.data(), e->h_qoff.size() * 8, (const void **)&e->dev_batch.qname_off},
+        {&e->b_qname, e->h_qname.data(), e->h_qname.size(), (const void **)&e->dev_batch.qname},
+        {&e->b_coff, e->h_coff.data(), e->h_coff.size() * 8, (const void **)&e->dev_batch.cigar_off},
+        {&e->b_cigar, e->h_cigar.data(), e->h_cigar.size() * 4, (const void **)&e->dev_batch.cigar},
+        {&e->b_soff, e->h_soff.data(), e->h_soff.size() * 8, (const void **)&e->dev_batch.seq_off},
+        {&e->b_seq, e->h_seq.data(), e->h_seq.size(), (const void **)&e->dev_batch.seq},
+        {&e->b_loff, e->h_loff.data(), e->h_loff.size() * 8, (const void **)&e->dev_batch.qual_off},
+        {&e->b_qual, e->h_qual.data(), e->h_qual.size(), (const void **)&e->dev_batch.qual},
+        {&e->b_nm, e->h_nm.data(), e->h_nm.size() * 4, (const void **)&e->dev_batch.nm},
+        {&e->b_nmt, e->h_nmt.data(), e->h_nmt.size(), (const void **)&e->dev_batch.nm_type},
+        {&e->b_mioff, e->h_mioff.data(), e->h_mioff.size() * 8, (const void **)&e->dev_batch.mi_off},
+        {&e->b_mi, e->h_mi.data(), e->h_mi.size(), (const void **)&e->dev_batch.mi},
+    };
+    for (auto &it : items) {
+        HIPCHK(it.d->ensure(it.bytes + 64));      // +64: string kernels may look one byte past a name
+        if (it.bytes) HIPCHK(hipMemcpyAsync(it.d->p, it.src, it.bytes, hipMemcpyHostToDevice, e->stream));
+        *it.dst = it.bytes ? it.d->p : nullptr;
+    }
+    if (!e->have_mi) { e->dev_batch.mi = nullptr; e->dev_batch.mi_off = nullptr; }
+    e->dev_batch.n_reads = (int64_t)e->h_core.size();
+    e->dev_batch.qname_bytes = e->h_qname.size(); e->dev_batch.cigar_words = e->h_cigar.size();
+    e->dev_batch.seq_bytes = e->h_seq.size(); e->dev_batch.qual_bytes = e->h_qual.size(); e->dev_batch.mi_bytes = e->h_mi.size();
+    if (e->h_cigar.empty()) e->dev_batch.cigar = e->b_cigar.as<uint32_t>();
+    return GCE_OK;
+}
+
+static int read_si(gce_engine *e) {
+    HIPCHK(hipMemcpyAsync(&e->h_si, e->si.p, sizeof(StreamInfo), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GCE_OK;
+}
+
+static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Every clusterByUMI of the stream (src/gencore.cpp:355 periodic, :409 end of file) + outputPair bookkeeping.
+int gce_process(gce_engine *e) {
+    if (!e) return GCE_ERR_INVALID;
+    if (!e->host_mode && !e->device_mode) return fail(e, GCE_ERR_INVALID, "nothing submitted");
+    (void)hipSetDevice(e->prm.device);
+    int rc;
+    if (e->host_mode && (rc = upload(e)) != GCE_OK) return rc;
+    const gce_batch &hb = e->dev_batch;
+    const int64_t N = hb.n_reads;
+    e->n = N;
+    e->processed = true;
+    memset(&e->timing, 0, sizeof e->timing);
+    memset(&e->h_si, 0, sizeof e->h_si);
+    if (N >= (int64_t)0xFFFFFFF0ll) return fail(e, GCE_ERR_INVALID, "more than 2^32 reads in one engine");
+    const size_t n1 = (size_t)(N > 0 ? N : 1);
+
+    DevBatch b{}; b.n = N; b.core = hb.core; b.qname_off = hb.qname_off; b.qname = hb.qname; b.cigar_off = hb.cigar_off; b.cigar = hb.cigar;
+    b.seq_off = hb.seq_off; b.seq = hb.seq; b.qual_off = hb.qual_off; b.qual = hb.qual; b.nm = hb.nm; b.nm_type = hb.nm_type;
+    b.mi_off = hb.mi_off; b.mi = hb.mi;
+
+    // reference + params to the device
+    const int nref = (int)e->ref_ptr.size();
+    HIPCHK(e->d_ref_ptr.ensure((size_t)(nref + 1) * 8)); HIPCHK(e->d_ref_len.ensure((size_t)(nref + 1) * 8));
+    if (nref) {
+        HIPCHK(hipMemcpyAsync(e->d_ref_ptr.p, e->ref_ptr.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_ref_len.p, e->ref_len.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(e->d_target_len.ensure(e->target_len.size() * 4 + 4));
+    if (!e->target_len.empty()) HIPCHK(hipMemcpyAsync(e->d_target_len.p, e->target_len.data(), e->target_len.size() * 4, hipMemcpyHostToDevice, e->stream));
+    DevParams p{};
+    p.proper_thr = e->prm.proper_umi_diff_threshold; p.unproper_thr = e->prm.unproper_umi_diff_threshold;
+    p.duplex_mismatch_thr = e->prm.duplex_mismatch_threshold; p.cluster_size_req = e->prm.cluster_size_req; p.base_score_req = e->prm.base_score_req;
+    p.high_q = e->prm.high_quality; p.moderate_q = e->prm.moderate_quality; p.low_q = e->prm.low_quality;
+    p.s_high = e->prm.score_high; p.s_moderate = e->prm.score_moderate; p.s_low = e->prm.score_low; p.s_bad = e->prm.score_bad;
+    p.skip_low_complexity_thr = e->prm.skip_low_complexity_cluster_threshold; p.duplex_only = e->prm.duplex_only; p.disable_duplex = e->prm.disable_duplex;
+    p.period = e->prm.flush_period; p.score_percent_req = e->prm.score_percent_req;
+    memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
+    p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>();
+    p.tick_offset = e->prm.tick_offset; p.trailing_flush = e->prm.trailing_flush;
+    p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
+
+    // ---- allocations that only depend on N
+    Work w{};
+    const int64_t n_chunks = (N + CHUNK - 1) / CHUNK;
+    w.n_chunks = n_chunks;
+    const int64_t max_events = (p.tick_offset % p.period + N) / p.period + 2;
+    w.max_events = (int)max_events;
+    uint64_t T = 1024; while (T < 2 * (uint64_t)n1) T <<= 1;
+    w.tmask = T - 1;
+    const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
+#define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
+    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
+    ENS(out_flag, n1); ENS(qname_src, n1 * 4); ENS(nm_new, n1 * 4); ENS(fr, n1 * 2); ENS(rr, n1 * 2); ENS(mate, n1 * 4); ENS(out_index, n1 * 4);
+    ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
+    ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
+    ENS(table, T * 8); ENS(tcount, T * 4); ENS(toff, T * 4);
+    ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
+    ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4);
+    const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
+    ENS(scan_part, (size_t)(nblk_T > nblk_N ? nblk_T : nblk_N) * 8 + 8); ENS(si, sizeof(StreamInfo));
+    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>();
+    w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
+    w.out_flag = e->out_flag.as<uint8_t>(); w.qname_src = e->qname_src.as<uint32_t>(); w.nm_new = e->nm_new.as<int32_t>();
+    w.fr = e->fr.as<int16_t>(); w.rr = e->rr.as<int16_t>(); w.mate = e->mate.as<uint32_t>(); w.out_index = e->out_index.as<uint32_t>();
+    w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();
+    w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
+    w.table = e->table.as<uint64_t>(); w.tcount = e->tcount.as<uint32_t>(); w.toff = e->toff.as<uint32_t>();
+    w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
+    w.pu = e->pu.as<uint32_t>(); w.pg = e->pg.as<uint32_t>(); w.gpl = e->gpl.as<uint32_t>(); w.gpr = e->gpr.as<uint32_t>();
+    w.grp_begin = e->grp_begin.as<uint32_t>(); w.grp_n = e->grp_n.as<uint32_t>();
+    w.scan_part = e->scan_part.as<uint64_t>(); w.si = e->si.as<StreamInfo>();
+
+    StreamInfo init{}; init.first_unmapped = NONE32;
+    HIPCHK(hipMemcpyAsync(e->si.p, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->table.p, 0xFF, T * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->tcount.p, 0, T * 4, e->stream));
+    hipStream_t s = e->stream;
+    HIPCHK(hipEventRecord(e->ev[EV_START], s));
+    if (N > 0) {
+        // ---- prescan + tick scan + flush events
+        int cpb = (int)((n_chunks + 4095) / 4096); if (cpb < 1) cpb = 1;
+        hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
+        hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
+        hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
+    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)n_chunks), dim3(CHUNK), 0, s, b, p, w);
+    HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
+    // ---- bucket offsets + compact cluster list.  cl_* arrays are sized by N (a cluster has >= 1 read).
+    ENS(cl_slot, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);
+    w.cl_slot = e->cl_slot.as<uint32_t>(); w.cl_start = e->cl_start.as<uint32_t>(); w.cl_n = e->cl_n.as<uint32_t>();
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_T), dim3(256), 0, s, (const uint32_t *)w.tcount, (uint64_t)T, w.scan_part);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_T, &w.si->n_clusters, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_table_apply, dim3(nblk_T), dim3(256), 0, s, w, (uint64_t)T);
+    if (N > 0) hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, s, N, w);
+    HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
+    if ((rc = read_si(e)) != GCE_OK) return rc;
+    HIPCHK(hipGetLastError());
+    const uint32_t C = (uint32_t)e->h_si.n_clusters;
+    const size_t c1 = C ? C : 1;
+    ENS(cl_npairs, c1 * 4); ENS(cl_ngroups, c1 * 4); ENS(cl_gbase, c1 * 4); ENS(cl_nresult, c1 * 4); ENS(cl_hasumi, c1);
+    w.cl_npairs = e->cl_npairs.as<uint32_t>(); w.cl_ngroups = e->cl_ngroups.as<uint32_t>(); w.cl_gbase = e->cl_gbase.as<uint32_t>();
+    w.cl_nresult = e->cl_nresult.as<uint32_t>(); w.cl_hasumi = e->cl_hasumi.as<uint8_t>();
+    uint32_t NG = 0;
+    if (C > 0 && e->h_si.error == 0) {
+        hipLaunchKernelGGL(k_pairing, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+        const unsigned nblk_C = cdiv(C, SCAN_TILE);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, (uint64_t)C, w.scan_part);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_C, &w.si->n_pairs /*scratch*/, &w.si->n_groups);
+        hipLaunchKernelGGL(k_u32_apply, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, w.cl_gbase, (uint64_t)C, (const uint64_t *)w.scan_part);
+        HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
+        if ((rc = read_si(e)) != GCE_OK) return rc;
+        HIPCHK(hipGetLastError());
+        NG = (uint32_t)e->h_si.n_groups;
+    } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
+    const size_t g1 = NG ? NG : 1;
+    ENS(gl_cluster, g1 * 4); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
+    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
+    w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
+    w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
+    if (NG > 0 && e->h_si.error == 0) {
+        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
+        hipLaunchKernelGGL(k_score, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        hipLaunchKernelGGL(k_consensus, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
+        hipLaunchKernelGGL(k_finish, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+    } else { HIPCHK(hipEventRecord(e->ev[EV_SCORE], s)); HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s)); }
+    if (N > 0 && e->h_si.error == 0) {
+        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);
+        hipLaunchKernelGGL(k_flag_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, w.scan_part);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_out, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_flag_apply, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, (const uint64_t *)w.scan_part, w.out_index);
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
+    if ((rc = read_si(e)) != GCE_OK) return rc;
+    HIPCHK(hipGetLastError());
+    e->h_si.n_groups = NG;
+    float ms = 0;
+    auto el = [&](int a, int c) { ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[c]); return (double)ms; };
+    e->timing.total_ms = el(EV_START, EV_FINISH);
+    e->timing.prescan_ms = el(EV_START, EV_PRESCAN); e->timing.cluster_ms = el(EV_PRESCAN, EV_CLUSTER); e->timing.csr_ms = el(EV_CLUSTER, EV_CSR);
+    e->timing.pairing_ms = el(EV_CSR, EV_PAIRING); e->timing.score_ms = el(EV_PAIRING, EV_SCORE); e->timing.consensus_ms = el(EV_SCORE, EV_CONSENSUS);
+    e->timing.finish_ms = el(EV_CONSENSUS, EV_FINISH);
+    e->timing.n_clusters = C; e->timing.n_groups = NG; e->timing.n_pairs = 0;
+    if (e->h_si.error != 0) {
+        char buf[160]; snprintf(buf, sizeof buf, "%s (read %u)", gce_status_message(e->h_si.error), e->h_si.error_read);
+        return fail(e, e->h_si.error, buf);
+    }
+    return GCE_OK;
+}
+
+static void fill_stats(gce_stats *dst, const long long *src) { memcpy(dst, src, sizeof(gce_stats)); }
+
+int gce_result_device(gce_engine *e, gce_result *out) {
+    if (!e || !out || !e->processed) return GCE_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    out->n_reads = e->n; out->out_flag = e->out_flag.as<uint8_t>(); out->qname_src = e->qname_src.as<uint32_t>(); out->nm_new = e->nm_new.as<int32_t>();
+    out->fr = e->fr.as<int16_t>(); out->rr = e->rr.as<int16_t>(); out->mate = e->mate.as<uint32_t>();
+    out->seq = e->dev_batch.seq; out->qual = e->dev_batch.qual; out->n_out = (int64_t)e->h_si.n_out; out->out_index = e->out_index.as<uint32_t>();
+    fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
+    return GCE_OK;
+}
+
+// Draining csPairs into Gencore::outputPair (src/gencore.cpp:356-360,410-414): result table copied to host memory.
+int gce_drain(gce_engine *e, gce_result *out) {
+    if (!e || !out || !e->processed) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    const size_t n = (size_t)e->n;
+    e->r_flag.resize(n); e->r_qsrc.resize(n); e->r_nm.resize(n); e->r_fr.resize(n); e->r_rr.resize(n); e->r_mate.resize(n);
+    e->r_oidx.resize((size_t)e->h_si.n_out);
+    e->r_seq.resize(e->dev_batch.seq_bytes); e->r_qual.resize(e->dev_batch.qual_bytes);
+    hipStream_t s = e->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(e->r_flag.data(), e->out_flag.p, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_qsrc.data(), e->qname_src.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_nm.data(), e->nm_new.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_fr.data(), e->fr.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_rr.data(), e->rr.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_mate.data(), e->mate.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (!e->r_oidx.empty()) HIPCHK(hipMemcpyAsync(e->r_oidx.data(), e->out_index.p, e->r_oidx.size() * 4, hipMemcpyDeviceToHost, s));
+        if (!e->r_seq.empty()) HIPCHK(hipMemcpyAsync(e->r_seq.data(), e->dev_batch.seq, e->r_seq.size(), hipMemcpyDeviceToHost, s));
+        if (!e->r_qual.empty()) HIPCHK(hipMemcpyAsync(e->r_qual.data(), e->dev_batch.qual, e->r_qual.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    memset(out, 0, sizeof *out);
+    out->n_reads = e->n; out->out_flag = e->r_flag.data(); out->qname_src = e->r_qsrc.data(); out->nm_new = e->r_nm.data();
+    out->fr = e->r_fr.data(); out->rr = e->r_rr.data(); out->mate = e->r_mate.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
+    out->n_out = (int64_t)e->h_si.n_out; out->out_index = e->r_oidx.data();
+    fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
+    return GCE_OK;
+}
+
+int gce_get_timing(gce_engine *e, gce_timing *out) {
+    if (!e || !out) return GCE_ERR_INVALID;
+    *out = e->timing;
+    return GCE_OK;
+}
+
+}  // extern "C"

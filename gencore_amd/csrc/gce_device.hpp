@@ -1,0 +1,297 @@
+// gce_device.hpp — device-side data views and scalar helpers of the MI355X consensus engine.
+// gfx950 only (wave64).  Reference citations are relative to /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gencore_amd.h"
+
+#define GCE_WAVE 64
+#define NONE32 0xFFFFFFFFu
+#define EMPTY64 0xFFFFFFFFFFFFFFFFull
+
+// thr_mode of a cluster instance (quirks Q1/Q2)
+enum : uint32_t { THR_PROPER = 0, THR_UNPROPER = 1, THR_NEVER = 2 };
+// read class
+enum : uint8_t { CLS_DROP = 0, CLS_CLUSTERED = 1, CLS_BYPASS = 2 };
+
+struct DevBatch {
+    int64_t n;
+    const gce_core *core;
+    const uint64_t *qname_off; const char *qname;
+    const uint64_t *cigar_off; const uint32_t *cigar;
+    const uint64_t *seq_off;   uint8_t *seq;
+    const uint64_t *qual_off;  uint8_t *qual;
+    const int32_t *nm; const uint8_t *nm_type;
+    const uint64_t *mi_off; const char *mi;
+};
+
+struct DevParams {
+    int32_t proper_thr, unproper_thr, duplex_mismatch_thr, cluster_size_req, base_score_req;
+    int32_t high_q, moderate_q, low_q;
+    int32_t s_high, s_moderate, s_low, s_bad;
+    int32_t skip_low_complexity_thr, duplex_only, disable_duplex, period;
+    double score_percent_req;
+    char prefix[32];
+    int32_t prefix_len;
+    int32_t n_targets;
+    const uint32_t *target_len;
+    int64_t tick_offset;
+    int32_t trailing_flush;
+    int32_t n_ref;
+    const uint8_t *const *ref_data;   // [n_ref] device pointers or nullptr
+    const int64_t *ref_len;           // [n_ref]
+};
+
+// stream-level scalars produced by the prescan (device resident)
+struct StreamInfo {
+    unsigned long long n_clustered;      // number of clustered reads (ticks)
+    unsigned int first_unmapped;         // index of the first unmapped read (U) or NONE32
+    int error;                           // first gce_status error raised on device (0 = none)
+    unsigned int error_read;
+    int n_events;                        // E: flush events inside this slice
+    int n_events_a;                      // E_A: events whose read index < U
+    unsigned long long n_clusters, n_groups, n_pairs, n_out;
+    long long pre[GCE_STATS_WORDS];
+    long long post[GCE_STATS_WORDS];
+};
+
+__device__ __forceinline__ void raise_error(StreamInfo *si, int code, uint32_t read) {
+    if (atomicCAS(&si->error, 0, code) == 0) si->error_read = read;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------------------------------- CIGAR
+__device__ __forceinline__ int cig_op(uint32_t w) { return (int)(w & 0xF); }
+__device__ __forceinline__ int cig_len(uint32_t w) { return (int)(w >> 4); }
+// bam_cigar_type bit0 = consumes query, bit1 = consumes reference; ops 10..15 consume nothing (bamutil.cpp:290-291)
+__device__ __forceinline__ int consumes_query(int op) { return (0x193 >> op) & 1; }   // M I S = X  -> bits 0,1,4,7,8
+__device__ __forceinline__ int consumes_ref(int op) { return (0x18D >> op) & 1; }     // M D N = X  -> bits 0,2,3,7,8
+
+// BamUtil::isPartOf (bamutil.cpp:204-255): op-by-op containment, from the end when right aligned.
+__device__ inline bool d_is_part_of(const uint32_t *part, int np, const uint32_t *whole, int nw, bool left) {
+    if (nw < np) return false;
+    for (int i = 0; i < np; i++) {
+        uint32_t a = left ? part[i] : part[np - 1 - i];
+        uint32_t b = left ? whole[i] : whole[nw - 1 - i];
+        if (cig_op(a) != cig_op(b)) return false;
+        int la = cig_len(a), lb = cig_len(b);
+        if (la > lb) return false;
+        if (la < lb && i != np - 1) {
+            if (i != np - 2) return false;
+            uint32_t nx = left ? part[i + 1] : part[np - 2 - i];
+            if (cig_op(nx) != 5 /*H*/) return false;
+        }
+    }
+    return true;
+}
+
+// BamUtil::getRefOffset (bamutil.cpp:293-314)
+__device__ inline int d_ref_offset(const uint32_t *cig, int n, int qpos) {
+    int ref = 0, query = 0;
+    for (int i = 0; i < n; i++) {
+        int op = cig_op(cig[i]), len = cig_len(cig[i]);
+        int cq = consumes_query(op), cr = consumes_ref(op);
+        query += len * cq;
+        ref += len * cr;
+        if (query > qpos) {
+            if (op == 1 || op == 4) return -1;           // inside I or S
+            return ref - cr * (query - qpos);
+        }
+    }
+    return -1;
+}
+
+// BamUtil::getMOffsetAndLen (bamutil.cpp:316-336): first M block only
+__device__ inline void d_first_m(const uint32_t *cig, int n, int &off, int &len) {
+    int query = 0;
+    for (int i = 0; i < n; i++) {
+        int op = cig_op(cig[i]), l = cig_len(cig[i]);
+        if (op == 0) { off = query; len = l; return; }
+        query += l * consumes_query(op);
+    }
+    off = 0; len = 0;
+}
+
+// bam_cigar2rlen (used by BamUtil::getRightRefPos, bamutil.cpp:379-383)
+__device__ inline int d_cigar_rlen(const uint32_t *cig, int n) {
+    int l = 0;
+    for (int i = 0; i < n; i++) l += cig_len(cig[i]) * consumes_ref(cig_op(cig[i]));
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------------- bases
+__device__ __forceinline__ int d_nib(const uint8_t *s, int i) {
+    uint8_t b = s[i >> 1];
+    return (i & 1) ? (b & 0xF) : (b >> 4);
+}
+// BamUtil::fourbits2base collapsed to an equivalence class: 1,2,4,8 keep their identity, everything else is 'N'
+// (bamutil.cpp:148-165).  Two nibbles decode to the same char iff their classes are equal.
+__device__ __forceinline__ int d_base_class(int nib4) { return (nib4 == 1 || nib4 == 2 || nib4 == 4 || nib4 == 8) ? nib4 : 15; }
+
+// FastaReader::getBase (fastareader.cpp:122-128) folded with group.cpp:438-439 and BamUtil::base2fourbits:
+// returns the BAM nibble of the reference base (1,2,4,8) or 0 when the base is not A/T/C/G.
+__device__ __forceinline__ int d_ref_nib(const uint8_t *ref, int64_t pos) {
+    int b = ref[pos >> 1];
+    int code = (pos & 1) ? (b >> 4) : (b & 0xF);     // FASTA code: A=1,T=2,C=3,G=4
+    // -> BAM nibble: A=1, T=8, C=2, G=4
+    return code == 1 ? 1 : code == 2 ? 8 : code == 3 ? 2 : code == 4 ? 4 : 0;
+}
+
+// Pair::qual2score (pair.cpp:77-86)
+__device__ __forceinline__ int d_qual2score(const DevParams &p, int q) {
+    return q >= p.high_q ? p.s_high : q >= p.moderate_q ? p.s_moderate : q >= p.low_q ? p.s_low : p.s_bad;
+}
+
+// ---------------------------------------------------------------------------------------------------- UMI
+__device__ __forceinline__ bool d_is_umi_char(char c) { return c == 'A' || c == 'T' || c == 'C' || c == 'G' || c == '_'; }
+
+// BamUtil::getUMI(string, prefix) (bamutil.cpp:40-112).  Returns false where the reference throws.
+__device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start, int &len) {
+    int n = 0;
+    while (s[n]) n++;
+    start = 0; len = 0;
+    if (p.prefix_len > 0) {
+        int pos = -1;
+        for (int i = n - 1; i >= 0; i--) {
+            char c = s[i];
+            bool hit = false;
+            for (int k = 0; k < p.prefix_len; k++) hit |= (p.prefix[k] == c);
+            if (hit) { pos = i; break; }
+        }
+        if (pos < 0) return true;
+        int st = pos + 2;
+        if (st > n) return false;                      // substr(start) with start > size() throws
+        int l = 0;
+        while (st + l < n && d_is_umi_char(s[st + l])) l++;
+        start = st; len = l;
+        return true;
+    }
+    int sep = -1;
+    for (int i = n - 1; i >= 0; i--) if (s[i] == ':') { sep = i; break; }
+    if (sep < 0 || sep >= n - 1) return true;
+    int st = sep + 1;
+    if (st < n - 1 && s[st] == '_') st++;
+    int us = 0;
+    for (int i = st; i < n; i++) {
+        char c = s[i];
+        if (!d_is_umi_char(c)) return true;
+        if (c == '_' && ++us > 1) return true;
+    }
+    start = st; len = n - st;
+    return true;
+}
+
+// Cluster::umiDiff (cluster.cpp:41-53)
+__device__ inline int d_umi_diff(const char *a, int la, const char *b, int lb) {
+    int m = la < lb ? la : lb;
+    int d = la > lb ? la - lb : lb - la;
+    for (int i = 0; i < m; i++) d += (a[i] != b[i]);
+    return d;
+}
+__device__ inline bool d_bytes_equal(const char *a, int la, const char *b, int lb) {
+    if (la != lb) return false;
+    for (int i = 0; i < la; i++) if (a[i] != b[i]) return false;
+    return true;
+}
+// std::string operator< on slices
+__device__ inline int d_slice_cmp(const char *a, int la, const char *b, int lb) {
+    int m = la < lb ? la : lb;
+    for (int i = 0; i < m; i++) {
+        unsigned char x = (unsigned char)a[i], y = (unsigned char)b[i];
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return la - lb;
+}
+__device__ inline int d_strcmp(const char *a, const char *b) {
+    for (int i = 0;; i++) {
+        unsigned char x = (unsigned char)a[i], y = (unsigned char)b[i];
+        if (x != y) return x < y ? -1 : 1;
+        if (x == 0) return 0;
+    }
+}
+
+// util.h:59-88 split(str, "_") reduced to what Cluster::isDuplex (cluster.cpp:246-258) needs: the token count and
+// the first two tokens.  Leading underscores are skipped, every later '_' closes a token (possibly an empty one),
+// and a trailing '_' yields one more empty token.
+__device__ inline int d_split2(const char *s, int n, int &s0, int &l0, int &s1, int &l1) {
+    int i = 0;
+    while (i < n && s[i] == '_') i++;
+    if (i >= n) return 0;
+    int cnt = 0, ts = i;
+    s0 = l0 = s1 = l1 = 0;
+    for (;; ) {
+        int j = ts;
+        while (j < n && s[j] != '_') j++;
+        if (cnt == 0) { s0 = ts; l0 = j - ts; }
+        else if (cnt == 1) { s1 = ts; l1 = j - ts; }
+        cnt++;
+        if (j >= n) break;                               // no further separator
+        ts = j + 1;                                      // may equal n: one more, empty, token
+    }
+    return cnt;
+}
+__device__ inline bool d_is_duplex(const char *a, int la, const char *b, int lb) {
+    int a0, al0, a1, al1, b0, bl0, b1, bl1;
+    if (d_split2(a, la, a0, al0, a1, al1) != 2) return false;
+    if (d_split2(b, lb, b0, bl0, b1, bl1) != 2) return false;
+    return d_bytes_equal(a + a0, al0, b + b1, bl1) && d_bytes_equal(a + a1, al1, b + b0, bl0);
+}
+
+// ---------------------------------------------------------------------------------------------------- cluster key
+struct ClusterKey { int32_t tid, left; int64_t right; };
+
+// Gencore::addToProperCluster key derivation (gencore.cpp:295-312).  Returns the read class.
+__device__ __forceinline__ uint8_t d_classify(const gce_core &c) {
+    if (c.tid < 0 || c.pos < 0) return CLS_DROP;                      // unmapped: counted, then dropped (gencore.cpp:255-266)
+    if (c.flag & (0x100 | 0x800)) return CLS_DROP;                    // secondary / supplementary (gencore.cpp:269-271)
+    long long d = (long long)c.mpos - (long long)c.pos;
+    if (d < 0) d = -d;
+    if (c.mtid == c.tid && d < 100000) return CLS_CLUSTERED;
+    if (c.mtid < 0) return CLS_BYPASS;                                 // mate unmapped: written as is (gencore.cpp:307-309)
+    return CLS_CLUSTERED;
+}
+__device__ __forceinline__ ClusterKey d_key(const gce_core &c, const DevParams &p) {
+    ClusterKey k;
+    k.tid = c.tid; k.left = c.pos;
+    long long d = (long long)c.mpos - (long long)c.pos;
+    if (d < 0) d = -d;
+    if (c.mtid == c.tid && d < 100000) {
+        if (c.isize < 0) k.left = c.mpos;
+        long long a = c.isize; if (a < 0) a = -a;
+        k.right = (long long)k.left + a - 1;
+    } else {
+        long long tl = (c.tid < p.n_targets && p.target_len) ? (long long)p.target_len[c.tid] : 0;
+        k.right = -1LL * tl * (long long)(c.mtid + 1) + (long long)c.mpos;
+    }
+    return k;
+}
+__device__ __forceinline__ uint64_t d_key_hash(const ClusterKey &k, uint32_t inst) {
+    uint64_t h = (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)(uint32_t)k.left + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 31;
+    h ^= (uint64_t)k.right * 0x165667B19E3779F9ull;
+    h ^= (uint64_t)inst * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+
+// padded in-memory l_qname (htslib l_extranul)
+__device__ __forceinline__ int d_lqname_pad(const gce_core &c) { return ((int)c.l_qname + 3) & ~3; }
+
+// wave-level helpers
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {   // popcount of mask bits below this lane
+    return __popcll(mask & ((1ull << lane_id()) - 1ull));
+}

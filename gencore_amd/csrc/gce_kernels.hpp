@@ -1,0 +1,1057 @@
+// gce_kernels.hpp — HIP kernels of the MI355X consensus engine (gfx950, wave64).
+//
+// Pipeline (one gce_process call, everything resident in HBM):
+//   k_prescan      read classification, sortedness check, UMI slice, pre-Stats, per-chunk clustered counts
+//   k_scan_chunks  exclusive scan of the chunk counts -> tick of every clustered read
+//   k_events       locate the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
+//   k_cluster      THE CLUSTERING SCAN: key (tid,left,right,instance) -> hash partition -> (slot, rank) per read
+//   k_table_*      bucket offsets (exclusive scan over the table) + compact cluster list
+//   k_scatter      CSR fill: members[] per cluster
+//   k_pairing      per cluster: qname order, mate pairing (cluster.cpp:260-273), greedy UMI grouping (cluster.cpp:55-100)
+//   k_group_fill   compact (cluster, group) list
+//   k_score        per group: Pair::computeScore (pair.cpp:88-172) -> score bytes, quals mutated in place
+//   k_consensus    per group: template pick (group.cpp:136-318) + column vote (group.cpp:320-579), both sides
+//   k_finish       per cluster: duplex merge / filter / FR,RR tags (cluster.cpp:116-188, pair.cpp:43-68)
+//   k_stats        Stats reductions (stats.cpp:101-139)
+#pragma once
+#include "gce_device.hpp"
+
+#define CHUNK 256            // reads per prescan/cluster block
+#define WAVES_PER_BLOCK 4
+
+struct Work {
+    // per read
+    uint8_t *cls;
+    const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
+    uint32_t *slot, *rank;
+    int8_t *score;                       // parallel to qual
+    // outputs per read
+    uint8_t *out_flag; uint32_t *qname_src; int32_t *nm_new; int16_t *fr, *rr; uint32_t *mate;
+    uint32_t *out_index;
+    // tick scan
+    uint32_t *chunk_cnt, *chunk_base; int64_t n_chunks;
+    // events
+    int32_t *ev_tid, *ev_pos; uint32_t *ev_read; int max_events;
+    // hash table
+    uint64_t *table; uint32_t *tcount, *toff; uint64_t tmask;
+    // clusters
+    uint32_t *cl_slot, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
+    // cluster-local arrays (indexed by cl_start + k)
+    uint32_t *members, *sorted, *pl, *pr, *pu, *pg, *gpl, *gpr, *grp_begin, *grp_n;
+    // groups (compact)
+    uint32_t *gl_cluster;
+    uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
+    // generic scan scratch
+    uint64_t *scan_part;
+    StreamInfo *si;
+};
+
+enum : uint8_t { RP_PENDING = 0, RP_OUT_SSCS = 1, RP_OUT_DCS = 2, RP_DROPPED = 3, RP_CONSUMED = 4 };
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ long long wave_sum64(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ===================================================================================================== prescan
+__global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work w, int chunks_per_block) {
+    __shared__ unsigned int s_cnt[WAVES_PER_BLOCK];
+    __shared__ long long s_stat[WAVES_PER_BLOCK][6];
+    __shared__ unsigned int s_unm[WAVES_PER_BLOCK];
+    long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
+    unsigned int first_unm = NONE32;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (int cb = 0; cb < chunks_per_block; cb++) {
+        int64_t chunk = (int64_t)blockIdx.x * chunks_per_block + cb;
+        if (chunk >= w.n_chunks) break;
+        int64_t i = chunk * CHUNK + threadIdx.x;
+        uint8_t c = CLS_DROP;
+        if (i < b.n) {
+            gce_core k = b.core[i];
+            c = d_classify(k);
+            if (i > 0) {                                                       // gencore.cpp:233-241
+                int ptid = b.core[i - 1].tid, ppos = b.core[i - 1].pos;
+                if ((k.tid < ptid || (k.tid == ptid && k.pos < ppos)) && k.tid >= 0 && k.pos >= 0) raise_error(w.si, GCE_ERR_UNSORTED, (uint32_t)i);
+            }
+            bool mapped = k.tid >= 0;                                          // Stats::addRead, stats.cpp:101-121
+            int mism = (mapped && b.nm_type[i]) ? b.nm[i] : 0;
+            st[0] += 1; st[1] += k.l_qseq; st[4] += mism;
+            if (!mapped) { st[2] += 1; st[3] += k.l_qseq; }
+            if (mism > 0) st[5] += 1;
+            if (k.tid < 0 || k.pos < 0) { if ((unsigned)i < first_unm) first_unm = (unsigned)i; }
+            w.cls[i] = c;
+            w.out_flag[i] = (c == CLS_BYPASS) ? 2 : 0;
+            w.qname_src[i] = (uint32_t)i; w.nm_new[i] = -1; w.fr[i] = -1; w.rr[i] = -1; w.mate[i] = NONE32;
+            if (c == CLS_CLUSTERED) {                                          // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38
+                const char *src; uint8_t hm = 0;
+                if (b.mi && b.mi_off[i] != 0xFFFFFFFFFFFFFFFFull) { src = b.mi + b.mi_off[i]; hm = 1; }
+                else src = b.qname + b.qname_off[i];
+                int s0, l0;
+                if (!d_umi_slice(src, p, s0, l0)) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); s0 = 0; l0 = 0; }
+                w.umi_ptr[i] = src + s0; w.umi_len[i] = (uint16_t)l0; w.has_mi[i] = hm;
+            }
+        }
+        unsigned long long m = __ballot(c == CLS_CLUSTERED);
+        if (lane == 0) s_cnt[wv] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) w.chunk_cnt[chunk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    for (int k = 0; k < 6; k++) { long long v = wave_sum64(st[k]); if (lane == 0) s_stat[wv][k] = v; }
+    unsigned int fu = (unsigned)wave_min((int)(first_unm ^ 0x80000000u)) ^ 0x80000000u;   // unsigned min via signed flip
+    if (lane == 0) s_unm[wv] = fu;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        long long v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];
+        if (v) atomicAdd((unsigned long long *)&w.si->pre[threadIdx.x], (unsigned long long)v);
+    }
+    if (threadIdx.x == 0) {
+        unsigned int u = min(min(s_unm[0], s_unm[1]), min(s_unm[2], s_unm[3]));
+        if (u != NONE32) atomicMin(&w.si->first_unmapped, u);
+    }
+}
+
+// single-block exclusive scan of the chunk counts
+__global__ __launch_bounds__(1024) void k_scan_chunks(Work w, DevParams p) {
+    __shared__ unsigned int s_w[16];
+    __shared__ unsigned int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (int64_t base = 0; base < w.n_chunks; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        unsigned int v = i < w.n_chunks ? w.chunk_cnt[i] : 0, x = v;
+        for (int o = 1; o < 64; o <<= 1) { unsigned int t = __shfl_up(x, o); if (lane >= o) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        unsigned int woff = 0;
+        for (int k = 0; k < wv; k++) woff += s_w[k];
+        unsigned int carry = s_carry;
+        if (i < w.n_chunks) w.chunk_base[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long total = s_carry;
+        w.si->n_clustered = total;
+        long long per = p.period;
+        long long e = (p.tick_offset + (long long)total) / per - p.tick_offset / per;
+        w.si->n_events = (int)(e < w.max_events ? e : w.max_events);
+        if (e > w.max_events) raise_error(w.si, GCE_ERR_INVALID, 0);
+    }
+}
+
+// one thread per flush event: find the read on which tick % period == 0 (gencore.cpp:319-322)
+__global__ void k_events(DevBatch b, DevParams p, Work w) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;      // event j+1
+    int E = w.si->n_events;
+    if (j >= E) return;
+    long long per = p.period;
+    long long gt = (p.tick_offset / per + (j + 1)) * per;      // global tick of this event
+    unsigned int t = (unsigned int)(gt - p.tick_offset);       // local inclusive count, >= 1
+    int64_t lo = 0, hi = w.n_chunks - 1;                       // last chunk with chunk_base < t
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) >> 1;
+        if (w.chunk_base[mid] < t) lo = mid; else hi = mid - 1;
+    }
+    unsigned int run = w.chunk_base[lo];
+    int64_t i = lo * CHUNK, end = min(b.n, i + CHUNK);
+    for (; i < end; i++) { if (w.cls[i] == CLS_CLUSTERED && ++run == t) break; }
+    w.ev_read[j] = (uint32_t)i;
+    w.ev_tid[j] = b.core[i].tid;
+    w.ev_pos[j] = b.core[i].pos;
+    if ((uint32_t)i < w.si->first_unmapped) atomicAdd(&w.si->n_events_a, 1);
+}
+
+// ===================================================================================================== clustering scan
+// thr_mode of an instance (see DESIGN.md "flush rule in closed form")
+__device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *si, const DevParams &p) {
+    uint32_t inst = ikey & 0x7FFFFFFFu, seg_b = ikey >> 31;
+    if (!seg_b) {
+        if ((int)(inst + 1) <= si->n_events_a) return THR_PROPER;
+        if (si->first_unmapped != NONE32) return THR_UNPROPER;
+        return p.trailing_flush ? THR_PROPER : THR_UNPROPER;
+    }
+    return ((int)(inst + 1) <= si->n_events) ? THR_PROPER : THR_NEVER;
+}
+
+__global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
+    __shared__ unsigned int s_cnt[WAVES_PER_BLOCK];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int64_t i = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    bool cl = false;
+    gce_core k;
+    if (i < b.n) {
+        k = b.core[i];
+        cl = d_classify(k) == CLS_CLUSTERED;
+    }
+    unsigned long long m = __ballot(cl);
+    if (lane == 0) s_cnt[wv] = __popcll(m);
+    __syncthreads();
+    if (i >= b.n) return;
+    if (!cl) { w.slot[i] = NONE32; return; }
+    unsigned int inblock = lanes_below(m) + 1;
+    for (int q = 0; q < wv; q++) inblock += s_cnt[q];
+    long long per = p.period;
+    long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x] + inblock;      // the reference's `tick` after ++
+    int e = (int)((tick - 1) / per - p.tick_offset / per);                              // flush events before this read
+    const StreamInfo *si = w.si;
+    unsigned int U = si->first_unmapped;
+    bool seg_b = (U != NONE32) && ((unsigned)i > U);
+    ClusterKey key = d_key(k, p);
+    // first event of this segment whose walk takes the key (gencore.cpp:333-354):
+    //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
+    int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
+    int a = lo, z = hi;
+    while (a < z) {
+        int mid = (a + z) >> 1;
+        int T = w.ev_tid[mid], P = w.ev_pos[mid];
+        bool cond = key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P);
+        if (cond) z = mid; else a = mid + 1;
+    }
+    int f = a + 1;                                                                      // 1-based; hi+1 if none
+    uint32_t inst = (uint32_t)max(e, f - 1);
+    uint32_t ikey = inst | (seg_b ? 0x80000000u : 0u);
+    uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
+    uint64_t h = d_key_hash(key, ikey) & w.tmask;
+    for (;;) {
+        uint64_t cur = w.table[h];
+        if (cur == EMPTY64) {
+            cur = atomicCAS((unsigned long long *)&w.table[h], (unsigned long long)EMPTY64, (unsigned long long)mine);
+            if (cur == EMPTY64) break;                                                  // claimed: this read owns the bucket
+        }
+        if ((uint32_t)(cur >> 32) == ikey) {
+            gce_core oc = b.core[(uint32_t)cur];
+            ClusterKey ok = d_key(oc, p);
+            if (ok.tid == key.tid && ok.left == key.left && ok.right == key.right) break;
+        }
+        h = (h + 1) & w.tmask;
+    }
+    w.slot[i] = (uint32_t)h;
+    w.rank[i] = atomicAdd(&w.tcount[h], 1u);
+}
+
+// ===================================================================================================== table scan (3 phases)
+// element(h) = (count>0) << 32 | count ; exclusive scan gives (cluster id, member offset)
+#define SCAN_TILE 2048
+__device__ __forceinline__ uint64_t tab_elem(const uint32_t *cnt, uint64_t h, uint64_t n) {
+    if (h >= n) return 0;
+    uint32_t c = cnt[h];
+    return ((uint64_t)(c > 0) << 32) | c;
+}
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *cnt, uint64_t n, uint64_t *part) {
+    __shared__ uint64_t s[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE, v = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) v += tab_elem(cnt, base + k * 256 + threadIdx.x, n);
+    v = (uint64_t)wave_sum64((long long)v);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_partials(uint64_t *part, uint64_t nparts, unsigned long long *total_hi, unsigned long long *total_lo) {
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (uint64_t base = 0; base < nparts; base += 1024) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < nparts ? part[i] : 0, x = v;
+        for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int k = 0; k < wv; k++) woff += s_w[k];
+        uint64_t carry = s_carry;
+        if (i < nparts) part[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *total_hi = s_carry >> 32; if (total_lo) *total_lo = s_carry & 0xFFFFFFFFull; }
+}
+__global__ __launch_bounds__(256) void k_table_apply(Work w, uint64_t n) {
+    __shared__ uint64_t s_w[4];
+    __shared__ uint64_t s_carry;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = w.scan_part[blockIdx.x];
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        uint64_t h = base + k * 256 + threadIdx.x;
+        uint64_t v = tab_elem(w.tcount, h, n), x = v;
+        for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        uint64_t carry = s_carry;
+        uint64_t ex = carry + woff + x - v;
+        if (h < n) {
+            uint32_t c = (uint32_t)v;
+            w.toff[h] = (uint32_t)ex;
+            if (c) { uint32_t cid = (uint32_t)(ex >> 32); w.cl_slot[cid] = (uint32_t)h; w.cl_start[cid] = (uint32_t)ex; w.cl_n[cid] = c; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__global__ void k_scatter(int64_t n, Work w) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = w.slot[i];
+    if (s == NONE32) return;
+    w.members[w.toff[s] + w.rank[i]] = (uint32_t)i;
+}
+
+// ===================================================================================================== pairing + UMI grouping
+__device__ __forceinline__ const char *d_qname(const DevBatch &b, uint32_t r) { return b.qname + b.qname_off[r]; }
+
+__global__ __launch_bounds__(256) void k_pairing(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+    const int lane = lane_id();
+    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (c >= n_clusters) return;
+    const uint32_t start = w.cl_start[c], n = w.cl_n[c];
+    uint64_t entry = w.table[w.cl_slot[c]];
+    uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
+    if (mode == THR_NEVER) {                      // pending after an early finishConsensus: never processed (gencore.cpp:23)
+        if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
+        return;
+    }
+    const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
+    // ---- (a) order the cluster's reads by (qname, input index): map<string,Pair*> order + arrival order (cluster.cpp:260-273)
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t i = base + lane;
+        if (i < n) {
+            uint32_t my = w.members[start + i];
+            const char *mq = d_qname(b, my);
+            uint32_t rk = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                uint32_t o = w.members[start + j];
+                if (o == my) continue;
+                int cmp = d_strcmp(d_qname(b, o), mq);
+                if (cmp < 0 || (cmp == 0 && o < my)) rk++;
+            }
+            w.sorted[start + rk] = my;
+        }
+    }
+    WAVE_SYNC();
+    // ---- (b) pairs: first read of a qname run = mLeft, last of the run (if any other) = mRight (pair.cpp:188-216)
+    uint32_t npairs = 0;
+    int any_umi = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t i = base + lane;
+        bool valid = i < n, first = false, last = false;
+        uint32_t q = NONE32;
+        if (valid) {
+            q = w.sorted[start + i];
+            const char *mq = d_qname(b, q);
+            first = (i == 0) || d_strcmp(d_qname(b, w.sorted[start + i - 1]), mq) != 0;
+            last = (i == n - 1) || d_strcmp(d_qname(b, w.sorted[start + i + 1]), mq) != 0;
+            if (!first) {       // setRight: `if(!mUMI.empty() && umi!=mUMI) error_exit` (pair.cpp:201-212)
+                uint32_t pv = w.sorted[start + i - 1];
+                if (w.umi_len[pv] != 0 && !d_bytes_equal(w.umi_ptr[pv], w.umi_len[pv], w.umi_ptr[q], w.umi_len[q])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
+            }
+        }
+        unsigned long long fm = __ballot(first);
+        uint32_t pidx = npairs + __popcll(fm & ((2ull << lane) - 1ull)) - 1;      // firsts up to and including this lane
+        if (valid) {
+            if (first) { w.pl[start + pidx] = q; if (last) w.pr[start + pidx] = NONE32; }
+            if (last && !first) w.pr[start + pidx] = q;
+            if (last) { w.pu[start + pidx] = q; if (w.umi_len[q]) any_umi = 1; }
+        }
+        npairs += __popcll(fm);
+    }
+    any_umi = __any(any_umi);
+    WAVE_SYNC();
+    // ---- (c) greedy UMI grouping (cluster.cpp:57-100)
+    uint32_t ngroups = 0;
+    if (!any_umi) {
+        for (uint32_t i = lane; i < npairs; i += 64) w.pg[start + i] = 0;
+        ngroups = 1;
+    } else {
+        uint32_t *pc = w.sorted;                 // reuse: per-pair count of identical UMIs (umiCount)
+        for (uint32_t i = lane; i < npairs; i += 64) {
+            uint32_t ui = w.pu[start + i];
+            const char *up = w.umi_ptr[ui]; int ul = w.umi_len[ui];
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < npairs; j++) { uint32_t uj = w.pu[start + j]; cnt += d_bytes_equal(up, ul, w.umi_ptr[uj], w.umi_len[uj]); }
+            pc[start + i] = cnt;
+            w.pg[start + i] = NONE32;
+        }
+        WAVE_SYNC();
+        uint32_t remaining = npairs;
+        while (remaining > 0) {
+            // top UMI: highest count, lexicographically first on ties (map order + strict `>`, cluster.cpp:68-76)
+            uint32_t best = NONE32, bcnt = 0; const char *bu = nullptr; int bl = 0;
+            for (uint32_t i = lane; i < npairs; i += 64) {
+                if (w.pg[start + i] != NONE32) continue;
+                uint32_t ui = w.pu[start + i], cnt = pc[start + i];
+                const char *up = w.umi_ptr[ui]; int ul = w.umi_len[ui];
+                bool better = best == NONE32 || cnt > bcnt || (cnt == bcnt && d_slice_cmp(up, ul, bu, bl) < 0);
+                if (better) { best = i; bcnt = cnt; bu = up; bl = ul; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                uint32_t ob = __shfl_xor(best, o), oc = __shfl_xor(bcnt, o);
+                if (ob == NONE32) continue;
+                uint32_t oui = w.pu[start + ob];
+                const char *ou = w.umi_ptr[oui]; int ol = w.umi_len[oui];
+                bool better;
+                if (best == NONE32) better = true;
+                else if (oc != bcnt) better = oc > bcnt;
+                else { int sc = d_slice_cmp(ou, ol, bu, bl); better = sc < 0 || (sc == 0 && ob < best); }
+                if (better) { best = ob; bcnt = oc; bu = ou; bl = ol; }
+            }
+            uint32_t absorbed = 0;
+            for (uint32_t base = 0; base < npairs; base += 64) {
+                uint32_t i = base + lane;
+                bool take = false;
+                if (i < npairs && w.pg[start + i] == NONE32) {
+                    uint32_t ui = w.pu[start + i];
+                    take = d_umi_diff(w.umi_ptr[ui], w.umi_len[ui], bu, bl) <= thr;
+                    if (take) w.pg[start + i] = ngroups;
+                }
+                absorbed += __popcll(__ballot(take));
+            }
+            remaining -= absorbed;
+            ngroups++;
+            WAVE_SYNC();
+        }
+    }
+    WAVE_SYNC();
+    // ---- (d) lay the pairs out group by group, qname order kept inside a group (Group::addPair, group.cpp:17-22)
+    uint32_t gbase = 0;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < npairs; base += 64) {
+            uint32_t i = base + lane;
+            bool in = i < npairs && w.pg[start + i] == g;
+            unsigned long long m = __ballot(in);
+            if (in) { uint32_t d = start + gbase + run + lanes_below(m); w.gpl[d] = w.pl[start + i]; w.gpr[d] = w.pr[start + i]; }
+            run += __popcll(m);
+        }
+        if (lane == 0) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
+        gbase += run;
+    }
+    if (lane == 0) { w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)any_umi; }
+}
+
+// exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word
+__global__ void k_group_fill(Work w, uint32_t n_clusters) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    uint32_t g0 = w.cl_gbase[c], ng = w.cl_ngroups[c];
+    for (uint32_t g = 0; g < ng; g++) w.gl_cluster[g0 + g] = c;
+}
+// scan of cl_ngroups -> cl_gbase : same 3-phase scheme on the plain counts
+__global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t *out, uint64_t n, const uint64_t *part) {
+    __shared__ uint64_t s_w[4];
+    __shared__ uint64_t s_carry;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = part[blockIdx.x];
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        uint64_t h = base + k * 256 + threadIdx.x;
+        uint64_t v = tab_elem(in, h, n), x = v;
+        for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        uint64_t carry = s_carry;
+        if (h < n) out[h] = (uint32_t)(carry + woff + x - v);
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+// ===================================================================================================== scoring
+// Pair::computeScore for every pair of a group that enters consensusMerge beyond the early return (group.cpp:73-77).
+__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+    const int lane = lane_id();
+    uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (gi >= n_groups) return;
+    uint32_t c = w.gl_cluster[gi];
+    uint32_t g = gi - w.cl_gbase[c];
+    uint32_t begin = w.grp_begin[w.cl_start[c] + g], np = w.grp_n[w.cl_start[c] + g];
+    if (np == 1 && w.gpr[begin] == NONE32) return;
+    for (uint32_t k = 0; k < np; k++) {
+        uint32_t L = w.gpl[begin + k], R = w.gpr[begin + k];
+        gce_core lk = b.core[L];
+        int8_t *ls = w.score + b.qual_off[L];
+        if (R == NONE32) { for (int i = lane; i < lk.l_qseq; i += 64) ls[i] = (int8_t)p.s_moderate; continue; }   // pair.cpp:89-105 (memset only)
+        gce_core rk = b.core[R];
+        int8_t *rs = w.score + b.qual_off[R];
+        int lmo, lml, rmo, rml;
+        d_first_m(b.cigar + b.cigar_off[L], lk.n_cigar, lmo, lml);
+        d_first_m(b.cigar + b.cigar_off[R], rk.n_cigar, rmo, rml);
+        if (!(lml > 0 && rml > 0)) {
+            for (int i = lane; i < lk.l_qseq; i += 64) ls[i] = (int8_t)p.s_moderate;
+            for (int i = lane; i < rk.l_qseq; i += 64) rs[i] = (int8_t)p.s_moderate;
+            continue;
+        }
+        int dis = rk.pos - lk.pos, lstart, rstart, cmp;
+        if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
+        else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
+        const uint8_t *lseq = b.seq + b.seq_off[L], *rseq = b.seq + b.seq_off[R];
+        uint8_t *lq = b.qual + b.qual_off[L], *rq = b.qual + b.qual_off[R];
+        for (int l = lane; l < lk.l_qseq; l += 64) {
+            int ql = lq[l];
+            if (l >= lstart && l < lstart + cmp) {
+                int r = rstart + (l - lstart);
+                int qr = rq[r];
+                if (d_nib(lseq, l) == d_nib(rseq, r)) {                   // pair.cpp:148-154
+                    int s = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4;
+                    ls[l] = (int8_t)s; rs[r] = (int8_t)s;
+                } else {                                                   // pair.cpp:155-168: quals rewritten in place
+                    lq[l] = (uint8_t)max(0, ql - qr);
+                    rq[r] = (uint8_t)max(0, qr - ql);
+                    if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3); rs[r] = 0; }
+                    else { ls[l] = 0; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3); }
+                }
+            } else ls[l] = (int8_t)d_qual2score(p, ql);
+        }
+        for (int r = lane; r < rk.l_qseq; r += 64)
+            if (!(r >= rstart && r < rstart + cmp)) rs[r] = (int8_t)d_qual2score(p, rq[r]);
+    }
+}
+
+// ===================================================================================================== consensus
+struct VoteCtx {
+    const DevBatch *b; const DevParams *p; const Work *w;
+    uint32_t out, nv, vbase; bool left_mode;
+    int len; const uint8_t *ref; int64_t ref_len;
+    const uint32_t *ocig; int oncig; int opos;
+    uint32_t *tally;      // lane-private LDS: word (bin*3+k)*64
+};
+struct ColResult { int base, qual, new_base_written, minc, diff; };
+
+// One column of Group::makeConsensus (group.cpp:369-526) for column `col` of the template.
+__device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base, int lane) {
+    const DevBatch &b = *v.b; const DevParams &p = *v.p; const Work &w = *v.w;
+    uint32_t *t = v.tally + lane;
+#pragma unroll
+    for (int k = 0; k < 48; k++) t[k * 64] = 0;
+    int total = 0;
+    for (uint32_t q = 0; q < v.nv; q++) {
+        uint32_t r = w.pl[v.vbase + q];                  // voter list (scratch)
+        int ld = (int)w.pr[v.vbase + q];
+        int rl = b.core[r].l_qseq;
+        int rp = v.left_mode ? col : col + ld;
+        if (rp < 0 || rp >= rl) continue;                // out of range is UB in the reference; skipped (same as oracle)
+        uint64_t qo = b.qual_off[r];
+        int base = d_nib(b.seq + b.seq_off[r], rp);
+        int qu = b.qual[qo + rp];
+        int sc = w.score[qo + rp];
+        uint32_t t0 = t[(base * 3) * 64];
+        uint32_t cnt = (t0 & 0xFFFF) + 1, tq = t0 >> 16;
+        if ((uint32_t)qu > tq) tq = qu;
+        t[(base * 3) * 64] = cnt | (tq << 16);
+        t[(base * 3 + 1) * 64] += (uint32_t)sc;
+        t[(base * 3 + 2) * 64] += (uint32_t)qu;
+        total += sc;
+    }
+    // top / second base: lexicographic max of (score, sum of quals), the LATER bin wins ties (group.cpp:394-416, quirk Q6)
+    int top = 0, top_s = -0x7FFFFFFF, top_q = 0;
+    for (int bb = 0; bb < 16; bb++) {
+        int s = (int)t[(bb * 3 + 1) * 64], qs = (int)t[(bb * 3 + 2) * 64];
+        if (s > top_s || (s == top_s && qs >= top_q)) { top_s = s; top = bb; top_q = qs; }
+    }
+    int sec = 0, sec_s = -0x7FFFFFFF, sec_q = (int)t[2 * 64];     // quals[secBase] with secBase initially 0
+    for (int bb = 0; bb < 16; bb++) {
+        if (bb == top) continue;
+        int s = (int)t[(bb * 3 + 1) * 64], qs = (int)t[(bb * 3 + 2) * 64];
+        if (s > sec_s || (s == sec_s && qs >= sec_q)) { sec_s = s; sec = bb; sec_q = qs; }
+    }
+    uint32_t tt = t[(top * 3) * 64];
+    int top_num = tt & 0xFFFF, top_qual = tt >> 16;
+    int sec_num = t[(sec * 3) * 64] & 0xFFFF;
+    sec_q = (int)t[(sec * 3 + 2) * 64];
+    ColResult res; res.minc = 0; res.diff = 0; res.new_base_written = 0; res.base = out_base;
+    bool need = false;
+    if (sec_num == 0) {                                                       // group.cpp:421-428
+        if (top_s >= p.base_score_req && top_qual >= p.moderate_q) { res.qual = top_qual; return res; }
+        need = true;
+    }
+    int ref4 = 0;                                                             // group.cpp:430-439
+    if (v.ref) {
+        int ro = d_ref_offset(v.ocig, v.oncig, col);
+        if (ro >= 0 && (int64_t)v.opos + ro < v.ref_len) ref4 = d_ref_nib(v.ref, (int64_t)v.opos + ro);
+    }
+    if (sec_num == 1) {                                                       // group.cpp:442-457
+        if (sec_q <= p.low_q) { if (top_num < 2 && top_qual < p.high_q) need = true; }
+        else { if (top_num < 3 || top_qual < p.high_q) need = true; }
+    }
+    if (sec_num > 1) {                                                        // group.cpp:460-464 (double, quirk Q12)
+        if ((double)top_s < p.score_percent_req * (double)total || top_qual < p.moderate_q) need = true;
+    }
+    if (top_s < p.base_score_req || top_qual <= p.low_q) need = true;         // group.cpp:466-467
+    if (need && ref4 != 0) {                                                  // group.cpp:470-501
+        int rbq = 0;                                                          // `char refBaseQual`
+        for (uint32_t q = 0; q < v.nv; q++) {
+            uint32_t r = w.pl[v.vbase + q];
+            int ld = (int)w.pr[v.vbase + q];
+            int rl = b.core[r].l_qseq;
+            int rp = v.left_mode ? col : col + ld;
+            if (rp < 0 || rp >= rl) continue;
+            int base = d_nib(b.seq + b.seq_off[r], rp);
+            int qu = b.qual[b.qual_off[r] + rp];
+            if (base == ref4) {
+                if (qu > rbq) rbq = (int)(int8_t)qu;
+                if (qu >= p.high_q) top = ref4;
+            }
+        }
+        if (top_qual < p.moderate_q) top = ref4;
+        if (top == ref4) top_qual = rbq & 0xFF;
+    }
+    if (out_base != top) {                                                    // group.cpp:503-524
+        res.base = top; res.new_base_written = 1; res.diff = 1;
+        if (ref4 != 0) { if (out_base == ref4) res.minc = 1; else if (top == ref4) res.minc = -1; }
+    }
+    res.qual = top_qual;
+    return res;
+}
+
+// Group::consensusMergeBam for one side (group.cpp:136-318).  Returns the template read or NONE32.
+// Scratch (cluster-local arrays that are dead after k_pairing): sorted = containedBy, pl = voters, pr = lenDiff.
+__device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left,
+                                   uint32_t *tally, int lane) {
+    const uint32_t *side = is_left ? w.gpl : w.gpr;
+    // ---- low-complexity skip for very deep groups (group.cpp:142-175)
+    if ((int)np > p.skip_low_complexity_thr) {
+        int distinct = 0; uint32_t first = NONE32;
+        for (uint32_t base = 0; base < np; base += 64) {
+            uint32_t k = base + lane;
+            bool uniq = false; uint32_t rd = NONE32;
+            if (k < np && (rd = side[begin + k]) != NONE32) {
+                uniq = true;
+                int nc = b.core[rd].n_cigar; const uint32_t *cg = b.cigar + b.cigar_off[rd];
+                for (uint32_t j = 0; j < k && uniq; j++) {
+                    uint32_t o = side[begin + j];
+                    if (o == NONE32 || b.core[o].n_cigar != nc) continue;
+                    const uint32_t *og = b.cigar + b.cigar_off[o];
+                    bool same = true;
+                    for (int x = 0; x < nc; x++) same &= (og[x] == cg[x]);
+                    if (same) uniq = false;
+                }
+            }
+            unsigned long long has = __ballot(rd != NONE32);
+            if (first == NONE32 && has) first = side[begin + base + (__ffsll((long long)has) - 1)];
+            distinct += __popcll(__ballot(uniq));
+        }
+        if ((double)distinct > (double)np * 0.1 && first != NONE32) {
+            int n = b.core[first].l_qseq, dn = 0;
+            const uint8_t *s = b.seq + b.seq_off[first];
+            for (int i = lane; i < n - 1; i += 64) dn += d_base_class(d_nib(s, i)) != d_base_class(d_nib(s, i + 1));
+            dn = wave_sum(dn);
+            if ((double)dn < (double)n * 0.5) return NONE32;
+        }
+    }
+    // ---- leftReadMode (group.cpp:177-194)
+    bool left_mode = is_left;
+    if (!is_left) {
+        int mn = 0x7FFFFFFF, mx = -1;
+        for (uint32_t k = lane; k < np; k += 64) { uint32_t rd = side[begin + k]; if (rd != NONE32) { int ps = b.core[rd].pos; mn = min(mn, ps); mx = max(mx, ps); } }
+        mn = wave_min(mn); mx = wave_max(mx);
+        if (mx < 0 || mn == mx) left_mode = true;
+    }
+    // ---- containedBy (group.cpp:196-233)
+    uint32_t *contained = w.sorted;
+    for (uint32_t base = 0; base < np; base += 64) {
+        uint32_t k = base + lane;
+        if (k < np) {
+            uint32_t part = side[begin + k];
+            uint32_t cb = 0;
+            if (part != NONE32) {
+                cb = 1;
+                gce_core pk = b.core[part]; const uint32_t *pc = b.cigar + b.cigar_off[part];
+                int prr = is_left ? 0 : pk.pos + d_cigar_rlen(pc, pk.n_cigar);
+                for (uint32_t j = 0; j < np; j++) {
+                    if (j == k) continue;
+                    uint32_t whole = side[begin + j];
+                    if (whole == NONE32) continue;
+                    gce_core wk = b.core[whole]; const uint32_t *wc = b.cigar + b.cigar_off[whole];
+                    if (!is_left && prr != wk.pos + d_cigar_rlen(wc, wk.n_cigar)) continue;
+                    if (d_is_part_of(pc, pk.n_cigar, wc, wk.n_cigar, left_mode)) cb++;
+                }
+            }
+            contained[begin + k] = cb;
+        }
+    }
+    WAVE_SYNC();
+    if ((int)np > p.skip_low_complexity_thr) {                 // the early `break` at group.cpp:231-232: later entries stay 0
+        uint32_t stop = NONE32;
+        for (uint32_t base = 0; base < np && stop == NONE32; base += 64) {
+            uint32_t k = base + lane;
+            unsigned long long m = __ballot(k < np && contained[begin + k] >= np / 2);
+            if (m) stop = base + (__ffsll((long long)m) - 1);
+        }
+        if (stop != NONE32) for (uint32_t k = stop + 1 + lane; k < np; k += 64) contained[begin + k] = 0;
+        WAVE_SYNC();
+    }
+    // ---- template = max containedBy, then shorter read, then first in qname order (group.cpp:235-261)
+    uint32_t best = NONE32; int bc = -1, blen = 0;
+    for (uint32_t k = lane; k < np; k += 64) {
+        int cb = (int)contained[begin + k];
+        uint32_t rd = side[begin + k];
+        int ln = rd != NONE32 ? b.core[rd].l_qseq : 0;
+        if (best == NONE32 || cb > bc || (cb == bc && ln < blen)) { best = k; bc = cb; blen = ln; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t ob = __shfl_xor(best, o); int oc = __shfl_xor(bc, o), ol = __shfl_xor(blen, o);
+        if (ob == NONE32) continue;
+        bool better = best == NONE32 || oc > bc || (oc == bc && (ol < blen || (ol == blen && ob < best)));
+        if (better) { best = ob; bc = oc; blen = ol; }
+    }
+    if ((double)bc < (double)np * 0.4 && np != 1) return NONE32;            // group.cpp:264-266
+    uint32_t out = side[begin + best];
+    if (out == NONE32) return NONE32;                                        // group.cpp:283-285
+    gce_core ok = b.core[out];
+    const uint32_t *ocig = b.cigar + b.cigar_off[out];
+    // ---- voters: template + every read the template is part of (group.cpp:287-313); lenDiff (group.cpp:339-348)
+    WAVE_SYNC();
+    uint32_t nv = 1;
+    if (lane == 0) { w.pl[begin] = out; w.pr[begin] = 0; }
+    for (uint32_t base = 0; base < np; base += 64) {
+        uint32_t j = base + lane;
+        bool take = false; uint32_t rd = NONE32; int ld = 0;
+        if (j < np && j != best && (rd = side[begin + j]) != NONE32) {
+            gce_core rk = b.core[rd]; const uint32_t *rc = b.cigar + b.cigar_off[rd];
+            take = d_is_part_of(ocig, ok.n_cigar, rc, rk.n_cigar, left_mode);
+            if (take) {
+                ld = rk.l_qseq - ok.l_qseq;
+                if (ld != 0 && rk.pos == ok.pos && d_is_part_of(ocig, ok.n_cigar, rc, rk.n_cigar, true)) ld = 0;
+            }
+        }
+        unsigned long long m = __ballot(take);
+        // NOTE: voters overwrite w.pl/w.pr at [begin+1 ...]; the source arrays here are gpl/gpr (distinct buffers)
+        if (take) { uint32_t d = begin + nv + lanes_below(m); w.pl[d] = rd; w.pr[d] = (uint32_t)ld; }
+        nv += __popcll(m);
+    }
+    WAVE_SYNC();
+    // ---- Group::makeConsensus (group.cpp:320-579)
+    int len = ok.l_qseq;
+    if (ok.n_cigar == 0) {                                                    // group.cpp:354-360
+        int mn = len;
+        for (uint32_t q = lane; q < nv; q += 64) mn = min(mn, b.core[w.pl[begin + q]].l_qseq);
+        len = wave_min(mn);
+    }
+    VoteCtx v;
+    v.b = &b; v.p = &p; v.w = &w; v.out = out; v.nv = nv; v.vbase = begin; v.left_mode = left_mode; v.len = len;
+    v.ref = nullptr; v.ref_len = 0; v.ocig = ocig; v.oncig = ok.n_cigar; v.opos = ok.pos; v.tally = tally;
+    if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {                  // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
+        const uint8_t *rd = p.ref_data[ok.tid];
+        int64_t need_len = (int64_t)d_ref_offset(ocig, ok.n_cigar, len - 1) + 1;
+        if (rd && (int64_t)ok.pos + need_len < p.ref_len[ok.tid]) { v.ref = rd; v.ref_len = p.ref_len[ok.tid]; }
+    }
+    uint8_t *oseq = b.seq + b.seq_off[out], *oqual = b.qual + b.qual_off[out];
+    const int nbytes = (len + 1) >> 1;
+    int minc = 0;
+    if (nbytes <= 256) {
+        // fast path: every lane owns bytes lane, lane+64, ... (2 columns each); results buffered in registers so the
+        // `mismatchInc > 5` restore (group.cpp:537-558) is simply "do not write"
+        uint8_t nb[4]; uint8_t nq0[4], nq1[4]; bool act0[4], act1[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            int bi = it * 64 + lane, c0 = bi * 2, c1 = c0 + 1;
+            act0[it] = c0 < len; act1[it] = c1 < len;
+            nb[it] = 0; nq0[it] = 0; nq1[it] = 0;
+            if (it * 64 < nbytes) {           // wave-uniform
+                uint8_t ob = act0[it] ? oseq[bi] : 0;
+                int hi = ob >> 4, lo = ob & 0xF;
+                if (act0[it]) { ColResult r = vote_column(v, c0, hi, lane); hi = r.base; nq0[it] = (uint8_t)r.qual; minc += r.minc; }
+                if (act1[it]) { ColResult r = vote_column(v, c1, lo, lane); lo = r.base; nq1[it] = (uint8_t)r.qual; minc += r.minc; }
+                nb[it] = (uint8_t)((hi << 4) | lo);
+            }
+        }
+        minc = wave_sum(minc);
+        bool restore = false;
+        if (minc != 0) {                                                      // group.cpp:528-573
+            if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+            else if (minc > 5) restore = true;
+            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+        }
+        if (!restore) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                int bi = it * 64 + lane;
+                if (act0[it]) { oseq[bi] = nb[it]; oqual[bi * 2] = nq0[it]; }
+                if (act1[it]) oqual[bi * 2 + 1] = nq1[it];
+            }
+        }
+    } else {
+        // long templates: pass 1 counts mismatchInc without writing, pass 2 recomputes and writes
+        for (int bi = lane; bi < nbytes; bi += 64) {
+            uint8_t ob = oseq[bi];
+            int c0 = bi * 2, c1 = c0 + 1;
+            if (c0 < len) minc += vote_column(v, c0, ob >> 4, lane).minc;
+            if (c1 < len) minc += vote_column(v, c1, ob & 0xF, lane).minc;
+        }
+        minc = wave_sum(minc);
+        bool restore = false;
+        if (minc != 0) {
+            if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+            else if (minc > 5) restore = true;
+            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+        }
+        if (!restore) {
+            for (int bi = lane; bi < nbytes; bi += 64) {
+                uint8_t ob = oseq[bi];
+                int c0 = bi * 2, c1 = c0 + 1, hi = ob >> 4, lo = ob & 0xF;
+                if (c0 < len) { ColResult r = vote_column(v, c0, hi, lane); hi = r.base; oqual[c0] = (uint8_t)r.qual; }
+                if (c1 < len) { ColResult r = vote_column(v, c1, lo, lane); lo = r.base; oqual[c1] = (uint8_t)r.qual; }
+                oseq[bi] = (uint8_t)((hi << 4) | lo);
+            }
+        }
+    }
+    WAVE_SYNC();
+    return out;
+}
+
+// UMI of a consensus record: MI tag of the record itself if it has one, else parsed from the qname it now carries
+// (BamUtil::getUMI, bamutil.cpp:23-38, after BamUtil::copyQName).
+__device__ inline void d_record_umi(const DevBatch &b, const DevParams &p, const Work &w, uint32_t rec, uint32_t name_src,
+                                    const char *&u, int &ul) {
+    if (w.has_mi[rec]) { u = w.umi_ptr[rec]; ul = w.umi_len[rec]; return; }
+    if (!w.has_mi[name_src]) { u = w.umi_ptr[name_src]; ul = w.umi_len[name_src]; return; }
+    const char *q = d_qname(b, name_src); int s0, l0;
+    d_umi_slice(q, p, s0, l0);
+    u = q + s0; ul = l0;
+}
+
+__global__ __launch_bounds__(256) void k_consensus(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+    __shared__ uint32_t s_tally[WAVES_PER_BLOCK][48 * 64];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (gi >= n_groups) return;
+    uint32_t c = w.gl_cluster[gi];
+    uint32_t g = gi - w.cl_gbase[c];
+    uint32_t cstart = w.cl_start[c];
+    uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
+    uint32_t left, right, merge;
+    if (np == 1 && w.gpr[begin] == NONE32) {                                 // group.cpp:73-77: untouched, mMergeReads = 1
+        left = w.gpl[begin]; right = NONE32; merge = 1;
+    } else {
+        // cross-contig clusters: smallest name among the shortest names (group.cpp:79-99)
+        gce_core oc = b.core[(uint32_t)w.table[w.cl_slot[c]]];
+        bool cross = d_key(oc, p).right < 0;
+        uint32_t ntc = NONE32;
+        if (cross) {
+            int bl = 0;
+            for (uint32_t k = lane; k < np; k += 64) {
+                uint32_t l = w.gpl[begin + k];
+                int ll = d_lqname_pad(b.core[l]);
+                if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
+            }
+            // lanes hold candidates in ascending k; reduce with (len, name, k) order — ties keep the earlier pair
+            uint32_t bk = ntc == NONE32 ? NONE32 : 0;   // tie-break key: position is implied by read index order within qname order
+            (void)bk;
+            for (int o = 32; o > 0; o >>= 1) {
+                uint32_t on = __shfl_xor(ntc, o); int ol = __shfl_xor(bl, o);
+                if (on == NONE32) continue;
+                bool better;
+                if (ntc == NONE32) better = true;
+                else if (ol != bl) better = ol < bl;
+                else { int sc = d_strcmp(d_qname(b, on), d_qname(b, ntc)); better = sc < 0 || (sc == 0 && on < ntc); }
+                if (better) { ntc = on; bl = ol; }
+            }
+        }
+        left = side_consensus(b, p, w, begin, np, true, s_tally[wv], lane);
+        right = side_consensus(b, p, w, begin, np, false, s_tally[wv], lane);
+        merge = np;
+        if (lane == 0) {
+            if (cross) { if (left != NONE32 && ntc != NONE32 && ntc != left) {           // group.cpp:109-112
+                    if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
+                    w.qname_src[left] = ntc; } }
+            else if (left != NONE32 && right != NONE32) {                                  // group.cpp:114-123
+                if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
+                else w.qname_src[left] = right;
+            }
+        }
+    }
+    if (lane == 0) {
+        // Pair::setLeft / setRight on the new Pair (group.cpp:124-132 -> pair.cpp:188-216)
+        const char *u = nullptr; int ul = 0;
+        if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
+        if (right != NONE32) {
+            const char *u2; int ul2;
+            d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
+            if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
+            u = u2; ul = ul2;
+        }
+        w.rp_left[gi] = left; w.rp_right[gi] = right; w.rp_merge[gi] = merge; w.rp_rmerge[gi] = 0;
+        w.rp_umi[gi] = u; w.rp_umilen[gi] = (uint16_t)ul; w.rp_state[gi] = RP_PENDING; w.rp_supp[gi] = -1;
+    }
+}
+
+// ===================================================================================================== finish
+// Cluster::duplexMergeBam (cluster.cpp:199-244): position-wise compare of the decoded bases; mismatches -> N / qual 0.
+// Only b1 (the surviving pair) is written: b2 is deleted right after the merge (cluster.cpp:151-152).
+__device__ inline int d_duplex_merge_bam(const DevBatch &b, uint32_t r1, uint32_t r2, int lane) {
+    int l1 = b.core[r1].l_qseq, l2 = b.core[r2].l_qseq;
+    int len = min(l1, l2), diff = 0;
+    uint8_t *s1 = b.seq + b.seq_off[r1], *q1 = b.qual + b.qual_off[r1];
+    const uint8_t *s2 = b.seq + b.seq_off[r2];
+    for (int bi = lane; bi * 2 < len; bi += 64) {
+        uint8_t x = s1[bi], y = s2[bi];
+        int c0 = bi * 2, c1 = c0 + 1;
+        int hi = x >> 4, lo = x & 0xF;
+        if (d_base_class(hi) != d_base_class(y >> 4)) { diff++; hi = 15; q1[c0] = 0; }
+        if (c1 < len && d_base_class(lo) != d_base_class(y & 0xF)) { diff++; lo = 15; q1[c1] = 0; }
+        s1[bi] = (uint8_t)((hi << 4) | lo);
+    }
+    return wave_sum(diff) + (l1 > l2 ? l1 - l2 : l2 - l1);
+}
+
+__device__ inline void d_emit_pair(const Work &w, uint32_t gi, bool duplex) {      // Pair::writeSscsDcsTag + Gencore::outputPair
+    uint32_t l = w.rp_left[gi], r = w.rp_right[gi];
+    int fr = (int)min(w.rp_merge[gi], 65535u) & 0xFF;                               // low byte of an unsigned short (quirk Q8)
+    int rr = (int)min(w.rp_rmerge[gi], 65535u) & 0xFF;
+    if (l != NONE32) { w.out_flag[l] = 1; w.fr[l] = (int16_t)fr; if (duplex) w.rr[l] = (int16_t)rr; w.mate[l] = r; }
+    if (r != NONE32) { w.out_flag[r] = 1; w.fr[r] = (int16_t)fr; if (duplex) w.rr[r] = (int16_t)rr; w.mate[r] = l; }
+}
+
+__global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+    const int lane = lane_id();
+    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (c >= n_clusters) return;
+    uint32_t G = w.cl_ngroups[c];
+    if (G == 0) { if (lane == 0) w.cl_nresult[c] = 0; return; }
+    uint32_t g0 = w.cl_gbase[c];
+    uint32_t nres = 0;
+    if (w.cl_hasumi[c] && !p.disable_duplex) {                                       // cluster.cpp:119-168
+        for (int idx = (int)G - 1; idx >= 0; idx--) {
+            uint32_t gi = g0 + idx;
+            if (w.rp_state[gi] == RP_CONSUMED) continue;
+            const char *u1 = w.rp_umi[gi]; int ul1 = w.rp_umilen[gi];
+            uint32_t found = NONE32;
+            for (int base = 0; base < idx && found == NONE32; base += 64) {
+                int i = base + lane;
+                bool hit = i < idx && w.rp_state[g0 + i] == RP_PENDING && d_is_duplex(u1, ul1, w.rp_umi[g0 + i], w.rp_umilen[g0 + i]);
+                unsigned long long m = __ballot(hit);
+                if (m) found = base + (__ffsll((long long)m) - 1);
+            }
+            uint32_t l1 = w.rp_left[gi], r1 = w.rp_right[gi], m1 = w.rp_merge[gi];
+            if (found != NONE32) {
+                uint32_t g2 = g0 + found;
+                uint32_t l2 = w.rp_left[g2], r2 = w.rp_right[g2], m2 = w.rp_merge[g2];
+                int diff = 0;
+                if (l1 != NONE32 && l2 != NONE32) diff += d_duplex_merge_bam(b, l1, l2, lane);
+                if (r1 != NONE32 && r2 != NONE32) diff += d_duplex_merge_bam(b, r1, r2, lane);
+                bool outp = diff <= p.duplex_mismatch_thr && (int)(m1 + m2) >= p.cluster_size_req;
+                if (lane == 0) {
+                    w.rp_supp[gi] = (int)(m1 + m2);
+                    w.rp_rmerge[gi] = m2;
+                    w.rp_state[gi] = outp ? RP_OUT_DCS : RP_DROPPED;
+                    w.rp_state[g2] = RP_CONSUMED;
+                    if (outp) d_emit_pair(w, gi, true);
+                }
+                nres += outp;
+            } else {
+                bool outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
+                if (lane == 0) { w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED; if (outp) d_emit_pair(w, gi, false); }
+                nres += outp;
+            }
+            WAVE_SYNC();
+        }
+    } else {                                                                          // cluster.cpp:169-183
+        for (uint32_t base = 0; base < G; base += 64) {
+            uint32_t i = base + lane;
+            bool outp = false;
+            if (i < G) {
+                uint32_t gi = g0 + i, m1 = w.rp_merge[gi];
+                outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
+                w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED;
+                if (outp) d_emit_pair(w, gi, false);
+            }
+            nres += __popcll(__ballot(outp));
+        }
+    }
+    if (lane == 0) w.cl_nresult[c] = nres;
+}
+
+// ===================================================================================================== Stats
+// All counters are additive (stats.h:47-65).  Block-local accumulation in LDS, one global atomic per non-zero counter.
+__global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_clusters, uint32_t n_groups) {
+    __shared__ unsigned long long s_pre[GCE_STATS_WORDS], s_post[GCE_STATS_WORDS];
+    for (int k = threadIdx.x; k < GCE_STATS_WORDS; k += blockDim.x) { s_pre[k] = 0; s_post[k] = 0; }
+    __syncthreads();
+    const uint64_t tid0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    // indices into gce_stats: 6 clusters, 7 multi, 8 molecules, 9 se, 10 pe, 11 sscs, 12 dcs, 13 uncounted, 14.. hist
+    for (uint64_t c = tid0; c < n_clusters; c += stride) {
+        uint32_t G = w.cl_ngroups[c];
+        if (G == 0) continue;
+        atomicAdd(&s_pre[6], 1ull); if (G > 1) atomicAdd(&s_pre[7], 1ull);              // cluster.cpp:102
+        uint32_t nr = w.cl_nresult[c];
+        if (nr > 0) { atomicAdd(&s_post[6], 1ull); if (nr > 1) atomicAdd(&s_post[7], 1ull); }   // cluster.cpp:185-187
+    }
+    for (uint64_t g = tid0; g < n_groups; g += stride) {
+        int supp = w.rp_supp[g];
+        if (supp < 0) continue;                                                          // consumed as the reverse strand: no event
+        bool pe = w.rp_left[g] != NONE32 && w.rp_right[g] != NONE32;
+        atomicAdd(&s_pre[8], 1ull);                                                      // Stats::addMolecule, stats.cpp:123-133
+        if (supp < GCE_MAX_SUPPORTING_READS) atomicAdd(&s_pre[14 + supp], 1ull); else atomicAdd(&s_pre[13], 1ull);
+        atomicAdd(&s_pre[pe ? 10 : 9], 1ull);
+        uint8_t st = w.rp_state[g];
+        if (st == RP_OUT_SSCS || st == RP_OUT_DCS) {
+            atomicAdd(&s_post[st == RP_OUT_DCS ? 12 : 11], 1ull);                        // addSSCS / addDCS
+            atomicAdd(&s_post[8], 1ull); atomicAdd(&s_post[14 + 1], 1ull); atomicAdd(&s_post[pe ? 10 : 9], 1ull);   // outputPair: addMolecule(1, PE)
+        }
+    }
+    for (uint64_t i = tid0; i < (uint64_t)b.n; i += stride) {                             // writeBam -> mPostStats->addRead
+        if (!w.out_flag[i]) continue;
+        gce_core k = b.core[i];
+        bool mapped = k.tid >= 0;
+        int nm = w.nm_new[i] >= 0 ? w.nm_new[i] : b.nm[i];
+        int mism = (mapped && b.nm_type[i]) ? nm : 0;
+        atomicAdd(&s_post[0], 1ull); atomicAdd(&s_post[1], (unsigned long long)k.l_qseq);
+        if (mism) { atomicAdd(&s_post[4], (unsigned long long)(long long)mism); }
+        if (!mapped) { atomicAdd(&s_post[2], 1ull); atomicAdd(&s_post[3], (unsigned long long)k.l_qseq); }
+        if (mism > 0) atomicAdd(&s_post[5], 1ull);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < GCE_STATS_WORDS; k += blockDim.x) {
+        if (s_pre[k]) atomicAdd((unsigned long long *)&w.si->pre[k], s_pre[k]);
+        if (s_post[k]) atomicAdd((unsigned long long *)&w.si->post[k], s_post[k]);
+    }
+}
+
+// out_index: ascending list of emitted reads (3-phase scan over out_flag != 0)
+__global__ __launch_bounds__(256) void k_flag_reduce(const uint8_t *flag, uint64_t n, uint64_t *part) {
+    __shared__ uint64_t s[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE, v = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) { uint64_t i = base + k * 256 + threadIdx.x; v += (i < n && flag[i]) ? 1 : 0; }
+    v = (uint64_t)wave_sum64((long long)v);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1] + s[2] + s[3]) << 32;    // keep the total in the high word like the table scan
+}
+__global__ __launch_bounds__(256) void k_flag_apply(const uint8_t *flag, uint64_t n, const uint64_t *part, uint32_t *out_index) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = (uint32_t)(part[blockIdx.x] >> 32);
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        uint64_t i = base + k * 256 + threadIdx.x;
+        bool f = i < n && flag[i];
+        unsigned long long m = __ballot(f);
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        uint32_t carry = s_carry;
+        if (f) out_index[carry + woff + lanes_below(m)] = (uint32_t)i;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
