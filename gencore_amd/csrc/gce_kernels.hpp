@@ -851,8 +851,6 @@ __global__ __launch_bounds__(256) void k_consensus(DevBatch b, DevParams p, Work
                 if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
             }
             // lanes hold candidates in ascending k; reduce with (len, name, k) order — ties keep the earlier pair
-            uint32_t bk = ntc == NONE32 ? NONE32 : 0;   // tie-break key: position is implied by read index order within qname order
-            (void)bk;
             for (int o = 32; o > 0; o >>= 1) {
                 uint32_t on = __shfl_xor(ntc, o); int ol = __shfl_xor(bl, o);
                 if (on == NONE32) continue;
@@ -892,20 +890,56 @@ __global__ __launch_bounds__(256) void k_consensus(DevBatch b, DevParams p, Work
 }
 
 // ===================================================================================================== finish
-// Cluster::duplexMergeBam (cluster.cpp:199-244): position-wise compare of the decoded bases; mismatches -> N / qual 0.
+// Cluster::duplexMergeBam (cluster.cpp:199-244).  The reference loop is
+//     for(i=0;i<len;i++){ if(seq1[i/2]==seq2[i/2]){ i++; continue; } compare base i; mismatch -> N / qual 0 in both }
+// i.e. a two-phase automaton over the packed bytes: arriving at a byte on its EVEN index it examines both nibbles;
+// after a masked high nibble whose low nibbles agree the bytes become equal, the `i++; continue` lands on the ODD index
+// of the next byte, and while it stays on odd indices only whole-byte equality and LOW nibbles are examined (a high
+// nibble mismatch is then skipped) until an unequal byte re-synchronises it.  The phase each byte is entered in is
+// computed exactly from two ballots (EQ = bytes equal, TO = byte sends the walk to the odd phase).
 // Only b1 (the surviving pair) is written: b2 is deleted right after the merge (cluster.cpp:151-152).
 __device__ inline int d_duplex_merge_bam(const DevBatch &b, uint32_t r1, uint32_t r2, int lane) {
     int l1 = b.core[r1].l_qseq, l2 = b.core[r2].l_qseq;
     int len = min(l1, l2), diff = 0;
     uint8_t *s1 = b.seq + b.seq_off[r1], *q1 = b.qual + b.qual_off[r1];
     const uint8_t *s2 = b.seq + b.seq_off[r2];
-    for (int bi = lane; bi * 2 < len; bi += 64) {
-        uint8_t x = s1[bi], y = s2[bi];
-        int c0 = bi * 2, c1 = c0 + 1;
-        int hi = x >> 4, lo = x & 0xF;
-        if (d_base_class(hi) != d_base_class(y >> 4)) { diff++; hi = 15; q1[c0] = 0; }
-        if (c1 < len && d_base_class(lo) != d_base_class(y & 0xF)) { diff++; lo = 15; q1[c1] = 0; }
-        s1[bi] = (uint8_t)((hi << 4) | lo);
+    const int nb = (len + 1) >> 1;
+    bool phase_odd = false;                                  // phase in which the chunk's first byte is entered (wave-uniform)
+    for (int base = 0; base < nb; base += 64) {
+        int k = base + lane;
+        bool valid = k < nb;
+        uint8_t x = valid ? s1[k] : 0, y = valid ? s2[k] : 0;
+        int xh = x >> 4, xl = x & 0xF, yh = y >> 4, yl = y & 0xF;
+        bool has_lo = (2 * k + 1) < len;
+        bool ne = valid && x != y;
+        bool mark_hi = ne && d_base_class(xh) != d_base_class(yh);
+        bool to_odd = mark_hi && xl == yl && has_lo;          // bytes equal after masking -> the walk continues on odd indices
+        unsigned long long EQ = __ballot(!ne), TO = __ballot(to_odd);
+        unsigned long long oddin = 0;
+        int pos = 0; bool st = phase_odd;
+        while (pos < 64) {
+            if (!st) {
+                unsigned long long m = TO & (~0ull << pos);
+                if (!m) { pos = 64; break; }
+                pos = __ffsll((long long)m);                 // index + 1: the byte after the one that switched phase
+                st = true;
+            } else {
+                unsigned long long m = ~EQ & (~0ull << pos);
+                int nx = m ? __ffsll((long long)m) - 1 : 64; // first unequal byte met in odd phase (it re-synchronises)
+                unsigned long long upto = nx >= 63 ? ~0ull : ((2ull << nx) - 1ull);
+                oddin |= upto & (~0ull << pos);
+                if (nx == 64) pos = 64; else { pos = nx + 1; st = false; }
+            }
+        }
+        phase_odd = st;
+        bool in_odd = (oddin >> lane) & 1ull;
+        if (ne) {
+            if (!in_odd) {
+                if (mark_hi) { diff++; xh = 15; q1[2 * k] = 0; }
+                if (has_lo && !(mark_hi && xl == yl) && d_base_class(xl) != d_base_class(yl)) { diff++; xl = 15; q1[2 * k + 1] = 0; }
+            } else if (has_lo && d_base_class(xl) != d_base_class(yl)) { diff++; xl = 15; q1[2 * k + 1] = 0; }
+            s1[k] = (uint8_t)((xh << 4) | xl);
+        }
     }
     return wave_sum(diff) + (l1 > l2 ? l1 - l2 : l2 - l1);
 }

@@ -1,0 +1,148 @@
+"""Parity tests proper: the HIP engine (through the C-ABI) against the CPU oracle on the same inputs — bit-exact
+on every emitted record (seq nibbles, quals, NM, qname source, FR/RR, mate links) and on both Stats blocks."""
+import numpy as np
+import pytest
+
+import fuzzgen
+from gencore_amd.batch import diff_results
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(batch, params, reference):
+    from gencore_amd.engine import run_stream
+    from oracle import oracle_py
+    want = oracle_py.run(batch, params, reference)
+    if want.status != 0:
+        from gencore_amd.capi import GceError
+        with pytest.raises(GceError) as ei:
+            run_stream(batch, params, reference)
+        assert ei.value.status == want.status
+        return None, want
+    got = run_stream(batch, params, reference)
+    diffs = diff_results(batch, got, want)
+    assert not diffs, "\n".join(diffs)
+    assert np.array_equal(got.out_index, np.nonzero(got.out_flag)[0])
+    return got, want
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_stream(built, seed):
+    batch, over, reference, contig_len = fuzzgen.make_case(seed)
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
+@pytest.mark.parametrize("seed,umi_mode,period", [(100, "duplex", 10000), (101, "duplex", 11), (102, "prefix", 5), (103, "colon", 3),
+                                                    (104, "none", 2), (105, "duplex", 1), (106, "prefix", 10000)])
+def test_fuzz_umi_modes(built, seed, umi_mode, period):
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, umi_mode=umi_mode, period=period)
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
+@pytest.mark.parametrize("seed,deep", [(200, 70), (201, 150), (202, 300)])
+def test_fuzz_deep_cluster(built, seed, deep):
+    """> 64 pairs in one cluster: multi-chunk wave loops; depth 300 also wraps the FR byte (quirk Q8)."""
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=6, umi_mode="duplex" if seed % 2 else "none", deep=deep)
+    over["skip_low_complexity_cluster_threshold"] = 100 if seed == 202 else 1000
+    got, want = run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+    if seed == 200:
+        assert got.fr.max() >= 0
+
+
+def synth_case(name, n_pairs, **over):
+    from gencore_amd import synth
+    from gencore_amd.capi import default_params
+    d = synth.generate(name, n_pairs=n_pairs)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"],
+                         cluster_size_req=d.info["supporting_reads"], **over)
+    prm._keep = tl
+    return batch, prm, d.reference_host()
+
+
+@pytest.mark.parametrize("name,n_pairs", [("cfg1s", None), ("cfg2", 60000), ("cfg3", 60000), ("cfg4s", 40000), ("cfg5", 3000)])
+def test_synthetic_configs(built, name, n_pairs):
+    """Down-scaled BASELINE.json configs (same generator, same flags) at sizes the oracle finishes in seconds."""
+    batch, prm, ref = synth_case(name, n_pairs)
+    got, want = run_both(batch, prm, ref)
+    assert len(got.emitted()) > 0
+
+
+def test_sharded_stream_context(built):
+    """tick_offset / trailing_flush (coordinate-sharded multi-GPU runs): per-contig slices reproduce the whole stream."""
+    from gencore_amd.shard import shard_by_contig
+    batch, over, reference, contig_len = fuzzgen.make_case(300, n_mol=80, umi_mode="prefix", period=17)
+    whole_p = fuzzgen.make_params(over, contig_len)
+    got_whole, _ = run_both(batch, whole_p, reference)
+    flags = np.zeros(batch.n, np.uint8)
+    for rank in range(2):
+        sub, idx, ctx = shard_by_contig(batch, 2, rank, over["flush_period"])
+        p = fuzzgen.make_params(dict(over, **ctx), contig_len)
+        got, _ = run_both(sub, p, reference)
+        flags[idx] = got.out_flag
+    assert np.array_equal(flags, got_whole.out_flag)
+
+
+def test_multiple_submits_concatenate(built):
+    from gencore_amd.engine import Engine
+    from oracle import oracle_py
+    batch, over, reference, contig_len = fuzzgen.make_case(301, n_mol=50, umi_mode="prefix", period=13)
+    prm = fuzzgen.make_params(over, contig_len)
+    want = oracle_py.run(batch, prm, reference)
+    from gencore_amd.shard import slice_batch
+    e = Engine(prm)
+    for tid, (nib, ln) in enumerate(reference):
+        if nib is not None:
+            e.set_reference(tid, nib, ln)
+    cut = batch.n // 3
+    e.add_reads(slice_batch(batch, np.arange(0, cut)))
+    e.add_reads(slice_batch(batch, np.arange(cut, batch.n)))
+    e.finish()
+    got = e.output()
+    e.close()
+    assert not diff_results(batch, got, want)
+
+
+def test_error_codes_match_reference_fatal_paths(built):
+    from gencore_amd.batch import ReadBatch
+    from gencore_amd.capi import default_params
+    tl = np.asarray([100000], np.uint32)
+    base = dict(flag=99, tid=0, cigar="20M", mtid=0, isize=50, seq="ACGTACGTACGTACGTACGT", qual=[37] * 20, nm=0)
+
+    def status_of(recs, **over):
+        got, want = run_both(ReadBatch.from_records(recs), default_params(n_targets=1, target_len=tl.ctypes.data, **over), [])
+        return want.status          # run_both already asserted that the engine raised the same status
+
+    # unsorted input: src/gencore.cpp:233-241
+    assert status_of([dict(base, qname="a", pos=500, mpos=530), dict(base, qname="b", pos=100, mpos=130)]) == -10
+    # mates whose MI tags give different UMIs: src/pair.cpp:201-212 (the MI string goes through the same getUMI parser)
+    assert status_of([dict(base, qname="a", pos=100, mpos=130, mi="x:AAAA"),
+                      dict(base, qname="a", flag=147, pos=130, mpos=100, isize=-50, mi="x:CCCC")]) == -11
+    assert status_of([dict(base, qname="a", pos=100, mpos=130, mi="AAAA"),
+                      dict(base, qname="a", flag=147, pos=130, mpos=100, isize=-50, mi="CCCC")]) == 0      # no ':' -> both UMIs ""
+    # UMI substr throw: src/bamutil.cpp:62
+    assert status_of([dict(base, qname="readUI", pos=100, mpos=130)], umi_prefix="UMI") == -13
+    # NM absent on a template whose mismatch count changes: src/group.cpp:532-535 dereferences NULL (quirk Q9)
+    ref_seq = "ACGTACGTACGTACGTACGT"
+    lowq = [37] * 20
+    lowq[3] = 2
+    bad = ref_seq[:3] + "A" + ref_seq[4:]
+    from oracle import oracle_py
+    refnib = oracle_py.pack_reference("G" * 100 + ref_seq + "G" * 200)
+    recs = [dict(base, qname="a", pos=100, mpos=130, seq=bad, qual=lowq, nm=None),
+            dict(base, qname="a", flag=147, pos=130, mpos=100, isize=-50, nm=None)]
+    got, want = run_both(ReadBatch.from_records(recs), default_params(n_targets=1, target_len=tl.ctypes.data), [(refnib, 320)])
+    assert want.status == -12
+
+
+def test_empty_and_tiny_inputs(built):
+    from gencore_amd.batch import ReadBatch
+    from gencore_amd.capi import default_params
+    tl = np.asarray([100000], np.uint32)
+    prm = default_params(n_targets=1, target_len=tl.ctypes.data)
+    base = dict(flag=99, tid=0, cigar="20M", mtid=0, isize=50, seq="ACGTACGTACGTACGTACGT", qual=[37] * 20, nm=0)
+    for recs in ([dict(base, qname="a", pos=100, mpos=130)],
+                 [dict(base, qname="a", pos=100, mpos=130), dict(base, qname="a", flag=147, pos=130, mpos=100, isize=-50)],
+                 [dict(base, qname="u", flag=77, tid=-1, pos=-1, mtid=-1, mpos=-1, isize=0, cigar="*", nm=None)]):
+        run_both(ReadBatch.from_records(recs), prm, [])
