@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite .db or *_kernel_stats.csv) for profiles/:
+"""(rocpd top_kernels view reports microseconds; the CSV reports nanoseconds.)
+Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite .db or *_kernel_stats.csv) for profiles/:
 only the engine's own kernels (k_*), with calls / total / average duration in microseconds."""
 import csv
 import glob
@@ -9,7 +10,7 @@ import sys
 
 def rows_from_db(path):
     cur = sqlite3.connect(path).cursor()
-    return [(r[0], int(r[1]), float(r[2]) / 1e3, float(r[3]) / 1e3, float(r[4])) for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels")]
+    return [(r[0], int(r[1]), float(r[2]), float(r[3]), float(r[4])) for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels")]
 
 
 def rows_from_csv(path):
