@@ -1,0 +1,53 @@
+"""N>1 path on CPU: two gloo ranks, each owns a coordinate shard (gencore_amd/shard.py), no data-path collective,
+one all-reduce(sum) of the additive Stats blocks — the same plumbing bench.py uses with RCCL.  The per-shard
+compute stand-in is the oracle (tests may use it); the product's kernels are covered by the -m gpu tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, seed, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fuzzgen
+    from gencore_amd.shard import shard_by_contig
+    from oracle import oracle_py
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, umi_mode="prefix", period=13)
+    sub, idx, ctx = shard_by_contig(batch, world, rank, over["flush_period"])
+    r = oracle_py.run(sub, fuzzgen.make_params(dict(over, **ctx), contig_len), reference)
+    stats = torch.from_numpy(np.concatenate([r.pre.as_array(), r.post.as_array()]))
+    dist.barrier()
+    dist.all_reduce(stats)                     # the final Stats merge
+    n_out = torch.tensor([int((r.out_flag != 0).sum())])
+    dist.all_reduce(n_out)
+    if rank == 0:
+        whole = oracle_py.run(batch, fuzzgen.make_params(over, contig_len), reference)
+        want = np.concatenate([whole.pre.as_array(), whole.post.as_array()])
+        q.put((bool(np.array_equal(stats.numpy(), want)), int(n_out.item()), int((whole.out_flag != 0).sum())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_and_stats_allreduce(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 500, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, n_out, want_out = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and n_out == want_out
