@@ -50,6 +50,8 @@ struct StreamInfo {
     unsigned int error_read;
     int n_events;                        // E: flush events inside this slice
     int n_events_a;                      // E_A: events whose read index < U
+    unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
+    unsigned int pad0;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];

@@ -40,6 +40,7 @@ struct Work {
     uint32_t *members, *sorted, *pl, *pr, *pu, *pg, *gpl, *gpr, *grp_begin, *grp_n;
     // groups (compact)
     uint32_t *gl_cluster;
+    uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     // generic scan scratch
     uint64_t *scan_part;
@@ -530,6 +531,7 @@ struct VoteCtx {
     int len; const uint8_t *ref; int64_t ref_len;
     const uint32_t *ocig; int oncig; int opos;
     uint32_t *tally;      // lane-private LDS: word (bin*3+k)*64
+    const uint32_t *voters; const uint32_t *vld;   // scratch: voter reads and their lenDiff
 };
 struct ColResult { int base, qual, new_base_written, minc, diff; };
 
@@ -541,8 +543,8 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
     for (int k = 0; k < 48; k++) t[k * 64] = 0;
     int total = 0;
     for (uint32_t q = 0; q < v.nv; q++) {
-        uint32_t r = w.pl[v.vbase + q];                  // voter list (scratch)
-        int ld = (int)w.pr[v.vbase + q];
+        uint32_t r = v.voters[v.vbase + q];              // voter list (scratch)
+        int ld = (int)v.vld[v.vbase + q];
         int rl = b.core[r].l_qseq;
         int rp = v.left_mode ? col : col + ld;
         if (rp < 0 || rp >= rl) continue;                // out of range is UB in the reference; skipped (same as oracle)
@@ -596,8 +598,8 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
     if (need && ref4 != 0) {                                                  // group.cpp:470-501
         int rbq = 0;                                                          // `char refBaseQual`
         for (uint32_t q = 0; q < v.nv; q++) {
-            uint32_t r = w.pl[v.vbase + q];
-            int ld = (int)w.pr[v.vbase + q];
+            uint32_t r = v.voters[v.vbase + q];
+            int ld = (int)v.vld[v.vbase + q];
             int rl = b.core[r].l_qseq;
             int rp = v.left_mode ? col : col + ld;
             if (rp < 0 || rp >= rl) continue;
@@ -620,7 +622,8 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
 }
 
 // Group::consensusMergeBam for one side (group.cpp:136-318).  Returns the template read or NONE32.
-// Scratch (cluster-local arrays that are dead after k_pairing): sorted = containedBy, pl = voters, pr = lenDiff.
+// Scratch (cluster-local arrays that are dead after k_pairing): left side uses sorted/pl/pr, right side pg/pu/members
+// for containedBy / voters / lenDiff (the two sides of a group may run concurrently on different waves).
 __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left,
                                    uint32_t *tally, int lane) {
     const uint32_t *side = is_left ? w.gpl : w.gpr;
@@ -663,7 +666,8 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         if (mx < 0 || mn == mx) left_mode = true;
     }
     // ---- containedBy (group.cpp:196-233)
-    uint32_t *contained = w.sorted;
+    uint32_t *contained = is_left ? w.sorted : w.pg;
+    uint32_t *voters = is_left ? w.pl : w.pu, *vld = is_left ? w.pr : w.members;
     for (uint32_t base = 0; base < np; base += 64) {
         uint32_t k = base + lane;
         if (k < np) {
@@ -718,7 +722,7 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
     // ---- voters: template + every read the template is part of (group.cpp:287-313); lenDiff (group.cpp:339-348)
     WAVE_SYNC();
     uint32_t nv = 1;
-    if (lane == 0) { w.pl[begin] = out; w.pr[begin] = 0; }
+    if (lane == 0) { voters[begin] = out; vld[begin] = 0; }
     for (uint32_t base = 0; base < np; base += 64) {
         uint32_t j = base + lane;
         bool take = false; uint32_t rd = NONE32; int ld = 0;
@@ -732,7 +736,7 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         }
         unsigned long long m = __ballot(take);
         // NOTE: voters overwrite w.pl/w.pr at [begin+1 ...]; the source arrays here are gpl/gpr (distinct buffers)
-        if (take) { uint32_t d = begin + nv + lanes_below(m); w.pl[d] = rd; w.pr[d] = (uint32_t)ld; }
+        if (take) { uint32_t d = begin + nv + lanes_below(m); voters[d] = rd; vld[d] = (uint32_t)ld; }
         nv += __popcll(m);
     }
     WAVE_SYNC();
@@ -740,12 +744,12 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
     int len = ok.l_qseq;
     if (ok.n_cigar == 0) {                                                    // group.cpp:354-360
         int mn = len;
-        for (uint32_t q = lane; q < nv; q += 64) mn = min(mn, b.core[w.pl[begin + q]].l_qseq);
+        for (uint32_t q = lane; q < nv; q += 64) mn = min(mn, b.core[voters[begin + q]].l_qseq);
         len = wave_min(mn);
     }
     VoteCtx v;
     v.b = &b; v.p = &p; v.w = &w; v.out = out; v.nv = nv; v.vbase = begin; v.left_mode = left_mode; v.len = len;
-    v.ref = nullptr; v.ref_len = 0; v.ocig = ocig; v.oncig = ok.n_cigar; v.opos = ok.pos; v.tally = tally;
+    v.ref = nullptr; v.ref_len = 0; v.ocig = ocig; v.oncig = ok.n_cigar; v.opos = ok.pos; v.tally = tally; v.voters = voters; v.vld = vld;
     if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {                  // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
         const uint8_t *rd = p.ref_data[ok.tid];
         int64_t need_len = (int64_t)d_ref_offset(ocig, ok.n_cigar, len - 1) + 1;
@@ -826,67 +830,256 @@ __device__ inline void d_record_umi(const DevBatch &b, const DevParams &p, const
     u = q + s0; ul = l0;
 }
 
-__global__ __launch_bounds__(256) void k_consensus(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+// ---- generic (any depth, any nibble, any length) consensus of deferred group sides: LDS tallies, global scratch
+__global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p, Work w) {
     __shared__ uint32_t s_tally[WAVES_PER_BLOCK][48 * 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const uint32_t n_slow = (uint32_t)w.si->n_slow;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
+        uint32_t e = w.slow_list[idx], gi = e >> 1; bool is_left = !(e & 1);
+        uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
+        uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
+        uint32_t out = side_consensus(b, p, w, begin, np, is_left, s_tally[wv], lane);
+        if (lane == 0) { if (is_left) w.rp_left[gi] = out; else w.rp_right[gi] = out; }
+        WAVE_SYNC();
+    }
+}
+
+__device__ __forceinline__ int rl32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+// BamUtil::isPartOf with the single-op case (e.g. 150M vs 148M) answered from registers
+__device__ __forceinline__ bool part_of_fast(uint32_t pc0, int pnc, const uint32_t *pcig, uint32_t wc0, int wnc, const uint32_t *wcig, bool left) {
+    if (pnc == 0) return true;
+    if (pnc == 1 && wnc == 1) return cig_op(pc0) == cig_op(wc0) && cig_len(pc0) <= cig_len(wc0);
+    return d_is_part_of(pcig, pnc, wcig, wnc, left);
+}
+
+// (score, qual-sum) lexicographic order used by the top/second scans of group.cpp:394-416
+__device__ __forceinline__ bool lex_gt(int s1, int q1, int s2, int q2) { return s1 > s2 || (s1 == s2 && q1 > q2); }
+__device__ __forceinline__ bool lex_eq(int s1, int q1, int s2, int q2) { return s1 == s2 && q1 == q2; }
+
+struct Tally5 { int cnt[5], ss[5], qs[5], tq[5]; int total; };
+__device__ __forceinline__ void tally_clear(Tally5 &t) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) { t.cnt[k] = 0; t.ss[k] = 0; t.qs[k] = 0; t.tq[k] = 0; }
+    t.total = 0;
+}
+// returns false for a nibble outside {1,2,4,8,15} (handled by the generic kernel)
+__device__ __forceinline__ bool tally_add(Tally5 &t, int nib, int q, int s) {
+    int m0 = nib == 1, m1 = nib == 2, m2 = nib == 4, m3 = nib == 8, m4 = nib == 15;
+    int m[5] = {m0, m1, m2, m3, m4};
+#pragma unroll
+    for (int k = 0; k < 5; k++) { t.cnt[k] += m[k]; t.ss[k] += m[k] * s; t.qs[k] += m[k] * q; t.tq[k] = max(t.tq[k], m[k] * q); }
+    t.total += s;
+    return (m0 | m1 | m2 | m3 | m4) != 0;
+}
+
+// One column of Group::makeConsensus (group.cpp:394-525) from the 5 real bins; the 11 other nibble bins are all
+// (count 0, score 0, qual 0) and only enter through the `>=` later-bin tie rule (quirk Q6):
+//   top    = LAST index whose (score, qualsum) equals the maximum over all 16 bins
+//   second = the same over the bins other than top
+struct ColOut { int base, qual, minc; };
+__device__ __forceinline__ ColOut decide_column(const Tally5 &t, const DevParams &p, int out_base, int ref4) {
+    const int IDX[5] = {1, 2, 4, 8, 15};
+    int ms = 0, mq = 0;                                   // the absent bins contribute (0,0)
+#pragma unroll
+    for (int k = 0; k < 5; k++) if (lex_gt(t.ss[k], t.qs[k], ms, mq)) { ms = t.ss[k]; mq = t.qs[k]; }
+    int top, tk = -1;                                     // tk: real-bin slot of top, -1 if top is an absent bin
+    if (lex_eq(t.ss[4], t.qs[4], ms, mq)) { top = 15; tk = 4; }
+    else if (ms == 0 && mq == 0) { top = 14; }
+    else {
+        top = 1; tk = 0;
+#pragma unroll
+        for (int k = 3; k >= 1; k--) if (tk == 0 && lex_eq(t.ss[k], t.qs[k], ms, mq)) { top = IDX[k]; tk = k; }
+        // (descending scan: the highest index with the maximum wins; slot 0 is the fallback)
+    }
+    int top_s = ms;
+    int s2 = 0, q2 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) if (k != tk && lex_gt(t.ss[k], t.qs[k], s2, q2)) { s2 = t.ss[k]; q2 = t.qs[k]; }
+    int sk = -1;
+    if (tk != 4 && lex_eq(t.ss[4], t.qs[4], s2, q2)) sk = 4;
+    else if (s2 == 0 && q2 == 0) sk = -1;                 // an absent bin (14, or 13 when top is 14): count 0, quals 0
+    else {
+#pragma unroll
+        for (int k = 3; k >= 0; k--) if (sk < 0 && k != tk && lex_eq(t.ss[k], t.qs[k], s2, q2)) sk = k;
+    }
+    int top_num = 0, top_qual = 0, sec_num = 0, sec_q = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { if (k == tk) { top_num = t.cnt[k]; top_qual = t.tq[k]; } if (k == sk) { sec_num = t.cnt[k]; sec_q = t.qs[k]; } }
+    ColOut r; r.base = out_base; r.minc = 0;
+    bool need = false;
+    if (sec_num == 0) {                                                       // group.cpp:421-428
+        if (top_s >= p.base_score_req && top_qual >= p.moderate_q) { r.qual = top_qual; return r; }
+        need = true;
+    }
+    if (sec_num == 1) {                                                       // group.cpp:442-457
+        if (sec_q <= p.low_q) { if (top_num < 2 && top_qual < p.high_q) need = true; }
+        else { if (top_num < 3 || top_qual < p.high_q) need = true; }
+    }
+    if (sec_num > 1 && ((double)top_s < p.score_percent_req * (double)t.total || top_qual < p.moderate_q)) need = true;   // :460-464
+    if (top_s < p.base_score_req || top_qual <= p.low_q) need = true;         // :466-467
+    if (need && ref4 != 0) {                                                  // :470-501 (ref4 is one of 1,2,4,8)
+        int rk = ref4 == 1 ? 0 : ref4 == 2 ? 1 : ref4 == 4 ? 2 : 3;
+        int rbq = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k == rk) rbq = t.tq[k];              // highest quality among the ref-consistent voters (< 128 here)
+        if (rbq >= p.high_q) top = ref4;
+        if (top_qual < p.moderate_q) top = ref4;
+        if (top == ref4) top_qual = rbq;
+    }
+    if (out_base != top) {                                                    // :503-524
+        r.base = top;
+        if (ref4 != 0) { if (out_base == ref4) r.minc = 1; else if (top == ref4) r.minc = -1; }
+    }
+    r.qual = top_qual;
+    return r;
+}
+
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+
+// One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
+// pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
+__global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+    __shared__ uint8_t s_res[WAVES_PER_BLOCK][3 * 256];          // buffered results: new seq byte, qual0, qual1 per template byte
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t wid = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const uint32_t gi = wid >> 1;
+    const bool is_left = !(wid & 1);
     if (gi >= n_groups) return;
-    uint32_t c = w.gl_cluster[gi];
-    uint32_t g = gi - w.cl_gbase[c];
-    uint32_t cstart = w.cl_start[c];
-    uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
-    uint32_t left, right, merge;
-    if (np == 1 && w.gpr[begin] == NONE32) {                                 // group.cpp:73-77: untouched, mMergeReads = 1
-        left = w.gpl[begin]; right = NONE32; merge = 1;
-    } else {
-        // cross-contig clusters: smallest name among the shortest names (group.cpp:79-99)
-        gce_core oc = b.core[(uint32_t)w.table[w.cl_slot[c]]];
-        bool cross = d_key(oc, p).right < 0;
-        uint32_t ntc = NONE32;
-        if (cross) {
-            int bl = 0;
-            for (uint32_t k = lane; k < np; k += 64) {
-                uint32_t l = w.gpl[begin + k];
-                int ll = d_lqname_pad(b.core[l]);
-                if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
-            }
-            // lanes hold candidates in ascending k; reduce with (len, name, k) order — ties keep the earlier pair
-            for (int o = 32; o > 0; o >>= 1) {
-                uint32_t on = __shfl_xor(ntc, o); int ol = __shfl_xor(bl, o);
-                if (on == NONE32) continue;
-                bool better;
-                if (ntc == NONE32) better = true;
-                else if (ol != bl) better = ol < bl;
-                else { int sc = d_strcmp(d_qname(b, on), d_qname(b, ntc)); better = sc < 0 || (sc == 0 && on < ntc); }
-                if (better) { ntc = on; bl = ol; }
+    const uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
+    const uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
+    uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
+    if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
+        if (lane == 0) rp_out[gi] = is_left ? w.gpl[begin] : NONE32;
+        return;
+    }
+    if (np > 64 || (int)np > p.skip_low_complexity_thr) {
+        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
+        return;
+    }
+    const uint32_t *side = is_left ? w.gpl : w.gpr;
+    // ---- per-lane pair metadata
+    uint32_t rd = lane < (int)np ? side[begin + lane] : NONE32;
+    const bool has = rd != NONE32;
+    int pos = 0, lq = 0, nc = 0, rrp = 0; uint32_t c0 = 0; uint64_t cigo = 0, so = 0, qo = 0;
+    if (has) {
+        gce_core k = b.core[rd];
+        pos = k.pos; lq = k.l_qseq; nc = k.n_cigar;
+        cigo = b.cigar_off[rd]; so = b.seq_off[rd]; qo = b.qual_off[rd];
+        if (nc > 0) c0 = b.cigar[cigo];
+        if (!is_left) rrp = pos + (nc == 1 ? cig_len(c0) * consumes_ref(cig_op(c0)) : d_cigar_rlen(b.cigar + cigo, nc));
+    }
+    const unsigned long long hmask = __ballot(has);
+    if (!hmask) { if (lane == 0) rp_out[gi] = NONE32; return; }              // no read on this side: "no majority" / out == NULL
+    // ---- leftReadMode (group.cpp:177-194)
+    bool left_mode = is_left;
+    if (!is_left) {
+        int p0 = rl32(pos, __ffsll((long long)hmask) - 1);
+        if (!__any(has && pos != p0)) left_mode = true;
+    }
+    // ---- containedBy (group.cpp:196-233)
+    int cb = has ? 1 : 0;
+    for (unsigned long long m = hmask; m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const int wnc = rl32(nc, j), wrrp = rl32(rrp, j); const uint32_t wc0 = (uint32_t)rl32((int)c0, j); const uint64_t wcig = rl64(cigo, j);
+        if (has && lane != j && (is_left || rrp == wrrp) && part_of_fast(c0, nc, b.cigar + cigo, wc0, wnc, b.cigar + wcig, left_mode)) cb++;
+    }
+    // ---- template: max containedBy, then shorter, then first in qname order (group.cpp:235-261)
+    int best = lane < (int)np ? lane : 0x7FFFFFFF, bc = lane < (int)np ? cb : -1, bl = has ? lq : 0;
+    for (int o = 32; o > 0; o >>= 1) {
+        int ob = __shfl_xor(best, o), oc = __shfl_xor(bc, o), ol = __shfl_xor(bl, o);
+        bool better = oc > bc || (oc == bc && (ol < bl || (ol == bl && ob < best)));
+        if (better) { best = ob; bc = oc; bl = ol; }
+    }
+    if ((double)bc < (double)np * 0.4 && np != 1) { if (lane == 0) rp_out[gi] = NONE32; return; }        // group.cpp:264-266
+    const uint32_t out = (uint32_t)rl32((int)rd, best);
+    if (out == NONE32) { if (lane == 0) rp_out[gi] = NONE32; return; }
+    const int o_pos = rl32(pos, best), o_lq = rl32(lq, best), o_nc = rl32(nc, best); const uint32_t o_c0 = (uint32_t)rl32((int)c0, best);
+    const uint64_t o_cigo = rl64(cigo, best), o_so = rl64(so, best), o_qo = rl64(qo, best);
+    const uint32_t *ocig = b.cigar + o_cigo;
+    // ---- voters and lenDiff (group.cpp:287-313,339-348)
+    bool take = false; int ld = 0;
+    if (has) {
+        take = lane == best || part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, left_mode);
+        if (take) { ld = lq - o_lq; if (ld != 0 && pos == o_pos && part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, true)) ld = 0; }
+    }
+    const unsigned long long vmask = __ballot(take);
+    int len = o_lq;
+    if (o_nc == 0) len = wave_min(take ? lq : 0x7FFFFFFF);                    // group.cpp:354-360
+    const int nbytes = (len + 1) >> 1;
+    if (nbytes > 256) {                                                       // very long template: generic kernel
+        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
+        return;
+    }
+    const gce_core ok = b.core[out];
+    const uint8_t *ref = nullptr; int64_t ref_len = 0;
+    if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {                  // group.cpp:362-367 -> Reference::getData
+        const uint8_t *rdp = p.ref_data[ok.tid];
+        int64_t need_len = (int64_t)d_ref_offset(ocig, o_nc, len - 1) + 1;
+        if (rdp && (int64_t)o_pos + need_len < p.ref_len[ok.tid]) { ref = rdp; ref_len = p.ref_len[ok.tid]; }
+    }
+    uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
+    uint8_t *res = s_res[wv];
+    int minc = 0; bool odd = false;
+    for (int it = 0; it * 64 < nbytes; it++) {
+        const int bi = it * 64 + lane, col0 = bi * 2;
+        const bool a0 = col0 < len, a1 = col0 + 1 < len;
+        Tally5 t0, t1; tally_clear(t0); tally_clear(t1);
+        for (unsigned long long m = vmask; m; m &= m - 1) {
+            const int v = __ffsll((long long)m) - 1;
+            const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+            const int r0 = col0 + vld, r1 = r0 + 1;
+            const uint8_t *vs = b.seq + vso; const uint8_t *vq = b.qual + vqo; const int8_t *vsc = w.score + vqo;
+            const bool in0 = a0 && r0 >= 0 && r0 < vlq, in1 = a1 && r1 >= 0 && r1 < vlq;
+            if (in0 && in1 && !(r0 & 1)) {                                   // aligned pair of columns: one seq byte, 2+2 bytes
+                uint8_t sb = vs[r0 >> 1];
+                uint16_t qq = *(const u16_unaligned *)(vq + r0), ss = *(const u16_unaligned *)(vsc + r0);
+                int q0 = qq & 0xFF, q1 = qq >> 8;
+                if (!tally_add(t0, sb >> 4, q0, (int)(int8_t)(ss & 0xFF))) odd = true;
+                if (!tally_add(t1, sb & 0xF, q1, (int)(int8_t)(ss >> 8))) odd = true;
+                if ((q0 | q1) & 0x80) odd = true;
+            } else {
+                if (in0) { int q0 = vq[r0]; if (!tally_add(t0, d_nib(vs, r0), q0, vsc[r0]) || (q0 & 0x80)) odd = true; }
+                if (in1) { int q1 = vq[r1]; if (!tally_add(t1, d_nib(vs, r1), q1, vsc[r1]) || (q1 & 0x80)) odd = true; }
             }
         }
-        left = side_consensus(b, p, w, begin, np, true, s_tally[wv], lane);
-        right = side_consensus(b, p, w, begin, np, false, s_tally[wv], lane);
-        merge = np;
-        if (lane == 0) {
-            if (cross) { if (left != NONE32 && ntc != NONE32 && ntc != left) {           // group.cpp:109-112
-                    if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
-                    w.qname_src[left] = ntc; } }
-            else if (left != NONE32 && right != NONE32) {                                  // group.cpp:114-123
-                if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
-                else w.qname_src[left] = right;
+        if (a0) {
+            uint8_t ob = oseq[bi];
+            int hi = ob >> 4, lo = ob & 0xF, q0 = 0, q1 = 0;
+            int ref0 = 0, ref1 = 0;
+            if (ref) {
+                int ro = d_ref_offset(ocig, o_nc, col0);
+                if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref0 = d_ref_nib(ref, (int64_t)o_pos + ro);
+                if (a1) { ro = d_ref_offset(ocig, o_nc, col0 + 1); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref1 = d_ref_nib(ref, (int64_t)o_pos + ro); }
             }
+            ColOut r0 = decide_column(t0, p, hi, ref0); hi = r0.base; q0 = r0.qual; minc += r0.minc;
+            if (a1) { ColOut r1 = decide_column(t1, p, lo, ref1); lo = r1.base; q1 = r1.qual; minc += r1.minc; }
+            res[bi] = (uint8_t)((hi << 4) | lo); res[256 + bi] = (uint8_t)q0; res[512 + bi] = (uint8_t)q1;
         }
     }
-    if (lane == 0) {
-        // Pair::setLeft / setRight on the new Pair (group.cpp:124-132 -> pair.cpp:188-216)
-        const char *u = nullptr; int ul = 0;
-        if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
-        if (right != NONE32) {
-            const char *u2; int ul2;
-            d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
-            if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
-            u = u2; ul = ul2;
-        }
-        w.rp_left[gi] = left; w.rp_right[gi] = right; w.rp_merge[gi] = merge; w.rp_rmerge[gi] = 0;
-        w.rp_umi[gi] = u; w.rp_umilen[gi] = (uint16_t)ul; w.rp_state[gi] = RP_PENDING; w.rp_supp[gi] = -1;
+    if (__any(odd)) {                                                         // exotic nibble or qual >= 128 among the voters
+        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
+        return;
     }
+    minc = wave_sum(minc);
+    bool restore = false;
+    if (minc != 0) {                                                          // group.cpp:528-573
+        if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+        else if (minc > 5) restore = true;
+        else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+    }
+    if (!restore) {
+        for (int bi = lane; bi < nbytes; bi += 64) {
+            oseq[bi] = res[bi];
+            oqual[2 * bi] = res[256 + bi];
+            if (2 * bi + 1 < len) oqual[2 * bi + 1] = res[512 + bi];
+        }
+    }
+    if (lane == 0) rp_out[gi] = out;
 }
 
 // ===================================================================================================== finish
@@ -959,6 +1152,47 @@ __global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w,
     uint32_t G = w.cl_ngroups[c];
     if (G == 0) { if (lane == 0) w.cl_nresult[c] = 0; return; }
     uint32_t g0 = w.cl_gbase[c];
+    // ---- the tail of Group::consensusMerge per group (group.cpp:104-132): mMergeReads, qname reconciliation, Pair UMI
+    {
+        const uint32_t cstart = w.cl_start[c];
+        gce_core oc = b.core[(uint32_t)w.table[w.cl_slot[c]]];
+        const bool cross = d_key(oc, p).right < 0;
+        for (uint32_t base = 0; base < G; base += 64) {
+            uint32_t g = base + lane;
+            if (g >= G) continue;
+            uint32_t gi = g0 + g, begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
+            uint32_t left = w.rp_left[gi], right = w.rp_right[gi];
+            bool single = np == 1 && w.gpr[begin] == NONE32;
+            if (!single) {
+                if (cross) {                                                  // group.cpp:79-99,109-112
+                    uint32_t ntc = NONE32; int bl = 0;
+                    for (uint32_t k = 0; k < np; k++) {
+                        uint32_t l = w.gpl[begin + k];
+                        int ll = d_lqname_pad(b.core[l]);
+                        if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
+                    }
+                    if (left != NONE32 && ntc != NONE32 && ntc != left) {
+                        if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
+                        w.qname_src[left] = ntc;
+                    }
+                } else if (left != NONE32 && right != NONE32) {               // group.cpp:114-123
+                    if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
+                    else w.qname_src[left] = right;
+                }
+            }
+            const char *u = nullptr; int ul = 0;                              // Pair::setLeft / setRight (pair.cpp:188-216)
+            if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
+            if (right != NONE32) {
+                const char *u2; int ul2;
+                d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
+                if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
+                u = u2; ul = ul2;
+            }
+            w.rp_merge[gi] = single ? 1 : np; w.rp_rmerge[gi] = 0;
+            w.rp_umi[gi] = u; w.rp_umilen[gi] = (uint16_t)ul; w.rp_state[gi] = RP_PENDING; w.rp_supp[gi] = -1;
+        }
+        WAVE_SYNC();
+    }
     uint32_t nres = 0;
     if (w.cl_hasumi[c] && !p.disable_duplex) {                                       // cluster.cpp:119-168
         for (int idx = (int)G - 1; idx >= 0; idx--) {

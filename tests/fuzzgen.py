@@ -20,7 +20,7 @@ def _mutate(seq, rate, rng):
     return "".join(out)
 
 
-def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None):
+def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=False):
     """Returns (ReadBatch, params overrides dict, reference list [(nibble array|None, n_bases)], contig lengths)."""
     from oracle import oracle_py
     rng = random.Random(seed)
@@ -98,6 +98,11 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None):
                 name += ":UMI_" + (ua + "_" + ub if strand == 0 else ub + "_" + ua)
             qf = [rng.choice(QUALS) for _ in fseq]
             qr = [rng.choice(QUALS) for _ in rseq]
+            if exotic:          # IUPAC codes (BAM nibbles outside A,C,G,T,N) and out-of-spec quals: generic-kernel paths
+                fseq = "".join(rng.choice("MRWSYKVHDB=") if rng.random() < 0.02 else ch for ch in fseq)
+                rseq = "".join(rng.choice("MRWSYKVHDB=") if rng.random() < 0.02 else ch for ch in rseq)
+                qf = [rng.choice([128, 200, 255]) if rng.random() < 0.01 else x for x in qf]
+                qr = [rng.choice([128, 200, 255]) if rng.random() < 0.01 else x for x in qr]
             if rng.random() < 0.7:                          # mostly-good reads so consensus paths vary
                 qf = [37 if rng.random() < 0.8 else x for x in qf]
                 qr = [37 if rng.random() < 0.8 else x for x in qr]

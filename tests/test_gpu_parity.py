@@ -39,6 +39,13 @@ def test_fuzz_umi_modes(built, seed, umi_mode, period):
     run_both(batch, fuzzgen.make_params(over, contig_len), reference)
 
 
+@pytest.mark.parametrize("seed", range(600, 612))
+def test_fuzz_exotic_nibbles_and_quals(built, seed):
+    """IUPAC nibbles and quals >= 128: the register-tally fast kernel must hand these group sides to the generic kernel."""
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=50, exotic=True)
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
 @pytest.mark.parametrize("seed,deep", [(200, 70), (201, 150), (202, 300)])
 def test_fuzz_deep_cluster(built, seed, deep):
     """> 64 pairs in one cluster: multi-chunk wave loops; depth 300 also wraps the FR byte (quirk Q8)."""
