@@ -39,7 +39,7 @@ struct gce_engine {
     hipEvent_t ev[EV_COUNT]{};
     // reference
     std::vector<DevBuf> ref_buf; std::vector<const uint8_t *> ref_ptr; std::vector<int64_t> ref_len;
-    DevBuf d_ref_ptr, d_ref_len, d_target_len;
+    DevBuf d_ref_ptr, d_ref_len, d_target_len, d_target_cum;
     // host staging (gce_submit)
     std::vector<gce_core> h_core; std::vector<uint64_t> h_qoff, h_coff, h_soff, h_loff, h_mioff;
     std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm;
@@ -119,7 +119,7 @@ void gce_destroy(gce_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
+    DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
                      &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi,
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
@@ -270,6 +270,13 @@ int gce_process(gce_engine *e) {
     }
     HIPCHK(e->d_target_len.ensure(e->target_len.size() * 4 + 4));
     if (!e->target_len.empty()) HIPCHK(hipMemcpyAsync(e->d_target_len.p, e->target_len.data(), e->target_len.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e->d_target_cum.ensure(e->target_len.size() * 8 + 8));
+    if (!e->target_len.empty()) {
+        std::vector<uint64_t> cum(e->target_len.size()); uint64_t acc = 0;
+        for (size_t i = 0; i < cum.size(); i++) { cum[i] = acc; acc += e->target_len[i]; }
+        HIPCHK(hipMemcpyAsync(e->d_target_cum.p, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     DevParams p{};
     p.proper_thr = e->prm.proper_umi_diff_threshold; p.unproper_thr = e->prm.unproper_umi_diff_threshold;
     p.duplex_mismatch_thr = e->prm.duplex_mismatch_threshold; p.cluster_size_req = e->prm.cluster_size_req; p.base_score_req = e->prm.base_score_req;
@@ -278,7 +285,7 @@ int gce_process(gce_engine *e) {
     p.skip_low_complexity_thr = e->prm.skip_low_complexity_cluster_threshold; p.duplex_only = e->prm.duplex_only; p.disable_duplex = e->prm.disable_duplex;
     p.period = e->prm.flush_period; p.score_percent_req = e->prm.score_percent_req;
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
-    p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>();
+    p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
     p.tick_offset = e->prm.tick_offset; p.trailing_flush = e->prm.trailing_flush;
     p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
 
@@ -298,7 +305,8 @@ int gce_process(gce_engine *e) {
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
     ENS(table, T * 8); ENS(tcount, T * 4); ENS(toff, T * 4);
     ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
-    ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4);
+    ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
+    w.slow_list = e->slow_list.as<uint32_t>();
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, (size_t)(nblk_T > nblk_N ? nblk_T : nblk_N) * 8 + 8); ENS(si, sizeof(StreamInfo));
     w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>();
@@ -321,7 +329,7 @@ int gce_process(gce_engine *e) {
     HIPCHK(hipEventRecord(e->ev[EV_START], s));
     if (N > 0) {
         // ---- prescan + tick scan + flush events
-        int cpb = (int)((n_chunks + 4095) / 4096); if (cpb < 1) cpb = 1;
+        int cpb = (int)((n_chunks + 32767) / 32768); if (cpb < 1) cpb = 1;
         hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
         hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
         hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
@@ -346,7 +354,9 @@ int gce_process(gce_engine *e) {
     w.cl_nresult = e->cl_nresult.as<uint32_t>(); w.cl_hasumi = e->cl_hasumi.as<uint8_t>();
     uint32_t NG = 0;
     if (C > 0 && e->h_si.error == 0) {
-        hipLaunchKernelGGL(k_pairing, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+        HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score recognises pair slots by gpl != NONE
+        hipLaunchKernelGGL(k_pairing_fast, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+        hipLaunchKernelGGL(k_pairing_slow, dim3(512), dim3(256), 0, s, b, p, w);
         const unsigned nblk_C = cdiv(C, SCAN_TILE);
         hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, (uint64_t)C, w.scan_part);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_C, &w.si->n_pairs /*scratch*/, &w.si->n_groups);
@@ -357,14 +367,14 @@ int gce_process(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(slow_list, g1 * 8); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gl_cluster, g1 * 4); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
-    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.slow_list = e->slow_list.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
+    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     if (NG > 0 && e->h_si.error == 0) {
         hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
-        hipLaunchKernelGGL(k_score, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * 4)), dim3(256), 0, s, b, p, w, (uint32_t)N);
         HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);

@@ -35,6 +35,7 @@ struct DevParams {
     int32_t prefix_len;
     int32_t n_targets;
     const uint32_t *target_len;
+    const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
     int64_t tick_offset;
     int32_t trailing_flush;
     int32_t n_ref;
@@ -51,7 +52,7 @@ struct StreamInfo {
     int n_events;                        // E: flush events inside this slice
     int n_events_a;                      // E_A: events whose read index < U
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
-    unsigned int pad0;
+    unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
@@ -268,14 +269,15 @@ __device__ __forceinline__ ClusterKey d_key(const gce_core &c, const DevParams &
     }
     return k;
 }
-__device__ __forceinline__ uint64_t d_key_hash(const ClusterKey &k, uint32_t inst) {
-    uint64_t h = (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
-    h ^= ((uint64_t)(uint32_t)k.left + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
-    h ^= h >> 31;
-    h ^= (uint64_t)k.right * 0x165667B19E3779F9ull;
-    h ^= (uint64_t)inst * 0xD6E8FEB86659FD93ull;
-    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-    return h;
+// Bucket of a cluster key.  The stream is coordinate sorted, so consecutive reads carry neighbouring `left` values:
+// a LOCALITY-PRESERVING bucket index (genome-linear left, two buckets per position, low bit from right/instance) makes
+// the table accesses of the clustering scan a sliding window that lives in L2 instead of 64-byte random HBM touches.
+// Collisions (same left, other right/instance, or positions 2^k apart) fall through to linear probing.
+__device__ __forceinline__ uint64_t d_key_hash(const ClusterKey &k, uint32_t inst, const DevParams &p) {
+    uint64_t g = (k.tid >= 0 && k.tid < p.n_targets && p.target_cum) ? p.target_cum[k.tid] : (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
+    uint64_t m = ((uint64_t)k.right * 0x165667B19E3779F9ull) ^ ((uint64_t)inst * 0xD6E8FEB86659FD93ull);
+    m ^= m >> 29;
+    return ((g + (uint64_t)(uint32_t)k.left) << 1) | (m & 1);
 }
 
 // padded in-memory l_qname (htslib l_extranul)

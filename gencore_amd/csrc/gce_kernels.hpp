@@ -51,6 +51,12 @@ enum : uint8_t { RP_PENDING = 0, RP_OUT_SSCS = 1, RP_OUT_DCS = 2, RP_DROPPED = 3
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+__device__ __forceinline__ int rl32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ long long wave_sum64(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
@@ -192,47 +198,62 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
     unsigned long long m = __ballot(cl);
     if (lane == 0) s_cnt[wv] = __popcll(m);
     __syncthreads();
-    if (i >= b.n) return;
-    if (!cl) { w.slot[i] = NONE32; return; }
-    unsigned int inblock = lanes_below(m) + 1;
-    for (int q = 0; q < wv; q++) inblock += s_cnt[q];
-    long long per = p.period;
-    long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x] + inblock;      // the reference's `tick` after ++
-    int e = (int)((tick - 1) / per - p.tick_offset / per);                              // flush events before this read
-    const StreamInfo *si = w.si;
-    unsigned int U = si->first_unmapped;
-    bool seg_b = (U != NONE32) && ((unsigned)i > U);
-    ClusterKey key = d_key(k, p);
-    // first event of this segment whose walk takes the key (gencore.cpp:333-354):
-    //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
-    int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
-    int a = lo, z = hi;
-    while (a < z) {
-        int mid = (a + z) >> 1;
-        int T = w.ev_tid[mid], P = w.ev_pos[mid];
-        bool cond = key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P);
-        if (cond) z = mid; else a = mid + 1;
-    }
-    int f = a + 1;                                                                      // 1-based; hi+1 if none
-    uint32_t inst = (uint32_t)max(e, f - 1);
-    uint32_t ikey = inst | (seg_b ? 0x80000000u : 0u);
-    uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
-    uint64_t h = d_key_hash(key, ikey) & w.tmask;
-    for (;;) {
-        uint64_t cur = w.table[h];
-        if (cur == EMPTY64) {
-            cur = atomicCAS((unsigned long long *)&w.table[h], (unsigned long long)EMPTY64, (unsigned long long)mine);
-            if (cur == EMPTY64) break;                                                  // claimed: this read owns the bucket
+    uint64_t h = ~0ull;
+    if (cl) {
+        unsigned int inblock = lanes_below(m) + 1;
+        for (int q = 0; q < wv; q++) inblock += s_cnt[q];
+        long long per = p.period;
+        long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x] + inblock;      // the reference's `tick` after ++
+        int e = (int)((tick - 1) / per - p.tick_offset / per);                              // flush events before this read
+        const StreamInfo *si = w.si;
+        unsigned int U = si->first_unmapped;
+        bool seg_b = (U != NONE32) && ((unsigned)i > U);
+        ClusterKey key = d_key(k, p);
+        // first event of this segment whose walk takes the key (gencore.cpp:333-354):
+        //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
+        int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
+        int a = lo, z = hi;
+        while (a < z) {
+            int mid = (a + z) >> 1;
+            int T = w.ev_tid[mid], P = w.ev_pos[mid];
+            bool cond = key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P);
+            if (cond) z = mid; else a = mid + 1;
         }
-        if ((uint32_t)(cur >> 32) == ikey) {
-            gce_core oc = b.core[(uint32_t)cur];
-            ClusterKey ok = d_key(oc, p);
-            if (ok.tid == key.tid && ok.left == key.left && ok.right == key.right) break;
+        int f = a + 1;                                                                      // 1-based; hi+1 if none
+        uint32_t inst = (uint32_t)max(e, f - 1);
+        uint32_t ikey = inst | (seg_b ? 0x80000000u : 0u);
+        uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
+        h = d_key_hash(key, ikey, p) & w.tmask;
+        for (;;) {
+            uint64_t cur = w.table[h];
+            if (cur == EMPTY64) {
+                cur = atomicCAS((unsigned long long *)&w.table[h], (unsigned long long)EMPTY64, (unsigned long long)mine);
+                if (cur == EMPTY64) break;                                                  // claimed: this read owns the bucket
+            }
+            if ((uint32_t)(cur >> 32) == ikey) {
+                gce_core oc = b.core[(uint32_t)cur];
+                ClusterKey ok = d_key(oc, p);
+                if (ok.tid == key.tid && ok.left == key.left && ok.right == key.right) break;
+            }
+            h = (h + 1) & w.tmask;
         }
-        h = (h + 1) & w.tmask;
     }
-    w.slot[i] = (uint32_t)h;
-    w.rank[i] = atomicAdd(&w.tcount[h], 1u);
+    // ---- in-cluster rank: neighbouring lanes that landed in the same bucket (sorted input => runs) share ONE atomicAdd
+    const uint64_t hprev = (uint64_t)__shfl_up((long long)h, 1);
+    const bool head = cl && (lane == 0 || hprev != h);
+    const unsigned long long heads = __ballot(head), bounds = __ballot(head || !cl);
+    uint32_t rbase = 0;
+    if (head) {
+        unsigned long long later = bounds & ~((2ull << lane) - 1ull);
+        int next = later ? __ffsll((long long)later) - 1 : 64;
+        rbase = atomicAdd(&w.tcount[h], (unsigned)(next - lane));
+    }
+    const int hl = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));            // my run's head lane (valid when cl)
+    const uint32_t hb = (uint32_t)__shfl((int)rbase, hl < 0 ? 0 : hl);
+    if (i < b.n) {
+        if (cl) { w.slot[i] = (uint32_t)h; w.rank[i] = hb + (uint32_t)(lane - hl); }
+        else w.slot[i] = NONE32;
+    }
 }
 
 // ===================================================================================================== table scan (3 phases)
@@ -313,10 +334,8 @@ __global__ void k_scatter(int64_t n, Work w) {
 // ===================================================================================================== pairing + UMI grouping
 __device__ __forceinline__ const char *d_qname(const DevBatch &b, uint32_t r) { return b.qname + b.qname_off[r]; }
 
-__global__ __launch_bounds__(256) void k_pairing(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
-    const int lane = lane_id();
-    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (c >= n_clusters) return;
+// generic path: any cluster size / name length, cluster-local global scratch
+__device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
     uint64_t entry = w.table[w.cl_slot[c]];
     uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
@@ -442,6 +461,137 @@ __global__ __launch_bounds__(256) void k_pairing(DevBatch b, DevParams p, Work w
     if (lane == 0) { w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)any_umi; }
 }
 
+
+__global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, Work w) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t n_slow = w.si->n_slow_pair;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
+        pairing_generic(b, p, w, w.slow_list[idx], lane);
+        WAVE_SYNC();
+    }
+}
+
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint64_t d_bswap64(uint64_t x) { return __builtin_bswap64(x); }
+// up to 8*NW bytes of a string as big-endian words, zero padded: integer order == strcmp order
+template <int NW>
+__device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (&wd)[NW]) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint64_t v = 0;
+        int rem = len - 8 * k;
+        if (rem > 0) {
+            v = *(const u64_unaligned *)(s + 8 * k);
+            if (rem < 8) v &= (1ull << (8 * rem)) - 1ull;
+            v = d_bswap64(v);
+        }
+        wd[k] = v;
+    }
+}
+__device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
+    x |= x >> 4; x |= x >> 2; x |= x >> 1;
+    return __popcll(x & 0x0101010101010101ull);
+}
+
+// One wave per cluster, <= 64 reads, names <= 64 bytes, UMIs <= 24 bytes: everything in registers.
+__global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+    const int lane = lane_id();
+    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (c >= n_clusters) return;
+    const uint32_t start = w.cl_start[c], n = w.cl_n[c];
+    uint64_t entry = w.table[w.cl_slot[c]];
+    uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
+    if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }
+    const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
+    bool defer = n > 64;
+    uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0;
+    if (!defer && lane < (int)n) {
+        my = w.members[start + lane];
+        nl = (int)b.core[my].l_qname - 1;
+        nm = d_qname(b, my);
+        ul = w.umi_len[my];
+    }
+    if (!defer && __any(nl > 64 || ul > 24)) defer = true;
+    if (defer) { if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; return; }
+    const bool act = lane < (int)n;
+    uint64_t nw[8];
+    load_be_words<8>(nm, act ? nl : 0, nw);
+    const int nwords = (wave_max(nl) + 7) >> 3;
+    // ---- order relations against every other read: LT (name strictly smaller), EQ (same name), LOW (smaller input index)
+    unsigned long long LT = 0, EQ = 0, LOW = 0;
+    for (int j = 0; j < (int)n; j++) {
+        int cmp = 0;                                        // sign of name_j - name_mine
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k < nwords) {
+                uint64_t o = rl64(nw[k], j);
+                if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
+            }
+        }
+        uint32_t oj = (uint32_t)rl32((int)my, j);
+        if (cmp < 0) LT |= 1ull << j;
+        if (cmp == 0 && j != lane) EQ |= 1ull << j;
+        if (oj < my) LOW |= 1ull << j;
+    }
+    // ---- pairs (cluster.cpp:260-273, pair.cpp:188-216): first read of a name = mLeft, last one = mRight
+    const bool first = act && !(EQ & LOW), last = act && !(EQ & ~LOW);
+    const unsigned long long FIRST = __ballot(first);
+    const uint32_t npairs = __popcll(FIRST);
+    const uint32_t pidx = __popcll(LT & FIRST);             // distinct names before mine
+    if (act && !first) {                                    // setRight: UMI must equal the pair's current UMI if that is non-empty
+        unsigned long long prev = EQ & LOW;                 // predecessor in arrival order = largest index among them
+        uint32_t pv = NONE32; 
+        for (unsigned long long m = prev; m; m &= m - 1) { uint32_t o = w.members[start + (__ffsll((long long)m) - 1)]; if (pv == NONE32 || o > pv) pv = o; }
+        if (w.umi_len[pv] != 0 && !d_bytes_equal(w.umi_ptr[pv], w.umi_len[pv], w.umi_ptr[my], w.umi_len[my])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
+    }
+    if (act) {
+        if (first) { w.pl[start + pidx] = my; if (last) w.pr[start + pidx] = NONE32; }
+        if (last && !first) w.pr[start + pidx] = my;
+        if (last) w.pu[start + pidx] = my;
+    }
+    const int any_umi = __any(act && last && ul > 0);
+    WAVE_SYNC();
+    // ---- lanes now stand for pairs (qname order)
+    const bool pact = lane < (int)npairs;
+    uint32_t L = NONE32, R = NONE32, g_of = 0, ngroups = 1;
+    if (pact) { L = w.pl[start + lane]; R = w.pr[start + lane]; }
+    if (any_umi) {                                           // greedy UMI grouping (cluster.cpp:57-100)
+        uint64_t uw[3] = {0, 0, 0}; int ulen = 0;
+        if (pact) { uint32_t ur = w.pu[start + lane]; ulen = w.umi_len[ur]; load_be_words<3>(w.umi_ptr[ur], ulen, uw); }
+        int cnt = 0, urank = 0;                              // umiCount[umi], and the rank of my UMI in std::string order
+        for (int q = 0; q < (int)npairs; q++) {
+            uint64_t a0 = rl64(uw[0], q), a1 = rl64(uw[1], q), a2 = rl64(uw[2], q); int al = rl32(ulen, q);
+            bool eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
+            bool lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
+            cnt += eq; urank += lt;
+        }
+        g_of = NONE32; ngroups = 0;
+        unsigned long long remaining = __ballot(pact);
+        while (remaining) {
+            int key = (pact && g_of == NONE32) ? (cnt * 64 + (63 - urank)) : -1;     // highest count, then smallest UMI
+            int best = wave_max(key);
+            int tl = __ffsll((long long)__ballot(key == best)) - 1;
+            uint64_t t0 = rl64(uw[0], tl), t1 = rl64(uw[1], tl), t2 = rl64(uw[2], tl);
+            int diff = popc_nonzero_bytes(t0 ^ uw[0]) + popc_nonzero_bytes(t1 ^ uw[1]) + popc_nonzero_bytes(t2 ^ uw[2]);   // Cluster::umiDiff
+            bool take = pact && g_of == NONE32 && diff <= thr;
+            if (take) g_of = ngroups;
+            remaining &= ~__ballot(take);
+            ngroups++;
+        }
+    }
+    // ---- lay the pairs out group by group (qname order inside a group)
+    uint32_t gbase = 0;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        unsigned long long m = __ballot(pact && g_of == g);
+        if (pact && g_of == g) { uint32_t d = start + gbase + lanes_below(m); w.gpl[d] = L; w.gpr[d] = R; }
+        uint32_t run = __popcll(m);
+        if (lane == 0) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
+        gbase += run;
+    }
+    if (lane == 0) { w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)any_umi; }
+}
+
 // exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word
 __global__ void k_group_fill(Work w, uint32_t n_clusters) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,53 +624,106 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 }
 
 // ===================================================================================================== scoring
-// Pair::computeScore for every pair of a group that enters consensusMerge beyond the early return (group.cpp:73-77).
-__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
-    const int lane = lane_id();
-    uint32_t gi = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (gi >= n_groups) return;
-    uint32_t c = w.gl_cluster[gi];
-    uint32_t g = gi - w.cl_gbase[c];
-    uint32_t begin = w.grp_begin[w.cl_start[c] + g], np = w.grp_n[w.cl_start[c] + g];
-    if (np == 1 && w.gpr[begin] == NONE32) return;
-    for (uint32_t k = 0; k < np; k++) {
-        uint32_t L = w.gpl[begin + k], R = w.gpr[begin + k];
-        gce_core lk = b.core[L];
-        int8_t *ls = w.score + b.qual_off[L];
-        if (R == NONE32) { for (int i = lane; i < lk.l_qseq; i += 64) ls[i] = (int8_t)p.s_moderate; continue; }   // pair.cpp:89-105 (memset only)
-        gce_core rk = b.core[R];
-        int8_t *rs = w.score + b.qual_off[R];
-        int lmo, lml, rmo, rml;
-        d_first_m(b.cigar + b.cigar_off[L], lk.n_cigar, lmo, lml);
-        d_first_m(b.cigar + b.cigar_off[R], rk.n_cigar, rmo, rml);
-        if (!(lml > 0 && rml > 0)) {
-            for (int i = lane; i < lk.l_qseq; i += 64) ls[i] = (int8_t)p.s_moderate;
-            for (int i = lane; i < rk.l_qseq; i += 64) rs[i] = (int8_t)p.s_moderate;
-            continue;
-        }
-        int dis = rk.pos - lk.pos, lstart, rstart, cmp;
-        if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
-        else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
-        const uint8_t *lseq = b.seq + b.seq_off[L], *rseq = b.seq + b.seq_off[R];
-        uint8_t *lq = b.qual + b.qual_off[L], *rq = b.qual + b.qual_off[R];
-        for (int l = lane; l < lk.l_qseq; l += 64) {
-            int ql = lq[l];
-            if (l >= lstart && l < lstart + cmp) {
-                int r = rstart + (l - lstart);
-                int qr = rq[r];
-                if (d_nib(lseq, l) == d_nib(rseq, r)) {                   // pair.cpp:148-154
-                    int s = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4;
-                    ls[l] = (int8_t)s; rs[r] = (int8_t)s;
-                } else {                                                   // pair.cpp:155-168: quals rewritten in place
-                    lq[l] = (uint8_t)max(0, ql - qr);
-                    rq[r] = (uint8_t)max(0, qr - ql);
-                    if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3); rs[r] = 0; }
-                    else { ls[l] = 0; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3); }
+// Pair::computeScore (pair.cpp:88-172).  16 lanes per pair slot, 4 slots per wave (gpl/gpr are pre-filled with NONE32,
+// so a slot is a pair iff gpl != NONE32): the kernel is bound by the dependent metadata chain slot -> reads -> core ->
+// CIGAR -> bases, so four independent chains share one wave and every level of the chain is issued as one batch.
+// Pairs of groups that never reach a vote get scores too; nothing reads them and no qual is touched for a mate-less
+// pair, so the result is identical to the reference's lazy evaluation.
+__device__ __forceinline__ uint32_t score4_plain(const DevParams &p, uint32_t q4) {
+    uint32_t s4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s4 |= (uint32_t)(d_qual2score(p, (q4 >> (8 * k)) & 0xFF) & 0xFF) << (8 * k);
+    return s4;
+}
+__device__ __forceinline__ void first_m_fast(const uint32_t *cig, int n, uint32_t c0, int &off, int &len) {
+    if (n >= 1 && cig_op(c0) == 0) { off = 0; len = cig_len(c0); return; }     // the common "150M" / leading-M case
+    d_first_m(cig, n, off, len);
+}
+__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots) {
+    const int lane = lane_id(), sl = lane & 15;
+    const uint32_t slot = ((blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) << 2) + (lane >> 4);
+    if (slot >= n_slots) return;
+    const uint32_t L = w.gpl[slot], R = w.gpr[slot];
+    if (L == NONE32) return;
+    const gce_core lk = b.core[L];
+    const uint64_t lqo = b.qual_off[L];
+    int8_t *ls = w.score + lqo;
+    const int llen = lk.l_qseq;
+    if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
+        return;
+    }
+    const gce_core rk = b.core[R];
+    const uint64_t rqo = b.qual_off[R], lso = b.seq_off[L], rso = b.seq_off[R], lco = b.cigar_off[L], rco = b.cigar_off[R];
+    const uint32_t lc0 = lk.n_cigar ? b.cigar[lco] : 0, rc0 = rk.n_cigar ? b.cigar[rco] : 0;
+    int8_t *rs = w.score + rqo;
+    const int rlen = rk.l_qseq;
+    int lmo, lml, rmo, rml;
+    first_m_fast(b.cigar + lco, lk.n_cigar, lc0, lmo, lml);
+    first_m_fast(b.cigar + rco, rk.n_cigar, rc0, rmo, rml);
+    if (!(lml > 0 && rml > 0)) {
+        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
+        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)p.s_moderate; }
+        return;
+    }
+    int dis = rk.pos - lk.pos, lstart, rstart, cmp;
+    if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
+    else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
+    const uint8_t *lseq = b.seq + lso, *rseq = b.seq + rso;
+    uint8_t *lq = b.qual + lqo, *rq = b.qual + rqo;
+    // 4 consecutive bases per lane: one (unaligned) dword for quals/scores, one for the packed nibbles.
+    // Device blobs are readable a few bytes past their end (contract of gce_submit_device; gce_submit pads).
+    const int ov_end = lstart + cmp;
+    for (int l0 = sl * 4; l0 < llen; l0 += 64) {
+        const int n4 = min(4, llen - l0);
+        const bool all_in = n4 == 4 && l0 >= lstart && l0 + 4 <= ov_end;
+        const bool all_out = n4 == 4 && (l0 + 4 <= lstart || l0 >= ov_end || cmp <= 0);
+        if (all_out) {
+            *(u32_unaligned *)(ls + l0) = score4_plain(p, *(const u32_unaligned *)(lq + l0));
+        } else if (all_in) {
+            const int r0 = rstart + (l0 - lstart);
+            uint32_t ql4 = *(const u32_unaligned *)(lq + l0), qr4 = *(const u32_unaligned *)(rq + r0);
+            uint32_t ln4 = *(const u32_unaligned *)(lseq + (l0 >> 1)), rn4 = *(const u32_unaligned *)(rseq + (r0 >> 1));
+            uint32_t sl4 = 0, sr4 = 0, nql4 = ql4, nqr4 = qr4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int lp = (l0 & 1) + k, rp = (r0 & 1) + k;                       // nibble index inside the loaded dword
+                const int lb = (ln4 >> (8 * (lp >> 1) + ((lp & 1) ? 0 : 4))) & 0xF, rb = (rn4 >> (8 * (rp >> 1) + ((rp & 1) ? 0 : 4))) & 0xF;
+                const int ql = (ql4 >> (8 * k)) & 0xFF, qr = (qr4 >> (8 * k)) & 0xFF;
+                int s_l, s_r;
+                if (lb == rb) { s_l = s_r = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; }   // pair.cpp:148-154
+                else {                                                                  // pair.cpp:155-168
+                    const int nl = max(0, ql - qr), nr = max(0, qr - ql);
+                    nql4 = (nql4 & ~(0xFFu << (8 * k))) | ((uint32_t)nl << (8 * k));
+                    nqr4 = (nqr4 & ~(0xFFu << (8 * k))) | ((uint32_t)nr << (8 * k));
+                    if (ql >= qr) { s_l = d_qual2score(p, ql - qr) - 3; s_r = 0; } else { s_l = 0; s_r = d_qual2score(p, qr - ql) - 3; }
                 }
-            } else ls[l] = (int8_t)d_qual2score(p, ql);
+                sl4 |= (uint32_t)(s_l & 0xFF) << (8 * k); sr4 |= (uint32_t)(s_r & 0xFF) << (8 * k);
+            }
+            *(u32_unaligned *)(ls + l0) = sl4; *(u32_unaligned *)(rs + r0) = sr4;
+            if (nql4 != ql4) *(u32_unaligned *)(lq + l0) = nql4;
+            if (nqr4 != qr4) *(u32_unaligned *)(rq + r0) = nqr4;
+        } else {
+            for (int k = 0; k < n4; k++) {
+                const int l = l0 + k, ql = lq[l];
+                if (l >= lstart && l < ov_end) {
+                    const int r = rstart + (l - lstart), qr = rq[r];
+                    if (d_nib(lseq, l) == d_nib(rseq, r)) { int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; ls[l] = (int8_t)sc; rs[r] = (int8_t)sc; }
+                    else {
+                        lq[l] = (uint8_t)max(0, ql - qr); rq[r] = (uint8_t)max(0, qr - ql);
+                        if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3); rs[r] = 0; }
+                        else { ls[l] = 0; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3); }
+                    }
+                } else ls[l] = (int8_t)d_qual2score(p, ql);
+            }
         }
-        for (int r = lane; r < rk.l_qseq; r += 64)
-            if (!(r >= rstart && r < rstart + cmp)) rs[r] = (int8_t)d_qual2score(p, rq[r]);
+    }
+    const int rov_end = rstart + cmp;
+    for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                                      // right bases outside the overlap
+        const int n4 = min(4, rlen - r0);
+        if (n4 == 4 && (cmp <= 0 || r0 + 4 <= rstart || r0 >= rov_end)) *(u32_unaligned *)(rs + r0) = score4_plain(p, *(const u32_unaligned *)(rq + r0));
+        else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)d_qual2score(p, rq[r]); }
     }
 }
 
@@ -845,11 +1048,6 @@ __global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p,
     }
 }
 
-__device__ __forceinline__ int rl32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
 // BamUtil::isPartOf with the single-op case (e.g. 150M vs 148M) answered from registers
 __device__ __forceinline__ bool part_of_fast(uint32_t pc0, int pnc, const uint32_t *pcig, uint32_t wc0, int wnc, const uint32_t *wcig, bool left) {
     if (pnc == 0) return true;
@@ -944,7 +1142,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
 __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
-    __shared__ uint8_t s_res[WAVES_PER_BLOCK][3 * 256];          // buffered results: new seq byte, qual0, qual1 per template byte
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048];   // per column: new base [512], new qual [512]; contested column list u16[512]
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t wid = blockIdx.x * WAVES_PER_BLOCK + wv;
     const uint32_t gi = wid >> 1;
@@ -1023,12 +1221,17 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
         if (rdp && (int64_t)o_pos + need_len < p.ref_len[ok.tid]) { ref = rdp; ref_len = p.ref_len[ok.tid]; }
     }
     uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
-    uint8_t *res = s_res[wv];
-    int minc = 0; bool odd = false;
+    uint8_t *resb = s_res[wv], *resq = s_res[wv] + 512;
+    uint16_t *cplx = (uint16_t *)(s_res[wv] + 1024);
+    // ---- pass A: every column, 5 accumulators.  A column whose voters all show the same A/C/G/T/N nibble with
+    //      total score >= baseScoreReq (> 0) and top quality >= moderate takes group.cpp:421-428's early accept:
+    //      base unchanged, qual = max qual.  Everything else is queued for the full 16-bin rule cascade (pass B).
+    const int accept_score = max(p.base_score_req, 1);
+    int n_cplx = 0; bool odd = false;
     for (int it = 0; it * 64 < nbytes; it++) {
         const int bi = it * 64 + lane, col0 = bi * 2;
         const bool a0 = col0 < len, a1 = col0 + 1 < len;
-        Tally5 t0, t1; tally_clear(t0); tally_clear(t1);
+        uint32_t pm0 = 0, pm1 = 0; int ss0 = 0, ss1 = 0, tq0 = 0, tq1 = 0, qor = 0;
         for (unsigned long long m = vmask; m; m &= m - 1) {
             const int v = __ffsll((long long)m) - 1;
             const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
@@ -1037,34 +1240,55 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
             const bool in0 = a0 && r0 >= 0 && r0 < vlq, in1 = a1 && r1 >= 0 && r1 < vlq;
             if (in0 && in1 && !(r0 & 1)) {                                   // aligned pair of columns: one seq byte, 2+2 bytes
                 uint8_t sb = vs[r0 >> 1];
-                uint16_t qq = *(const u16_unaligned *)(vq + r0), ss = *(const u16_unaligned *)(vsc + r0);
+                uint16_t qq = *(const u16_unaligned *)(vq + r0), sc = *(const u16_unaligned *)(vsc + r0);
                 int q0 = qq & 0xFF, q1 = qq >> 8;
-                if (!tally_add(t0, sb >> 4, q0, (int)(int8_t)(ss & 0xFF))) odd = true;
-                if (!tally_add(t1, sb & 0xF, q1, (int)(int8_t)(ss >> 8))) odd = true;
-                if ((q0 | q1) & 0x80) odd = true;
+                pm0 |= 1u << (sb >> 4); pm1 |= 1u << (sb & 0xF);
+                ss0 += (int)(int8_t)(sc & 0xFF); ss1 += (int)(int8_t)(sc >> 8);
+                tq0 = max(tq0, q0); tq1 = max(tq1, q1); qor |= q0 | q1;
             } else {
-                if (in0) { int q0 = vq[r0]; if (!tally_add(t0, d_nib(vs, r0), q0, vsc[r0]) || (q0 & 0x80)) odd = true; }
-                if (in1) { int q1 = vq[r1]; if (!tally_add(t1, d_nib(vs, r1), q1, vsc[r1]) || (q1 & 0x80)) odd = true; }
+                if (in0) { int q0 = vq[r0]; pm0 |= 1u << d_nib(vs, r0); ss0 += vsc[r0]; tq0 = max(tq0, q0); qor |= q0; }
+                if (in1) { int q1 = vq[r1]; pm1 |= 1u << d_nib(vs, r1); ss1 += vsc[r1]; tq1 = max(tq1, q1); qor |= q1; }
             }
         }
+        if ((qor & 0x80) || ((pm0 | pm1) & ~0x8116u)) odd = true;            // qual >= 128 or a nibble outside {1,2,4,8,15}
+        bool c0 = false, c1 = false;
         if (a0) {
             uint8_t ob = oseq[bi];
-            int hi = ob >> 4, lo = ob & 0xF, q0 = 0, q1 = 0;
-            int ref0 = 0, ref1 = 0;
-            if (ref) {
-                int ro = d_ref_offset(ocig, o_nc, col0);
-                if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref0 = d_ref_nib(ref, (int64_t)o_pos + ro);
-                if (a1) { ro = d_ref_offset(ocig, o_nc, col0 + 1); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref1 = d_ref_nib(ref, (int64_t)o_pos + ro); }
-            }
-            ColOut r0 = decide_column(t0, p, hi, ref0); hi = r0.base; q0 = r0.qual; minc += r0.minc;
-            if (a1) { ColOut r1 = decide_column(t1, p, lo, ref1); lo = r1.base; q1 = r1.qual; minc += r1.minc; }
-            res[bi] = (uint8_t)((hi << 4) | lo); res[256 + bi] = (uint8_t)q0; res[512 + bi] = (uint8_t)q1;
+            resb[col0] = ob >> 4; resq[col0] = (uint8_t)tq0;
+            c0 = !(__popc(pm0) == 1 && ss0 >= accept_score && tq0 >= p.moderate_q);
+            if (a1) { resb[col0 + 1] = ob & 0xF; resq[col0 + 1] = (uint8_t)tq1; c1 = !(__popc(pm1) == 1 && ss1 >= accept_score && tq1 >= p.moderate_q); }
         }
+        unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+        if (c0) cplx[n_cplx + lanes_below(m0)] = (uint16_t)col0;
+        n_cplx += __popcll(m0);
+        if (c1) cplx[n_cplx + lanes_below(m1)] = (uint16_t)(col0 + 1);
+        n_cplx += __popcll(m1);
     }
     if (__any(odd)) {                                                         // exotic nibble or qual >= 128 among the voters
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
+    WAVE_SYNC();
+    // ---- pass B: the contested columns, one lane per column, full tallies + rule cascade + reference arbitration
+    int minc = 0;
+    for (int base = 0; base < n_cplx; base += 64) {
+        const bool actv = base + lane < n_cplx;
+        const int col = actv ? cplx[base + lane] : 0;
+        Tally5 t; tally_clear(t);
+        for (unsigned long long m = vmask; m; m &= m - 1) {
+            const int v = __ffsll((long long)m) - 1;
+            const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+            const int rp = col + vld;
+            if (actv && rp >= 0 && rp < vlq) tally_add(t, d_nib(b.seq + vso, rp), b.qual[vqo + rp], w.score[vqo + rp]);
+        }
+        if (actv) {
+            int ref4 = 0;
+            if (ref) { int ro = d_ref_offset(ocig, o_nc, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
+            ColOut r = decide_column(t, p, resb[col], ref4);
+            resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
+        }
+    }
+    WAVE_SYNC();
     minc = wave_sum(minc);
     bool restore = false;
     if (minc != 0) {                                                          // group.cpp:528-573
@@ -1074,9 +1298,9 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
     }
     if (!restore) {
         for (int bi = lane; bi < nbytes; bi += 64) {
-            oseq[bi] = res[bi];
-            oqual[2 * bi] = res[256 + bi];
-            if (2 * bi + 1 < len) oqual[2 * bi + 1] = res[512 + bi];
+            const int c0 = 2 * bi;
+            if (c0 + 1 < len) { oseq[bi] = (uint8_t)((resb[c0] << 4) | resb[c0 + 1]); *(u16_unaligned *)(oqual + c0) = (uint16_t)(resq[c0] | (resq[c0 + 1] << 8)); }
+            else { oseq[bi] = (uint8_t)((resb[c0] << 4) | (oseq[bi] & 0xF)); oqual[c0] = resq[c0]; }
         }
     }
     if (lane == 0) rp_out[gi] = out;
