@@ -50,7 +50,7 @@ struct gce_engine {
     DevBuf cls, umi_ptr, umi_len, has_mi, slot, rank, score, out_flag, qname_src, nm_new, fr, rr, mate, out_index;
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
-    DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster;
+    DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
     DevBuf slow_list, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
@@ -124,7 +124,7 @@ void gce_destroy(gce_engine *e) {
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->slow_list, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -367,9 +367,9 @@ int gce_process(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
-    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
+    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     if (NG > 0 && e->h_si.error == 0) {

@@ -39,7 +39,7 @@ struct Work {
     // cluster-local arrays (indexed by cl_start + k)
     uint32_t *members, *sorted, *pl, *pr, *pu, *pg, *gpl, *gpr, *grp_begin, *grp_n;
     // groups (compact)
-    uint32_t *gl_cluster;
+    uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     // generic scan scratch
@@ -597,7 +597,8 @@ __global__ void k_group_fill(Work w, uint32_t n_clusters) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_clusters) return;
     uint32_t g0 = w.cl_gbase[c], ng = w.cl_ngroups[c];
-    for (uint32_t g = 0; g < ng; g++) w.gl_cluster[g0 + g] = c;
+    const uint32_t cs = w.cl_start[c];
+    for (uint32_t g = 0; g < ng; g++) { w.gl_cluster[g0 + g] = c; w.g_begin[g0 + g] = w.grp_begin[cs + g]; w.g_np[g0 + g] = w.grp_n[cs + g]; }
 }
 // scan of cl_ngroups -> cl_gbase : same 3-phase scheme on the plain counts
 __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t *out, uint64_t n, const uint64_t *part) {
@@ -1148,8 +1149,7 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
     const uint32_t gi = wid >> 1;
     const bool is_left = !(wid & 1);
     if (gi >= n_groups) return;
-    const uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
-    const uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
+    const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
     if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
         if (lane == 0) rp_out[gi] = is_left ? w.gpl[begin] : NONE32;
@@ -1228,6 +1228,64 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
     //      base unchanged, qual = max qual.  Everything else is queued for the full 16-bin rule cascade (pass B).
     const int accept_score = max(p.base_score_req, 1);
     int n_cplx = 0; bool odd = false;
+    const bool even_ld = left_mode || !__any(take && (ld & 1));              // every voter's columns stay byte aligned
+    if (even_ld && nbytes <= 128) {
+        // Batched form (templates up to 256 bases): both 64-byte slices at once, voters four at a time, so a wave has
+        // 4 x 6 independent loads in flight per round trip instead of 3.
+        const int biA = lane, biB = 64 + lane;
+        const int cA = 2 * biA, cB = 2 * biB;
+        const bool aA0 = cA < len, aA1 = cA + 1 < len, aB0 = cB < len, aB1 = cB + 1 < len;
+        uint32_t pmA0 = 0, pmA1 = 0, pmB0 = 0, pmB1 = 0; int ssA0 = 0, ssA1 = 0, ssB0 = 0, ssB1 = 0, tqA0 = 0, tqA1 = 0, tqB0 = 0, tqB1 = 0, qor = 0;
+        unsigned long long m = vmask;
+        while (m) {
+            int vv[4]; uint8_t sbA[4], sbB[4]; uint16_t qqA[4], qqB[4], scA[4], scB[4]; bool okA0[4], okA1[4], okB0[4], okB1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { vv[u] = m ? __ffsll((long long)m) - 1 : -1; if (m) m &= m - 1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                okA0[u] = okA1[u] = okB0[u] = okB1[u] = false; sbA[u] = sbB[u] = 0; qqA[u] = qqB[u] = scA[u] = scB[u] = 0;
+                if (vv[u] >= 0) {                                              // wave-uniform
+                    const int v = vv[u];
+                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+                    const uint8_t *vs = b.seq + vso; const uint8_t *vq = b.qual + vqo; const int8_t *vsc = w.score + vqo;
+                    const int rA = cA + vld, rB = cB + vld;
+                    okA0[u] = aA0 && rA >= 0 && rA < vlq; okA1[u] = aA1 && rA + 1 >= 0 && rA + 1 < vlq;
+                    okB0[u] = aB0 && rB >= 0 && rB < vlq; okB1[u] = aB1 && rB + 1 >= 0 && rB + 1 < vlq;
+                    if (okA0[u] || okA1[u]) { const int r = max(rA, 0); sbA[u] = vs[r >> 1]; qqA[u] = *(const u16_unaligned *)(vq + r); scA[u] = *(const u16_unaligned *)(vsc + r); }
+                    if (okB0[u] || okB1[u]) { const int r = max(rB, 0); sbB[u] = vs[r >> 1]; qqB[u] = *(const u16_unaligned *)(vq + r); scB[u] = *(const u16_unaligned *)(vsc + r); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (okA0[u]) { int q = qqA[u] & 0xFF; pmA0 |= 1u << (sbA[u] >> 4); ssA0 += (int)(int8_t)(scA[u] & 0xFF); tqA0 = max(tqA0, q); qor |= q; }
+                if (okA1[u]) { int q = qqA[u] >> 8; pmA1 |= 1u << (sbA[u] & 0xF); ssA1 += (int)(int8_t)(scA[u] >> 8); tqA1 = max(tqA1, q); qor |= q; }
+                if (okB0[u]) { int q = qqB[u] & 0xFF; pmB0 |= 1u << (sbB[u] >> 4); ssB0 += (int)(int8_t)(scB[u] & 0xFF); tqB0 = max(tqB0, q); qor |= q; }
+                if (okB1[u]) { int q = qqB[u] >> 8; pmB1 |= 1u << (sbB[u] & 0xF); ssB1 += (int)(int8_t)(scB[u] >> 8); tqB1 = max(tqB1, q); qor |= q; }
+            }
+        }
+        if ((qor & 0x80) || ((pmA0 | pmA1 | pmB0 | pmB1) & ~0x8116u)) odd = true;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int bi = half ? biB : biA, col0 = 2 * bi;
+            const bool a0 = half ? aB0 : aA0, a1 = half ? aB1 : aA1;
+            const uint32_t pm0 = half ? pmB0 : pmA0, pm1 = half ? pmB1 : pmA1;
+            const int ss0 = half ? ssB0 : ssA0, ss1 = half ? ssB1 : ssA1, tq0 = half ? tqB0 : tqA0, tq1 = half ? tqB1 : tqA1;
+            if (half * 64 < nbytes) {                                          // wave-uniform
+                bool c0 = false, c1 = false;
+                if (a0) {
+                    uint8_t ob = oseq[bi];
+                    resb[col0] = ob >> 4; resq[col0] = (uint8_t)tq0;
+                    c0 = !(__popc(pm0) == 1 && ss0 >= accept_score && tq0 >= p.moderate_q);
+                    if (a1) { resb[col0 + 1] = ob & 0xF; resq[col0 + 1] = (uint8_t)tq1; c1 = !(__popc(pm1) == 1 && ss1 >= accept_score && tq1 >= p.moderate_q); }
+                }
+                unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+                if (c0) cplx[n_cplx + lanes_below(m0)] = (uint16_t)col0;
+                n_cplx += __popcll(m0);
+                if (c1) cplx[n_cplx + lanes_below(m1)] = (uint16_t)(col0 + 1);
+                n_cplx += __popcll(m1);
+            }
+        }
+    } else
     for (int it = 0; it * 64 < nbytes; it++) {
         const int bi = it * 64 + lane, col0 = bi * 2;
         const bool a0 = col0 < len, a1 = col0 + 1 < len;
@@ -1275,11 +1333,23 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
         const bool actv = base + lane < n_cplx;
         const int col = actv ? cplx[base + lane] : 0;
         Tally5 t; tally_clear(t);
-        for (unsigned long long m = vmask; m; m &= m - 1) {
-            const int v = __ffsll((long long)m) - 1;
-            const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
-            const int rp = col + vld;
-            if (actv && rp >= 0 && rp < vlq) tally_add(t, d_nib(b.seq + vso, rp), b.qual[vqo + rp], w.score[vqo + rp]);
+        for (unsigned long long m = vmask; m;) {
+            int vv[4], nb_[4], qb_[4], sc_[4]; bool ok_[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { vv[u] = m ? __ffsll((long long)m) - 1 : -1; if (m) m &= m - 1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ok_[u] = false; nb_[u] = 0; qb_[u] = 0; sc_[u] = 0;
+                if (vv[u] >= 0) {
+                    const int v = vv[u];
+                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+                    const int rp = col + vld;
+                    ok_[u] = actv && rp >= 0 && rp < vlq;
+                    if (ok_[u]) { nb_[u] = d_nib(b.seq + vso, rp); qb_[u] = b.qual[vqo + rp]; sc_[u] = w.score[vqo + rp]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (ok_[u]) tally_add(t, nb_[u], qb_[u], sc_[u]);
         }
         if (actv) {
             int ref4 = 0;
