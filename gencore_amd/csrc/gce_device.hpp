@@ -53,6 +53,8 @@ struct StreamInfo {
     int n_events_a;                      // E_A: events whose read index < U
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
+    unsigned int n_fb;                   // groups handed from the fused LDS kernel to the global-memory path
+    unsigned int pad1;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];

@@ -41,6 +41,7 @@ struct Work {
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
+    uint32_t *fb_list; uint8_t *slot_flag;   // groups the fused LDS kernel handed to the global-memory path; their pair slots
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     // generic scan scratch
     uint64_t *scan_part;
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     const int lane = lane_id(), sl = lane & 15;
     const uint32_t slot = ((blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) << 2) + (lane >> 4);
     if (slot >= n_slots) return;
+    if (!w.slot_flag[slot]) return;                                            // only pairs of groups on the global-memory path
     const uint32_t L = w.gpl[slot], R = w.gpr[slot];
     if (L == NONE32) return;
     const gce_core lk = b.core[L];
@@ -1142,13 +1144,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
-__global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048];   // per column: new base [512], new qual [512]; contested column list u16[512]
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t wid = blockIdx.x * WAVES_PER_BLOCK + wv;
-    const uint32_t gi = wid >> 1;
-    const bool is_left = !(wid & 1);
-    if (gi >= n_groups) return;
+__device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
     if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
@@ -1221,8 +1217,8 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
         if (rdp && (int64_t)o_pos + need_len < p.ref_len[ok.tid]) { ref = rdp; ref_len = p.ref_len[ok.tid]; }
     }
     uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
-    uint8_t *resb = s_res[wv], *resq = s_res[wv] + 512;
-    uint16_t *cplx = (uint16_t *)(s_res[wv] + 1024);
+    uint8_t *resb = s_res_wave, *resq = s_res_wave + 512;
+    uint16_t *cplx = (uint16_t *)(s_res_wave + 1024);
     // ---- pass A: every column, 5 accumulators.  A column whose voters all show the same A/C/G/T/N nibble with
     //      total score >= baseScoreReq (> 0) and top quality >= moderate takes group.cpp:421-428's early accept:
     //      base unchanged, qual = max qual.  Everything else is queued for the full 16-bin rule cascade (pass B).
@@ -1374,6 +1370,25 @@ __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p,
         }
     }
     if (lane == 0) rp_out[gi] = out;
+}
+
+// default pipeline: every group takes the global-memory path
+__global__ void k_all_groups_to_fb(Work w, uint32_t n_groups, uint32_t n_slots) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups) w.fb_list[i] = i;
+    if (i < n_slots) w.slot_flag[i] = 1;
+    if (i == 0) w.si->n_fb = n_groups;
+}
+
+// global-memory consensus for the groups on fb_list (both sides), grid-stride
+__global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048];   // per column: new base [512], new qual [512]; contested column list u16[512]
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t n = 2u * w.si->n_fb;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
+        consensus_fast_side(b, p, w, w.fb_list[idx >> 1], !(idx & 1), s_res[wv], lane);
+        WAVE_SYNC();
+    }
 }
 
 // ===================================================================================================== finish

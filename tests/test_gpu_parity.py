@@ -56,6 +56,21 @@ def test_fuzz_deep_cluster(built, seed, deep):
         assert got.fr.max() >= 0
 
 
+@pytest.mark.parametrize("seed", [0, 3, 7, 12, 29, 33, 41, 600, 603])
+def test_fused_lds_group_kernel(built, seed, monkeypatch):
+    """GCE_FUSED_GROUPS=1: the LDS-resident one-wave-per-group kernel (gce_fused.hpp) must give the same bits."""
+    monkeypatch.setenv("GCE_FUSED_GROUPS", "1")
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, exotic=seed >= 600)
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
+@pytest.mark.parametrize("name,n_pairs", [("cfg3", 60000), ("cfg2", 40000)])
+def test_fused_lds_group_kernel_synthetic(built, name, n_pairs, monkeypatch):
+    monkeypatch.setenv("GCE_FUSED_GROUPS", "1")
+    batch, prm, ref = synth_case(name, n_pairs)
+    run_both(batch, prm, ref)
+
+
 def synth_case(name, n_pairs, **over):
     from gencore_amd import synth
     from gencore_amd.capi import default_params
