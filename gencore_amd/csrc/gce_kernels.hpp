@@ -459,7 +459,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
         if (lane == 0) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
         gbase += run;
     }
-    if (lane == 0) { w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)any_umi; }
+    if (lane == 0) { const bool cross = d_key(b.core[w.members[start]], p).right < 0; w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0)); }
 }
 
 
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
         if (lane == 0) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
         gbase += run;
     }
-    if (lane == 0) { w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)any_umi; }
+    if (lane == 0) { const bool cross = d_key(b.core[w.members[start]], p).right < 0; w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0)); }
 }
 
 // exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word
@@ -1454,104 +1454,94 @@ __device__ inline void d_emit_pair(const Work &w, uint32_t gi, bool duplex) {   
     if (r != NONE32) { w.out_flag[r] = 1; w.fr[r] = (int16_t)fr; if (duplex) w.rr[r] = (int16_t)rr; w.mate[r] = l; }
 }
 
+// The tail of Group::consensusMerge (group.cpp:104-132) — mMergeReads, qname reconciliation, the new Pair's UMI — one
+// THREAD per group; groups of clusters that cannot form a duplex (no UMI, --no_duplex, or a single group) are also
+// filtered, tagged and emitted here (cluster.cpp:169-183; with one group the duplex loop finds no partner, :157-166).
+__global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n_groups) return;
+    const uint32_t c = w.gl_cluster[gi];
+    const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
+    uint32_t left = w.rp_left[gi], right = w.rp_right[gi];
+    const uint8_t cflags = w.cl_hasumi[c];
+    const uint32_t G = w.cl_ngroups[c];
+    const bool single = np == 1 && w.gpr[begin] == NONE32;
+    if (!single) {
+        if (cflags & 2) {                                                 // cross-contig cluster: group.cpp:79-99,109-112
+            uint32_t ntc = NONE32; int bl = 0;
+            for (uint32_t k = 0; k < np; k++) {
+                uint32_t l = w.gpl[begin + k];
+                int ll = d_lqname_pad(b.core[l]);
+                if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
+            }
+            if (left != NONE32 && ntc != NONE32 && ntc != left) {
+                if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
+                w.qname_src[left] = ntc;
+            }
+        } else if (left != NONE32 && right != NONE32) {                   // group.cpp:114-123
+            if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
+            else w.qname_src[left] = right;
+        }
+    }
+    const uint32_t merge = single ? 1 : np;
+    const bool duplex_cluster = (cflags & 1) && !p.disable_duplex && G >= 2;
+    const char *u = nullptr; int ul = 0;                                  // Pair::setLeft / setRight (pair.cpp:188-216)
+    if ((cflags & 1) || b.mi) {
+        if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
+        if (right != NONE32) {
+            const char *u2; int ul2;
+            d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
+            if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
+            u = u2; ul = ul2;
+        }
+    }
+    w.rp_merge[gi] = merge; w.rp_rmerge[gi] = 0; w.rp_umi[gi] = u; w.rp_umilen[gi] = (uint16_t)ul;
+    if (duplex_cluster) { w.rp_state[gi] = RP_PENDING; w.rp_supp[gi] = -1; return; }
+    const bool outp = !p.duplex_only && (int)merge >= p.cluster_size_req;
+    w.rp_supp[gi] = (int)merge; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED;
+    if (outp) d_emit_pair(w, gi, false);
+}
+
+// Duplex matching (cluster.cpp:119-168), one wave per cluster that has UMIs and at least two groups.
 __global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
     const int lane = lane_id();
     uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (c >= n_clusters) return;
-    uint32_t G = w.cl_ngroups[c];
-    if (G == 0) { if (lane == 0) w.cl_nresult[c] = 0; return; }
-    uint32_t g0 = w.cl_gbase[c];
-    // ---- the tail of Group::consensusMerge per group (group.cpp:104-132): mMergeReads, qname reconciliation, Pair UMI
-    {
-        const uint32_t cstart = w.cl_start[c];
-        gce_core oc = b.core[(uint32_t)w.table[w.cl_slot[c]]];
-        const bool cross = d_key(oc, p).right < 0;
-        for (uint32_t base = 0; base < G; base += 64) {
-            uint32_t g = base + lane;
-            if (g >= G) continue;
-            uint32_t gi = g0 + g, begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
-            uint32_t left = w.rp_left[gi], right = w.rp_right[gi];
-            bool single = np == 1 && w.gpr[begin] == NONE32;
-            if (!single) {
-                if (cross) {                                                  // group.cpp:79-99,109-112
-                    uint32_t ntc = NONE32; int bl = 0;
-                    for (uint32_t k = 0; k < np; k++) {
-                        uint32_t l = w.gpl[begin + k];
-                        int ll = d_lqname_pad(b.core[l]);
-                        if (ntc == NONE32 || ll < bl || (ll == bl && d_strcmp(d_qname(b, l), d_qname(b, ntc)) < 0)) { ntc = l; bl = ll; }
-                    }
-                    if (left != NONE32 && ntc != NONE32 && ntc != left) {
-                        if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
-                        w.qname_src[left] = ntc;
-                    }
-                } else if (left != NONE32 && right != NONE32) {               // group.cpp:114-123
-                    if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
-                    else w.qname_src[left] = right;
-                }
+    const uint32_t G = w.cl_ngroups[c];
+    if (G < 2 || !(w.cl_hasumi[c] & 1) || p.disable_duplex) return;
+    const uint32_t g0 = w.cl_gbase[c];
+    for (int idx = (int)G - 1; idx >= 0; idx--) {
+        uint32_t gi = g0 + idx;
+        if (w.rp_state[gi] == RP_CONSUMED) continue;
+        const char *u1 = w.rp_umi[gi]; int ul1 = w.rp_umilen[gi];
+        uint32_t found = NONE32;
+        for (int base = 0; base < idx && found == NONE32; base += 64) {
+            int i = base + lane;
+            bool hit = i < idx && w.rp_state[g0 + i] == RP_PENDING && d_is_duplex(u1, ul1, w.rp_umi[g0 + i], w.rp_umilen[g0 + i]);
+            unsigned long long m = __ballot(hit);
+            if (m) found = base + (__ffsll((long long)m) - 1);
+        }
+        uint32_t l1 = w.rp_left[gi], r1 = w.rp_right[gi], m1 = w.rp_merge[gi];
+        if (found != NONE32) {
+            uint32_t g2 = g0 + found;
+            uint32_t l2 = w.rp_left[g2], r2 = w.rp_right[g2], m2 = w.rp_merge[g2];
+            int diff = 0;
+            if (l1 != NONE32 && l2 != NONE32) diff += d_duplex_merge_bam(b, l1, l2, lane);
+            if (r1 != NONE32 && r2 != NONE32) diff += d_duplex_merge_bam(b, r1, r2, lane);
+            bool outp = diff <= p.duplex_mismatch_thr && (int)(m1 + m2) >= p.cluster_size_req;
+            if (lane == 0) {
+                w.rp_supp[gi] = (int)(m1 + m2);
+                w.rp_rmerge[gi] = m2;
+                w.rp_state[gi] = outp ? RP_OUT_DCS : RP_DROPPED;
+                w.rp_state[g2] = RP_CONSUMED;
+                if (outp) d_emit_pair(w, gi, true);
             }
-            const char *u = nullptr; int ul = 0;                              // Pair::setLeft / setRight (pair.cpp:188-216)
-            if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
-            if (right != NONE32) {
-                const char *u2; int ul2;
-                d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
-                if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
-                u = u2; ul = ul2;
-            }
-            w.rp_merge[gi] = single ? 1 : np; w.rp_rmerge[gi] = 0;
-            w.rp_umi[gi] = u; w.rp_umilen[gi] = (uint16_t)ul; w.rp_state[gi] = RP_PENDING; w.rp_supp[gi] = -1;
+        } else {
+            bool outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
+            if (lane == 0) { w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED; if (outp) d_emit_pair(w, gi, false); }
         }
         WAVE_SYNC();
     }
-    uint32_t nres = 0;
-    if (w.cl_hasumi[c] && !p.disable_duplex) {                                       // cluster.cpp:119-168
-        for (int idx = (int)G - 1; idx >= 0; idx--) {
-            uint32_t gi = g0 + idx;
-            if (w.rp_state[gi] == RP_CONSUMED) continue;
-            const char *u1 = w.rp_umi[gi]; int ul1 = w.rp_umilen[gi];
-            uint32_t found = NONE32;
-            for (int base = 0; base < idx && found == NONE32; base += 64) {
-                int i = base + lane;
-                bool hit = i < idx && w.rp_state[g0 + i] == RP_PENDING && d_is_duplex(u1, ul1, w.rp_umi[g0 + i], w.rp_umilen[g0 + i]);
-                unsigned long long m = __ballot(hit);
-                if (m) found = base + (__ffsll((long long)m) - 1);
-            }
-            uint32_t l1 = w.rp_left[gi], r1 = w.rp_right[gi], m1 = w.rp_merge[gi];
-            if (found != NONE32) {
-                uint32_t g2 = g0 + found;
-                uint32_t l2 = w.rp_left[g2], r2 = w.rp_right[g2], m2 = w.rp_merge[g2];
-                int diff = 0;
-                if (l1 != NONE32 && l2 != NONE32) diff += d_duplex_merge_bam(b, l1, l2, lane);
-                if (r1 != NONE32 && r2 != NONE32) diff += d_duplex_merge_bam(b, r1, r2, lane);
-                bool outp = diff <= p.duplex_mismatch_thr && (int)(m1 + m2) >= p.cluster_size_req;
-                if (lane == 0) {
-                    w.rp_supp[gi] = (int)(m1 + m2);
-                    w.rp_rmerge[gi] = m2;
-                    w.rp_state[gi] = outp ? RP_OUT_DCS : RP_DROPPED;
-                    w.rp_state[g2] = RP_CONSUMED;
-                    if (outp) d_emit_pair(w, gi, true);
-                }
-                nres += outp;
-            } else {
-                bool outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
-                if (lane == 0) { w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED; if (outp) d_emit_pair(w, gi, false); }
-                nres += outp;
-            }
-            WAVE_SYNC();
-        }
-    } else {                                                                          // cluster.cpp:169-183
-        for (uint32_t base = 0; base < G; base += 64) {
-            uint32_t i = base + lane;
-            bool outp = false;
-            if (i < G) {
-                uint32_t gi = g0 + i, m1 = w.rp_merge[gi];
-                outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
-                w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED;
-                if (outp) d_emit_pair(w, gi, false);
-            }
-            nres += __popcll(__ballot(outp));
-        }
-    }
-    if (lane == 0) w.cl_nresult[c] = nres;
 }
 
 // ===================================================================================================== Stats
@@ -1566,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
         uint32_t G = w.cl_ngroups[c];
         if (G == 0) continue;
         atomicAdd(&s_pre[6], 1ull); if (G > 1) atomicAdd(&s_pre[7], 1ull);              // cluster.cpp:102
-        uint32_t nr = w.cl_nresult[c];
+        uint32_t nr = 0; { const uint32_t g0 = w.cl_gbase[c]; for (uint32_t g = 0; g < G; g++) { uint8_t st = w.rp_state[g0 + g]; nr += (st == RP_OUT_SSCS || st == RP_OUT_DCS); } }
         if (nr > 0) { atomicAdd(&s_post[6], 1ull); if (nr > 1) atomicAdd(&s_post[7], 1ull); }   // cluster.cpp:185-187
     }
     for (uint64_t g = tid0; g < n_groups; g += stride) {
