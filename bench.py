@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="override the workload's pair count (per GPU)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,7 +62,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ------------------------------------------------------------------ workload (synthetic, generated on the GPU)
-    data = synth.generate(args.workload, n_pairs=args.pairs, seed=rank, device=dev)
+    data = synth.generate(args.workload, n_pairs=args.pairs, seed=rank, device=dev, align=args.align)
     t = data.t
     n_reads, n_pairs = data.n_reads, data.info["n_pairs"]
     tl = np.asarray(data.target_len, np.uint32)

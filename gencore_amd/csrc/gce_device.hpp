@@ -43,6 +43,25 @@ struct DevParams {
     const int64_t *ref_len;           // [n_ref]
 };
 
+// Per-read descriptor written once by the thread-per-read prescan: everything the per-pair / per-group kernels need about a
+// read in ONE 48-byte record (three 16-byte loads) instead of the dependent chain core -> offsets -> first CIGAR word.
+struct __attribute__((aligned(16))) ReadDesc {
+    uint64_t so, qo;          // byte offsets of the packed bases / quals
+    uint32_t c0;              // first CIGAR word (0 if none)
+    int32_t pos, lq, isize;
+    int32_t mo, ml;           // BamUtil::getMOffsetAndLen: first M block (bamutil.cpp:316-336)
+    uint16_t nc; uint16_t pad; int32_t rlen;   // n_cigar, bam_cigar2rlen
+};
+
+// three 16-byte loads instead of a dozen field loads
+__device__ __forceinline__ ReadDesc load_desc(const ReadDesc *base, uint32_t i) {
+    union { ReadDesc d; uint4 q[3]; } u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(base + i);
+    u.q[0] = src[0]; u.q[1] = src[1]; u.q[2] = src[2];
+    return u.d;
+}
+static_assert(sizeof(ReadDesc) == 48, "ReadDesc must stay 48 bytes");
+
 // stream-level scalars produced by the prescan (device resident)
 struct StreamInfo {
     unsigned long long n_clustered;      // number of clustered reads (ticks)

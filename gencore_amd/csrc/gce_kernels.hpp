@@ -23,6 +23,7 @@ struct Work {
     // per read
     uint8_t *cls;
     const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
+    ReadDesc *rdesc;
     uint32_t *slot, *rank;
     int8_t *score;                       // parallel to qual
     // outputs per read
@@ -92,6 +93,15 @@ __global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work
             w.cls[i] = c;
             w.out_flag[i] = (c == CLS_BYPASS) ? 2 : 0;
             w.qname_src[i] = (uint32_t)i; w.nm_new[i] = -1; w.fr[i] = -1; w.rr[i] = -1; w.mate[i] = NONE32;
+            if (c == CLS_CLUSTERED) {
+                ReadDesc d;
+                d.so = b.seq_off[i]; d.qo = b.qual_off[i]; d.pos = k.pos; d.lq = k.l_qseq; d.isize = k.isize; d.nc = k.n_cigar; d.pad = 0;
+                const uint32_t *cg = b.cigar + b.cigar_off[i];
+                d.c0 = k.n_cigar ? cg[0] : 0;
+                if (k.n_cigar == 1) { int op = cig_op(d.c0), ln = cig_len(d.c0); d.mo = 0; d.ml = op == 0 ? ln : 0; d.rlen = ln * consumes_ref(op); }
+                else { int mo_, ml_; d_first_m(cg, k.n_cigar, mo_, ml_); d.mo = mo_; d.ml = ml_; d.rlen = d_cigar_rlen(cg, k.n_cigar); }
+                { union { ReadDesc d; uint4 q[3]; } u; u.d = d; uint4 *dst = reinterpret_cast<uint4 *>(w.rdesc + i); dst[0] = u.q[0]; dst[1] = u.q[1]; dst[2] = u.q[2]; }
+            }
             if (c == CLS_CLUSTERED) {                                          // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38
                 const char *src; uint8_t hm = 0;
                 if (b.mi && b.mi_off[i] != 0xFFFFFFFFFFFFFFFFull) { src = b.mi + b.mi_off[i]; hm = 1; }
@@ -641,29 +651,20 @@ __device__ __forceinline__ void first_m_fast(const uint32_t *cig, int n, uint32_
     if (n >= 1 && cig_op(c0) == 0) { off = 0; len = cig_len(c0); return; }     // the common "150M" / leading-M case
     d_first_m(cig, n, off, len);
 }
-__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots) {
-    const int lane = lane_id(), sl = lane & 15;
-    const uint32_t slot = ((blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) << 2) + (lane >> 4);
-    if (slot >= n_slots) return;
-    if (!w.slot_flag[slot]) return;                                            // only pairs of groups on the global-memory path
-    const uint32_t L = w.gpl[slot], R = w.gpr[slot];
-    if (L == NONE32) return;
-    const gce_core lk = b.core[L];
-    const uint64_t lqo = b.qual_off[L];
+// global-memory form (reads longer than 160 bases): 16 lanes per pair, dword accesses straight to HBM
+__device__ void score_pair_global(const DevBatch &b, const DevParams &p, const Work &w, uint32_t L, uint32_t R, const ReadDesc &lk, int sl) {
+    const uint64_t lqo = lk.qo;
     int8_t *ls = w.score + lqo;
-    const int llen = lk.l_qseq;
+    const int llen = lk.lq;
     if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
         for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
         return;
     }
-    const gce_core rk = b.core[R];
-    const uint64_t rqo = b.qual_off[R], lso = b.seq_off[L], rso = b.seq_off[R], lco = b.cigar_off[L], rco = b.cigar_off[R];
-    const uint32_t lc0 = lk.n_cigar ? b.cigar[lco] : 0, rc0 = rk.n_cigar ? b.cigar[rco] : 0;
+    const ReadDesc rk = load_desc(w.rdesc, R);
+    const uint64_t rqo = rk.qo, lso = lk.so, rso = rk.so;
     int8_t *rs = w.score + rqo;
-    const int rlen = rk.l_qseq;
-    int lmo, lml, rmo, rml;
-    first_m_fast(b.cigar + lco, lk.n_cigar, lc0, lmo, lml);
-    first_m_fast(b.cigar + rco, rk.n_cigar, rc0, rmo, rml);
+    const int rlen = rk.lq;
+    const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
     if (!(lml > 0 && rml > 0)) {
         const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
         for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
@@ -727,6 +728,108 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
         const int n4 = min(4, rlen - r0);
         if (n4 == 4 && (cmp <= 0 || r0 + 4 <= rstart || r0 >= rov_end)) *(u32_unaligned *)(rs + r0) = score4_plain(p, *(const u32_unaligned *)(rq + r0));
         else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)d_qual2score(p, rq[r]); }
+    }
+}
+
+
+typedef uint4 uint4_unaligned __attribute__((aligned(1)));
+#define SC_SEQ 0
+#define SC_QUAL 80
+#define SC_SCORE 240
+#define SC_READ 400
+
+// LDS form: each quarter-wave stages its pair with ONE 16-byte load per lane and read (lanes 0-4 bases, 5-14 quals),
+// scores in LDS, and writes the score rows (and the rare rewritten qual rows) back with 16-byte stores.
+__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pair[WAVES_PER_BLOCK][4][2 * SC_READ];
+    const int lane = lane_id(), sl = lane & 15, qd = lane >> 4, wv = threadIdx.x >> 6;
+    const uint32_t slot = ((blockIdx.x * WAVES_PER_BLOCK + wv) << 2) + qd;
+    if (slot >= n_slots) return;
+    const uint32_t L = w.gpl[slot], R = w.gpr[slot];
+    if (L == NONE32) return;
+    if (use_flags && !w.slot_flag[slot]) return;                               // only pairs of groups on the global-memory path
+    const ReadDesc lk = load_desc(w.rdesc, L);
+    const int llen = lk.lq;
+    int8_t *gls = w.score + lk.qo;
+    if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
+        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)p.s_moderate; }
+        return;
+    }
+    const ReadDesc rk = load_desc(w.rdesc, R);
+    const int rlen = rk.lq;
+    if (llen > 160 || rlen > 160) { score_pair_global(b, p, w, L, R, lk, sl); return; }
+    int8_t *grs = w.score + rk.qo;
+    const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
+    if (!(lml > 0 && rml > 0)) {
+        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)p.s_moderate; }
+        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)p.s_moderate; }
+        return;
+    }
+    uint8_t *LL = s_pair[wv][qd], *RR = LL + SC_READ;
+    {   // stage: lanes 0..4 -> 80 bytes of bases, lanes 5..14 -> 160 bytes of quals (reads past lq are never used)
+        const uint8_t *ls_ = sl < 5 ? b.seq + lk.so + 16 * sl : b.qual + lk.qo + 16 * (sl - 5);
+        const uint8_t *rs_ = sl < 5 ? b.seq + rk.so + 16 * sl : b.qual + rk.qo + 16 * (sl - 5);
+        const int off = sl < 5 ? SC_SEQ + 16 * sl : SC_QUAL + 16 * (sl - 5);
+        const bool lneed = sl < 5 ? 32 * sl < llen : (sl < 15 && 16 * (sl - 5) < llen);
+        const bool rneed = sl < 5 ? 32 * sl < rlen : (sl < 15 && 16 * (sl - 5) < rlen);
+        uint4 lv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
+        if (lneed) lv = *(const uint4_unaligned *)ls_;
+        if (rneed) rv = *(const uint4_unaligned *)rs_;
+        if (sl < 15) { *(uint4 *)(LL + off) = lv; *(uint4 *)(RR + off) = rv; }
+    }
+    WAVE_SYNC();
+    int dis = rk.pos - lk.pos, lstart, rstart, cmp;
+    if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
+    else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
+    const int ov_end = lstart + cmp, rov_end = rstart + cmp;
+    bool dirty = false;
+    for (int l0 = sl * 4; l0 < llen; l0 += 64) {                               // left read, 4 bases per lane (aligned LDS dwords)
+        const uint32_t ql4 = *(const uint32_t *)(LL + SC_QUAL + l0);
+        uint32_t s4 = 0, nq4 = ql4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int l = l0 + k, ql = (ql4 >> (8 * k)) & 0xFF;
+            int sc;
+            if (l >= lstart && l < ov_end) {
+                const int r = rstart + (l - lstart), qr = RR[SC_QUAL + r];
+                const int lb = (LL[l >> 1] >> ((l & 1) ? 0 : 4)) & 0xF, rb = (RR[r >> 1] >> ((r & 1) ? 0 : 4)) & 0xF;
+                if (lb == rb) { sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; RR[SC_SCORE + r] = (uint8_t)sc; }     // pair.cpp:148-154
+                else {                                                          // pair.cpp:155-168: quals rewritten
+                    nq4 = (nq4 & ~(0xFFu << (8 * k))) | ((uint32_t)max(0, ql - qr) << (8 * k));
+                    RR[SC_QUAL + r] = (uint8_t)max(0, qr - ql); dirty = true;
+                    if (ql >= qr) { sc = d_qual2score(p, ql - qr) - 3; RR[SC_SCORE + r] = 0; }
+                    else { sc = 0; RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, qr - ql) - 3); }
+                }
+            } else sc = d_qual2score(p, ql);
+            s4 |= (uint32_t)(sc & 0xFF) << (8 * k);
+        }
+        *(uint32_t *)(LL + SC_SCORE + l0) = s4;
+        if (nq4 != ql4) *(uint32_t *)(LL + SC_QUAL + l0) = nq4;
+    }
+    // NOTE: the loop above reads RR quals of overlap positions before (possibly) rewriting them, one lane per position.
+    for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                               // right bases outside the overlap
+        const uint32_t qr4 = *(const uint32_t *)(RR + SC_QUAL + r0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int r = r0 + k; if (r < rlen && !(r >= rstart && r < rov_end)) RR[SC_SCORE + r] = (uint8_t)d_qual2score(p, (qr4 >> (8 * k)) & 0xFF); }
+    }
+    const bool any_dirty = __any(dirty) && true;                               // per wave is enough (a clean pair rewrites identical bytes)
+    WAVE_SYNC();
+    // write back: full 16-byte chunks, then the tail bytes (the rows of the next read start right after lq)
+    {
+        const int lfull = llen >> 4, rfull = rlen >> 4;
+        if (sl < lfull) *(uint4_unaligned *)(gls + 16 * sl) = *(const uint4 *)(LL + SC_SCORE + 16 * sl);
+        if (sl < rfull) *(uint4_unaligned *)(grs + 16 * sl) = *(const uint4 *)(RR + SC_SCORE + 16 * sl);
+        if (lfull * 16 + sl < llen) gls[lfull * 16 + sl] = (int8_t)LL[SC_SCORE + lfull * 16 + sl];
+        if (rfull * 16 + sl < rlen) grs[rfull * 16 + sl] = (int8_t)RR[SC_SCORE + rfull * 16 + sl];
+        if (any_dirty) {
+            uint8_t *glq = b.qual + lk.qo, *grq = b.qual + rk.qo;
+            if (sl < lfull) *(uint4_unaligned *)(glq + 16 * sl) = *(const uint4 *)(LL + SC_QUAL + 16 * sl);
+            if (sl < rfull) *(uint4_unaligned *)(grq + 16 * sl) = *(const uint4 *)(RR + SC_QUAL + 16 * sl);
+            if (lfull * 16 + sl < llen) glq[lfull * 16 + sl] = LL[SC_QUAL + lfull * 16 + sl];
+            if (rfull * 16 + sl < rlen) grq[rfull * 16 + sl] = RR[SC_QUAL + rfull * 16 + sl];
+        }
     }
 }
 
@@ -1051,11 +1154,20 @@ __global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p,
     }
 }
 
+// BamUtil::getRefOffset with the single-M case ("150M") answered from the first CIGAR word
+__device__ __forceinline__ int ref_off_fast(const uint32_t *cig, int n, uint32_t c0, int qpos) {
+    if (n == 1 && cig_op(c0) == 0) return qpos < cig_len(c0) ? qpos : -1;
+    return d_ref_offset(cig, n, qpos);
+}
 // BamUtil::isPartOf with the single-op case (e.g. 150M vs 148M) answered from registers
 __device__ __forceinline__ bool part_of_fast(uint32_t pc0, int pnc, const uint32_t *pcig, uint32_t wc0, int wnc, const uint32_t *wcig, bool left) {
     if (pnc == 0) return true;
-    if (pnc == 1 && wnc == 1) return cig_op(pc0) == cig_op(wc0) && cig_len(pc0) <= cig_len(wc0);
-    return d_is_part_of(pcig, pnc, wcig, wnc, left);
+    if (wnc < pnc) return false;
+    if (pnc == 1) {                                      // the part's only op is also its last: it may be shorter (bamutil.cpp:233-236)
+        const uint32_t wv = wnc == 1 ? wc0 : (left ? wcig[0] : wcig[wnc - 1]);
+        return cig_op(pc0) == cig_op(wv) && cig_len(pc0) <= cig_len(wv);
+    }
+    return d_is_part_of(pcig, pnc, wcig, wnc, left);     // both CIGARs have >= 2 ops: their offsets were loaded
 }
 
 // (score, qual-sum) lexicographic order used by the top/second scans of group.cpp:394-416
@@ -1160,12 +1272,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     uint32_t rd = lane < (int)np ? side[begin + lane] : NONE32;
     const bool has = rd != NONE32;
     int pos = 0, lq = 0, nc = 0, rrp = 0; uint32_t c0 = 0; uint64_t cigo = 0, so = 0, qo = 0;
+    int isz = 0;
     if (has) {
-        gce_core k = b.core[rd];
-        pos = k.pos; lq = k.l_qseq; nc = k.n_cigar;
-        cigo = b.cigar_off[rd]; so = b.seq_off[rd]; qo = b.qual_off[rd];
-        if (nc > 0) c0 = b.cigar[cigo];
-        if (!is_left) rrp = pos + (nc == 1 ? cig_len(c0) * consumes_ref(cig_op(c0)) : d_cigar_rlen(b.cigar + cigo, nc));
+        const ReadDesc k = load_desc(w.rdesc, rd);
+        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen;
+        if (nc > 1 || (nc == 1 && cig_op(c0) != 0)) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
     }
     const unsigned long long hmask = __ballot(has);
     if (!hmask) { if (lane == 0) rp_out[gi] = NONE32; return; }              // no read on this side: "no majority" / out == NULL
@@ -1209,12 +1320,12 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
-    const gce_core ok = b.core[out];
+    const int o_isz = rl32(isz, best), o_tid = b.core[out].tid;
     const uint8_t *ref = nullptr; int64_t ref_len = 0;
-    if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {                  // group.cpp:362-367 -> Reference::getData
-        const uint8_t *rdp = p.ref_data[ok.tid];
-        int64_t need_len = (int64_t)d_ref_offset(ocig, o_nc, len - 1) + 1;
-        if (rdp && (int64_t)o_pos + need_len < p.ref_len[ok.tid]) { ref = rdp; ref_len = p.ref_len[ok.tid]; }
+    if (o_isz != 0 && o_tid >= 0 && o_tid < p.n_ref) {                       // group.cpp:362-367 -> Reference::getData
+        const uint8_t *rdp = p.ref_data[o_tid];
+        int64_t need_len = (int64_t)ref_off_fast(ocig, o_nc, o_c0, len - 1) + 1;
+        if (rdp && (int64_t)o_pos + need_len < p.ref_len[o_tid]) { ref = rdp; ref_len = p.ref_len[o_tid]; }
     }
     uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
     uint8_t *resb = s_res_wave, *resq = s_res_wave + 512;
@@ -1349,7 +1460,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         }
         if (actv) {
             int ref4 = 0;
-            if (ref) { int ro = d_ref_offset(ocig, o_nc, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
+            if (ref) { int ro = ref_off_fast(ocig, o_nc, o_c0, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
             ColOut r = decide_column(t, p, resb[col], ref4);
             resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
         }

@@ -102,7 +102,9 @@ class SynthData:
         return [(r.cpu().numpy(), n) for r, n in self.reference]
 
 
-def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, **over):
+def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, align=1, **over):
+    """align: start every read's seq / qual slice on a multiple of `align` bytes (the gce_batch offsets are free-form;
+    an aligned layout lets the kernels' dword accesses stay inside cache lines)."""
     cfg = dict(CONFIGS[name])
     cfg.update(over)
     if n_pairs is not None:
@@ -231,8 +233,10 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
 
     # ---------------------------------------------------------------- per-base data, chunked over reads
     SB = (L + 1) // 2
-    seq = torch.empty(N * SB, dtype=torch.uint8, device=dev)
-    qual = torch.empty(N * L, dtype=torch.uint8, device=dev)
+    SBs = (SB + align - 1) // align * align          # strides of the seq / qual slices
+    Ls = (L + align - 1) // align * align
+    seq = torch.zeros(N * SBs, dtype=torch.uint8, device=dev)
+    qual = torch.zeros(N * Ls, dtype=torch.uint8, device=dev)
     nm = torch.empty(N, dtype=torch.int32, device=dev)
     bam_nib = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev)
     j = torch.arange(L, **i64).unsqueeze(0)
@@ -263,8 +267,8 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
         nibs = bam_nib[base]
         if L % 2:
             nibs = torch.cat([nibs, torch.zeros(e - s, 1, dtype=torch.uint8, device=dev)], 1)
-        seq[s * SB:e * SB] = ((nibs[:, 0::2] << 4) | nibs[:, 1::2]).reshape(-1)
-        qual[s * L:e * L] = q.to(torch.uint8).reshape(-1)
+        seq.view(N, SBs)[s:e, :SB] = (nibs[:, 0::2] << 4) | nibs[:, 1::2]
+        qual.view(N, Ls)[s:e, :L] = q.to(torch.uint8)
         del roff, h, gpos, rb, base, nibs, q, bkey, rid
 
     # ---------------------------------------------------------------- qnames: SIM:<lane>:<tile>:<x>:<y>[:UMI_<umi>]
@@ -328,7 +332,7 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
 
     rid = torch.arange(N, **i64)
     tensors = dict(core=core, qname_off=qname_off, qname=qname, cigar_off=cigar_off, cigar=cigar.to(torch.int32),
-                   seq_off=rid * SB, seq=seq, qual_off=rid * L, qual=qual, nm=nm,
+                   seq_off=rid * SBs, seq=seq, qual_off=rid * Ls, qual=qual, nm=nm,
                    nm_type=torch.full((N,), ord("C"), dtype=torch.uint8, device=dev))
     info = dict(name=name, n_pairs=P, n_reads=N, n_molecules=M, read_len=L, umi_len=Utot,
                 umi_prefix="UMI" if U else "", supporting_reads=cfg["supporting_reads"])
