@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -287,6 +288,11 @@ int gce_process(gce_engine *e) {
     p.s_high = e->prm.score_high; p.s_moderate = e->prm.score_moderate; p.s_low = e->prm.score_low; p.s_bad = e->prm.score_bad;
     p.skip_low_complexity_thr = e->prm.skip_low_complexity_cluster_threshold; p.duplex_only = e->prm.duplex_only; p.disable_duplex = e->prm.disable_duplex;
     p.period = e->prm.flush_period; p.score_percent_req = e->prm.score_percent_req;
+    {   // scores are qual2score(q) in {s_*}, +4 on overlap match, -3 on overlap mismatch, or 0 (pair.cpp:77-172)
+        int mn = std::min(std::min(p.s_high, p.s_moderate), std::min(p.s_low, p.s_bad)), mx = std::max(std::max(p.s_high, p.s_moderate), std::max(p.s_low, p.s_bad));
+        p.score_bias = std::max(0, 3 - mn); p.score_max = std::max(0, mx + 4);
+        if (p.score_max + p.score_bias > 255) return fail(e, GCE_ERR_INVALID, "score constants out of range");
+    }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
     p.tick_offset = e->prm.tick_offset; p.trailing_flush = e->prm.trailing_flush;

@@ -30,6 +30,7 @@ struct DevParams {
     int32_t high_q, moderate_q, low_q;
     int32_t s_high, s_moderate, s_low, s_bad;
     int32_t skip_low_complexity_thr, duplex_only, disable_duplex, period;
+    int32_t score_bias, score_max;    // score bytes are stored as score + score_bias (>= 0); score_max = largest possible score
     double score_percent_req;
     char prefix[32];
     int32_t prefix_len;

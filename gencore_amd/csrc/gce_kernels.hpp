@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 __device__ __forceinline__ uint32_t score4_plain(const DevParams &p, uint32_t q4) {
     uint32_t s4 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) s4 |= (uint32_t)(d_qual2score(p, (q4 >> (8 * k)) & 0xFF) & 0xFF) << (8 * k);
+    for (int k = 0; k < 4; k++) s4 |= (uint32_t)((d_qual2score(p, (q4 >> (8 * k)) & 0xFF) + p.score_bias) & 0xFF) << (8 * k);
     return s4;
 }
 __device__ __forceinline__ void first_m_fast(const uint32_t *cig, int n, uint32_t c0, int &off, int &len) {
@@ -657,7 +657,7 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
     int8_t *ls = w.score + lqo;
     const int llen = lk.lq;
     if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     const ReadDesc rk = load_desc(w.rdesc, R);
@@ -666,9 +666,9 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
     const int rlen = rk.lq;
     const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
     if (!(lml > 0 && rml > 0)) {
-        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)p.s_moderate; }
-        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)p.s_moderate; }
+        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     int dis = rk.pos - lk.pos, lstart, rstart, cmp;
@@ -703,7 +703,7 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
                     nqr4 = (nqr4 & ~(0xFFu << (8 * k))) | ((uint32_t)nr << (8 * k));
                     if (ql >= qr) { s_l = d_qual2score(p, ql - qr) - 3; s_r = 0; } else { s_l = 0; s_r = d_qual2score(p, qr - ql) - 3; }
                 }
-                sl4 |= (uint32_t)(s_l & 0xFF) << (8 * k); sr4 |= (uint32_t)(s_r & 0xFF) << (8 * k);
+                sl4 |= (uint32_t)((s_l + p.score_bias) & 0xFF) << (8 * k); sr4 |= (uint32_t)((s_r + p.score_bias) & 0xFF) << (8 * k);
             }
             *(u32_unaligned *)(ls + l0) = sl4; *(u32_unaligned *)(rs + r0) = sr4;
             if (nql4 != ql4) *(u32_unaligned *)(lq + l0) = nql4;
@@ -713,13 +713,13 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
                 const int l = l0 + k, ql = lq[l];
                 if (l >= lstart && l < ov_end) {
                     const int r = rstart + (l - lstart), qr = rq[r];
-                    if (d_nib(lseq, l) == d_nib(rseq, r)) { int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; ls[l] = (int8_t)sc; rs[r] = (int8_t)sc; }
+                    if (d_nib(lseq, l) == d_nib(rseq, r)) { int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4 + p.score_bias; ls[l] = (int8_t)sc; rs[r] = (int8_t)sc; }
                     else {
                         lq[l] = (uint8_t)max(0, ql - qr); rq[r] = (uint8_t)max(0, qr - ql);
-                        if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3); rs[r] = 0; }
-                        else { ls[l] = 0; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3); }
+                        if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3 + p.score_bias); rs[r] = (int8_t)p.score_bias; }
+                        else { ls[l] = (int8_t)p.score_bias; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
                     }
-                } else ls[l] = (int8_t)d_qual2score(p, ql);
+                } else ls[l] = (int8_t)(d_qual2score(p, ql) + p.score_bias);
             }
         }
     }
@@ -727,7 +727,7 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
     for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                                      // right bases outside the overlap
         const int n4 = min(4, rlen - r0);
         if (n4 == 4 && (cmp <= 0 || r0 + 4 <= rstart || r0 >= rov_end)) *(u32_unaligned *)(rs + r0) = score4_plain(p, *(const u32_unaligned *)(rq + r0));
-        else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)d_qual2score(p, rq[r]); }
+        else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)(d_qual2score(p, rq[r]) + p.score_bias); }
     }
 }
 
@@ -752,8 +752,8 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     const int llen = lk.lq;
     int8_t *gls = w.score + lk.qo;
     if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
-        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)p.s_moderate; }
+        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     const ReadDesc rk = load_desc(w.rdesc, R);
@@ -762,9 +762,9 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     int8_t *grs = w.score + rk.qo;
     const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
     if (!(lml > 0 && rml > 0)) {
-        const uint32_t six = 0x01010101u * (uint32_t)(p.s_moderate & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)p.s_moderate; }
-        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)p.s_moderate; }
+        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
+        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     uint8_t *LL = s_pair[wv][qd], *RR = LL + SC_READ;
@@ -795,15 +795,15 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
             if (l >= lstart && l < ov_end) {
                 const int r = rstart + (l - lstart), qr = RR[SC_QUAL + r];
                 const int lb = (LL[l >> 1] >> ((l & 1) ? 0 : 4)) & 0xF, rb = (RR[r >> 1] >> ((r & 1) ? 0 : 4)) & 0xF;
-                if (lb == rb) { sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; RR[SC_SCORE + r] = (uint8_t)sc; }     // pair.cpp:148-154
+                if (lb == rb) { sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; RR[SC_SCORE + r] = (uint8_t)(sc + p.score_bias); }     // pair.cpp:148-154
                 else {                                                          // pair.cpp:155-168: quals rewritten
                     nq4 = (nq4 & ~(0xFFu << (8 * k))) | ((uint32_t)max(0, ql - qr) << (8 * k));
                     RR[SC_QUAL + r] = (uint8_t)max(0, qr - ql); dirty = true;
-                    if (ql >= qr) { sc = d_qual2score(p, ql - qr) - 3; RR[SC_SCORE + r] = 0; }
-                    else { sc = 0; RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, qr - ql) - 3); }
+                    if (ql >= qr) { sc = d_qual2score(p, ql - qr) - 3; RR[SC_SCORE + r] = (uint8_t)p.score_bias; }
+                    else { sc = 0; RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
                 }
             } else sc = d_qual2score(p, ql);
-            s4 |= (uint32_t)(sc & 0xFF) << (8 * k);
+            s4 |= (uint32_t)((sc + p.score_bias) & 0xFF) << (8 * k);
         }
         *(uint32_t *)(LL + SC_SCORE + l0) = s4;
         if (nq4 != ql4) *(uint32_t *)(LL + SC_QUAL + l0) = nq4;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                               // right bases outside the overlap
         const uint32_t qr4 = *(const uint32_t *)(RR + SC_QUAL + r0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int r = r0 + k; if (r < rlen && !(r >= rstart && r < rov_end)) RR[SC_SCORE + r] = (uint8_t)d_qual2score(p, (qr4 >> (8 * k)) & 0xFF); }
+        for (int k = 0; k < 4; k++) { const int r = r0 + k; if (r < rlen && !(r >= rstart && r < rov_end)) RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, (qr4 >> (8 * k)) & 0xFF) + p.score_bias); }
     }
     const bool any_dirty = __any(dirty) && true;                               // per wave is enough (a clean pair rewrites identical bytes)
     WAVE_SYNC();
@@ -860,7 +860,7 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
         uint64_t qo = b.qual_off[r];
         int base = d_nib(b.seq + b.seq_off[r], rp);
         int qu = b.qual[qo + rp];
-        int sc = w.score[qo + rp];
+        int sc = (int)(uint8_t)w.score[qo + rp] - p.score_bias;
         uint32_t t0 = t[(base * 3) * 64];
         uint32_t cnt = (t0 & 0xFFFF) + 1, tq = t0 >> 16;
         if ((uint32_t)qu > tq) tq = qu;
@@ -1364,10 +1364,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (okA0[u]) { int q = qqA[u] & 0xFF; pmA0 |= 1u << (sbA[u] >> 4); ssA0 += (int)(int8_t)(scA[u] & 0xFF); tqA0 = max(tqA0, q); qor |= q; }
-                if (okA1[u]) { int q = qqA[u] >> 8; pmA1 |= 1u << (sbA[u] & 0xF); ssA1 += (int)(int8_t)(scA[u] >> 8); tqA1 = max(tqA1, q); qor |= q; }
-                if (okB0[u]) { int q = qqB[u] & 0xFF; pmB0 |= 1u << (sbB[u] >> 4); ssB0 += (int)(int8_t)(scB[u] & 0xFF); tqB0 = max(tqB0, q); qor |= q; }
-                if (okB1[u]) { int q = qqB[u] >> 8; pmB1 |= 1u << (sbB[u] & 0xF); ssB1 += (int)(int8_t)(scB[u] >> 8); tqB1 = max(tqB1, q); qor |= q; }
+                if (okA0[u]) { int q = qqA[u] & 0xFF; pmA0 |= 1u << (sbA[u] >> 4); ssA0 += (int)(scA[u] & 0xFF) - p.score_bias; tqA0 = max(tqA0, q); qor |= q; }
+                if (okA1[u]) { int q = qqA[u] >> 8; pmA1 |= 1u << (sbA[u] & 0xF); ssA1 += (int)(scA[u] >> 8) - p.score_bias; tqA1 = max(tqA1, q); qor |= q; }
+                if (okB0[u]) { int q = qqB[u] & 0xFF; pmB0 |= 1u << (sbB[u] >> 4); ssB0 += (int)(scB[u] & 0xFF) - p.score_bias; tqB0 = max(tqB0, q); qor |= q; }
+                if (okB1[u]) { int q = qqB[u] >> 8; pmB1 |= 1u << (sbB[u] & 0xF); ssB1 += (int)(scB[u] >> 8) - p.score_bias; tqB1 = max(tqB1, q); qor |= q; }
             }
         }
         if ((qor & 0x80) || ((pmA0 | pmA1 | pmB0 | pmB1) & ~0x8116u)) odd = true;
@@ -1408,11 +1408,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 uint16_t qq = *(const u16_unaligned *)(vq + r0), sc = *(const u16_unaligned *)(vsc + r0);
                 int q0 = qq & 0xFF, q1 = qq >> 8;
                 pm0 |= 1u << (sb >> 4); pm1 |= 1u << (sb & 0xF);
-                ss0 += (int)(int8_t)(sc & 0xFF); ss1 += (int)(int8_t)(sc >> 8);
+                ss0 += (int)(sc & 0xFF) - p.score_bias; ss1 += (int)(sc >> 8) - p.score_bias;
                 tq0 = max(tq0, q0); tq1 = max(tq1, q1); qor |= q0 | q1;
             } else {
-                if (in0) { int q0 = vq[r0]; pm0 |= 1u << d_nib(vs, r0); ss0 += vsc[r0]; tq0 = max(tq0, q0); qor |= q0; }
-                if (in1) { int q1 = vq[r1]; pm1 |= 1u << d_nib(vs, r1); ss1 += vsc[r1]; tq1 = max(tq1, q1); qor |= q1; }
+                if (in0) { int q0 = vq[r0]; pm0 |= 1u << d_nib(vs, r0); ss0 += (int)(uint8_t)vsc[r0] - p.score_bias; tq0 = max(tq0, q0); qor |= q0; }
+                if (in1) { int q1 = vq[r1]; pm1 |= 1u << d_nib(vs, r1); ss1 += (int)(uint8_t)vsc[r1] - p.score_bias; tq1 = max(tq1, q1); qor |= q1; }
             }
         }
         if ((qor & 0x80) || ((pm0 | pm1) & ~0x8116u)) odd = true;            // qual >= 128 or a nibble outside {1,2,4,8,15}
@@ -1452,7 +1452,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                     const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
                     const int rp = col + vld;
                     ok_[u] = actv && rp >= 0 && rp < vlq;
-                    if (ok_[u]) { nb_[u] = d_nib(b.seq + vso, rp); qb_[u] = b.qual[vqo + rp]; sc_[u] = w.score[vqo + rp]; }
+                    if (ok_[u]) { nb_[u] = d_nib(b.seq + vso, rp); qb_[u] = b.qual[vqo + rp]; sc_[u] = (int)(uint8_t)w.score[vqo + rp] - p.score_bias; }
                 }
             }
 #pragma unroll

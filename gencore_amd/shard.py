@@ -47,6 +47,25 @@ def slice_batch(batch, idx):
                      qual=qual, nm=batch.nm[idx].copy(), nm_type=batch.nm_type[idx].copy(), mi_off=mi_off, mi=mi)
 
 
+def slice_contiguous(batch, lo, hi):
+    """Sub-batch of the contiguous read range [lo, hi) — vectorised (no per-read python loop)."""
+    core = batch.core[lo:hi].copy()
+    n = hi - lo
+
+    def cut(off, data, last_len):
+        if n == 0:
+            return np.zeros(0, np.uint64), data[:0].copy()
+        a = int(off[lo]); e = int(off[hi - 1]) + int(last_len)
+        return (off[lo:hi] - np.uint64(a)).astype(np.uint64), data[a:e].copy()
+    qoff, qname = cut(batch.qname_off, batch.qname, core["l_qname"][-1] if n else 0)
+    coff, cigar = cut(batch.cigar_off, batch.cigar, core["n_cigar"][-1] if n else 0)
+    soff, seq = cut(batch.seq_off, batch.seq, (int(core["l_qseq"][-1]) + 1) // 2 if n else 0)
+    loff, qual = cut(batch.qual_off, batch.qual, core["l_qseq"][-1] if n else 0)
+    assert batch.mi is None, "slice_contiguous: MI blobs not supported"
+    return ReadBatch(core=core, qname_off=qoff, qname=qname, cigar_off=coff, cigar=cigar, seq_off=soff, seq=seq, qual_off=loff,
+                     qual=qual, nm=batch.nm[lo:hi].copy(), nm_type=batch.nm_type[lo:hi].copy(), mi_off=None, mi=None)
+
+
 def clustered_mask(core):
     """Reads that reach the cluster map and advance `tick` (gencore.cpp:255-271,295-312)."""
     tid, pos, mtid, mpos, flag = (core[k].astype(np.int64) for k in ("tid", "pos", "mtid", "mpos", "flag"))

@@ -168,3 +168,48 @@ def test_empty_and_tiny_inputs(built):
                  [dict(base, qname="a", pos=100, mpos=130), dict(base, qname="a", flag=147, pos=130, mpos=100, isize=-50)],
                  [dict(base, qname="u", flag=77, tid=-1, pos=-1, mtid=-1, mpos=-1, isize=0, cigar="*", nm=None)]):
         run_both(ReadBatch.from_records(recs), prm, [])
+
+
+def test_full_size_shard_property(built):
+    """Size-independent property at BASELINE scale (cfg2, 1 M pairs / 2 M reads, ~200 flush events, oracle too slow to be the
+    checker here): processing the stream as three coordinate shards (with their tick_offset / trailing_flush context) must
+    reproduce the whole-stream result table and the additive Stats exactly; and two runs of the same stream are identical."""
+    from gencore_amd import synth
+    from gencore_amd.capi import default_params
+    from gencore_amd.engine import run_stream
+    d = synth.generate("cfg3", n_pairs=400000)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+
+    def prm(**ctx):
+        p = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"], cluster_size_req=2, **ctx)
+        p._keep = tl
+        return p
+    ref = d.reference_host()
+    whole = run_stream(batch, prm(), ref)
+    again = run_stream(batch, prm(), ref)
+    assert not diff_results(batch, whole, again)
+    # conservation laws of the path
+    n_clustered = int((whole.pre.as_dict()["reads"]))
+    assert n_clustered == batch.n
+    post = whole.post.as_dict()
+    assert post["molecules"] == post["sscs"] + post["dcs"] and post["reads"] == int((whole.out_flag != 0).sum())
+    assert whole.pre.as_dict()["molecules"] >= post["molecules"]
+    from gencore_amd.shard import clustered_mask
+    tid = batch.core["tid"].astype(np.int64)
+    cm = clustered_mask(batch.core)
+    bounds = [0, 6, 14, 24]
+    flags = np.zeros(batch.n, np.uint8); fr = np.full(batch.n, -1, np.int16); nm = np.full(batch.n, -1, np.int32)
+    pre = np.zeros(114, np.int64); post_sum = np.zeros(114, np.int64)
+    total_ticks = int(cm.sum())
+    from gencore_amd.shard import slice_contiguous
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        idx = np.nonzero((tid >= lo) & (tid < hi))[0]
+        before = int(cm[tid < lo].sum()); mine = int(cm[idx].sum())
+        ctx = dict(tick_offset=before, trailing_flush=int(total_ticks // 10000 > (before + mine) // 10000))
+        sub = slice_contiguous(batch, int(idx[0]), int(idx[-1]) + 1)
+        r = run_stream(sub, prm(**ctx), ref)
+        flags[idx], fr[idx], nm[idx] = r.out_flag, r.fr, r.nm_new
+        pre += r.pre.as_array(); post_sum += r.post.as_array()
+    assert np.array_equal(flags, whole.out_flag) and np.array_equal(fr, whole.fr) and np.array_equal(nm, whole.nm_new)
+    assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post_sum, whole.post.as_array())
