@@ -1286,19 +1286,29 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         int p0 = rl32(pos, __ffsll((long long)hmask) - 1);
         if (!__any(has && pos != p0)) left_mode = true;
     }
-    // ---- containedBy (group.cpp:196-233)
-    int cb = has ? 1 : 0;
-    for (unsigned long long m = hmask; m; m &= m - 1) {
-        const int j = __ffsll((long long)m) - 1;
-        const int wnc = rl32(nc, j), wrrp = rl32(rrp, j); const uint32_t wc0 = (uint32_t)rl32((int)c0, j); const uint64_t wcig = rl64(cigo, j);
-        if (has && lane != j && (is_left || rrp == wrrp) && part_of_fast(c0, nc, b.cigar + cigo, wc0, wnc, b.cigar + wcig, left_mode)) cb++;
-    }
-    // ---- template: max containedBy, then shorter, then first in qname order (group.cpp:235-261)
-    int best = lane < (int)np ? lane : 0x7FFFFFFF, bc = lane < (int)np ? cb : -1, bl = has ? lq : 0;
-    for (int o = 32; o > 0; o >>= 1) {
-        int ob = __shfl_xor(best, o), oc = __shfl_xor(bc, o), ol = __shfl_xor(bl, o);
-        bool better = oc > bc || (oc == bc && (ol < bl || (ol == bl && ob < best)));
-        if (better) { best = ob; bc = oc; bl = ol; }
+    // ---- containedBy (group.cpp:196-233) and the template pick (group.cpp:235-261).
+    // Shortcut: when every read of the side carries the same single-op CIGAR and the same length (the usual "150M" group) and
+    // the right-end filter cannot split them, every read is part of every other: containedBy = #reads for all, and the
+    // (max containedBy, shorter, first in qname order) winner is simply the first read present.
+    const int first_has = __ffsll((long long)hmask) - 1;
+    const uint32_t c0f = (uint32_t)rl32((int)c0, first_has); const int lqf = rl32(lq, first_has);
+    const bool uniform = !__any(has && (nc != 1 || c0 != c0f || lq != lqf)) && (is_left || left_mode);
+    int best, bc;
+    if (uniform) { best = first_has; bc = __popcll(hmask); }
+    else {
+        int cb = has ? 1 : 0;
+        for (unsigned long long m = hmask; m; m &= m - 1) {
+            const int j = __ffsll((long long)m) - 1;
+            const int wnc = rl32(nc, j), wrrp = rl32(rrp, j); const uint32_t wc0 = (uint32_t)rl32((int)c0, j); const uint64_t wcig = rl64(cigo, j);
+            if (has && lane != j && (is_left || rrp == wrrp) && part_of_fast(c0, nc, b.cigar + cigo, wc0, wnc, b.cigar + wcig, left_mode)) cb++;
+        }
+        int bl = has ? lq : 0;
+        best = lane < (int)np ? lane : 0x7FFFFFFF; bc = lane < (int)np ? cb : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            int ob = __shfl_xor(best, o), oc = __shfl_xor(bc, o), ol = __shfl_xor(bl, o);
+            bool better = oc > bc || (oc == bc && (ol < bl || (ol == bl && ob < best)));
+            if (better) { best = ob; bc = oc; bl = ol; }
+        }
     }
     if ((double)bc < (double)np * 0.4 && np != 1) { if (lane == 0) rp_out[gi] = NONE32; return; }        // group.cpp:264-266
     const uint32_t out = (uint32_t)rl32((int)rd, best);
@@ -1308,7 +1318,8 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const uint32_t *ocig = b.cigar + o_cigo;
     // ---- voters and lenDiff (group.cpp:287-313,339-348)
     bool take = false; int ld = 0;
-    if (has) {
+    if (uniform) take = has;                                                  // identical CIGARs: every read votes, lenDiff 0
+    else if (has) {
         take = lane == best || part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, left_mode);
         if (take) { ld = lq - o_lq; if (ld != 0 && pos == o_pos && part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, true)) ld = 0; }
     }
@@ -1336,61 +1347,86 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const int accept_score = max(p.base_score_req, 1);
     int n_cplx = 0; bool odd = false;
     const bool even_ld = left_mode || !__any(take && (ld & 1));              // every voter's columns stay byte aligned
-    if (even_ld && nbytes <= 128) {
-        // Batched form (templates up to 256 bases): both 64-byte slices at once, voters four at a time, so a wave has
-        // 4 x 6 independent loads in flight per round trip instead of 3.
-        const int biA = lane, biB = 64 + lane;
-        const int cA = 2 * biA, cB = 2 * biB;
-        const bool aA0 = cA < len, aA1 = cA + 1 < len, aB0 = cB < len, aB1 = cB + 1 < len;
-        uint32_t pmA0 = 0, pmA1 = 0, pmB0 = 0, pmB1 = 0; int ssA0 = 0, ssA1 = 0, ssB0 = 0, ssB1 = 0, tqA0 = 0, tqA1 = 0, tqB0 = 0, tqB1 = 0, qor = 0;
+    const int nvot = __popcll(vmask);
+    if (even_ld && len <= 256 && nvot * (p.score_max + p.score_bias) <= 255) {
+        // SWAR form: one lane = 4 consecutive columns = 2 packed-base bytes + 4 quals + 4 scores, i.e. three loads per voter.
+        //   unanimity  : XOR of the voter's two base bytes with the template's, OR-accumulated (a zero nibble = all agree)
+        //   score sum  : packed byte add (scores are stored biased >= 0 and nv * max < 256, so bytes never carry)
+        //   top quality: packed byte max (quals < 128; anything else is handed to the generic kernel)
+        const int c4 = 4 * lane;
+        const bool act = c4 < len;
+        const int nval = act ? min(4, len - c4) : 0;
+        const uint32_t nmask = nval >= 4 ? 0xFFFFu : nval == 3 ? 0xF0FFu : nval == 2 ? 0x00FFu : nval == 1 ? 0x00F0u : 0u;
+        const uint32_t bmask = nval >= 4 ? 0xFFFFFFFFu : nval == 0 ? 0u : ((1u << (8 * nval)) - 1u);
+        uint32_t t16 = 0;
+        if (act) t16 = *(const u16_unaligned *)(oseq + 2 * lane);
+        uint32_t dacc = 0, ssum = 0, tqm = 0, qor = 0, cnt = 0;
         unsigned long long m = vmask;
         while (m) {
-            int vv[4]; uint8_t sbA[4], sbB[4]; uint16_t qqA[4], qqB[4], scA[4], scB[4]; bool okA0[4], okA1[4], okB0[4], okB1[4];
+            int vv[4]; uint32_t s16[4], q4[4], sc4[4], vm[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { vv[u] = m ? __ffsll((long long)m) - 1 : -1; if (m) m &= m - 1; }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                okA0[u] = okA1[u] = okB0[u] = okB1[u] = false; sbA[u] = sbB[u] = 0; qqA[u] = qqB[u] = scA[u] = scB[u] = 0;
+                s16[u] = t16; q4[u] = 0; sc4[u] = 0; vm[u] = 0;
                 if (vv[u] >= 0) {                                              // wave-uniform
                     const int v = vv[u];
                     const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
-                    const uint8_t *vs = b.seq + vso; const uint8_t *vq = b.qual + vqo; const int8_t *vsc = w.score + vqo;
-                    const int rA = cA + vld, rB = cB + vld;
-                    okA0[u] = aA0 && rA >= 0 && rA < vlq; okA1[u] = aA1 && rA + 1 >= 0 && rA + 1 < vlq;
-                    okB0[u] = aB0 && rB >= 0 && rB < vlq; okB1[u] = aB1 && rB + 1 >= 0 && rB + 1 < vlq;
-                    if (okA0[u] || okA1[u]) { const int r = max(rA, 0); sbA[u] = vs[r >> 1]; qqA[u] = *(const u16_unaligned *)(vq + r); scA[u] = *(const u16_unaligned *)(vsc + r); }
-                    if (okB0[u] || okB1[u]) { const int r = max(rB, 0); sbB[u] = vs[r >> 1]; qqB[u] = *(const u16_unaligned *)(vq + r); scB[u] = *(const u16_unaligned *)(vsc + r); }
+                    const int r0 = c4 + vld;
+                    if (act) {
+                        if (r0 >= 0 && r0 + nval <= vlq) {                     // the whole unit lies inside the voter
+                            s16[u] = *(const u16_unaligned *)(b.seq + vso + (r0 >> 1));
+                            q4[u] = *(const u32_unaligned *)(b.qual + vqo + r0);
+                            sc4[u] = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + r0);
+                            vm[u] = bmask;
+                        } else {                                               // unit straddles an end of the voter: byte by byte
+                            uint32_t sx = t16;
+                            for (int k = 0; k < nval; k++) {
+                                const int rp = r0 + k;
+                                if (rp >= 0 && rp < vlq) {
+                                    const int nb = d_nib(b.seq + vso, rp), sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
+                                    sx = (sx & ~(0xFu << sh)) | ((uint32_t)nb << sh);
+                                    q4[u] |= (uint32_t)b.qual[vqo + rp] << (8 * k);
+                                    sc4[u] |= (uint32_t)(uint8_t)w.score[vqo + rp] << (8 * k);
+                                    vm[u] |= 0xFFu << (8 * k);
+                                }
+                            }
+                            s16[u] = sx;
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (okA0[u]) { int q = qqA[u] & 0xFF; pmA0 |= 1u << (sbA[u] >> 4); ssA0 += (int)(scA[u] & 0xFF) - p.score_bias; tqA0 = max(tqA0, q); qor |= q; }
-                if (okA1[u]) { int q = qqA[u] >> 8; pmA1 |= 1u << (sbA[u] & 0xF); ssA1 += (int)(scA[u] >> 8) - p.score_bias; tqA1 = max(tqA1, q); qor |= q; }
-                if (okB0[u]) { int q = qqB[u] & 0xFF; pmB0 |= 1u << (sbB[u] >> 4); ssB0 += (int)(scB[u] & 0xFF) - p.score_bias; tqB0 = max(tqB0, q); qor |= q; }
-                if (okB1[u]) { int q = qqB[u] >> 8; pmB1 |= 1u << (sbB[u] & 0xF); ssB1 += (int)(scB[u] >> 8) - p.score_bias; tqB1 = max(tqB1, q); qor |= q; }
+                const uint32_t qv = q4[u] & vm[u];
+                dacc |= (s16[u] ^ t16) & nmask;
+                ssum += sc4[u] & vm[u];
+                cnt += vm[u] & 0x01010101u;
+                qor |= qv;
+                const uint32_t ge = ((tqm | 0x80808080u) - qv) & 0x80808080u;          // per byte: tqm >= qv
+                const uint32_t sel = (ge - (ge >> 7)) | ge;                            // 0xFF where tqm >= qv
+                tqm = (tqm & sel) | (qv & ~sel);
             }
         }
-        if ((qor & 0x80) || ((pmA0 | pmA1 | pmB0 | pmB1) & ~0x8116u)) odd = true;
+        if (qor & 0x80808080u) odd = true;
+        bool cq[4];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int bi = half ? biB : biA, col0 = 2 * bi;
-            const bool a0 = half ? aB0 : aA0, a1 = half ? aB1 : aA1;
-            const uint32_t pm0 = half ? pmB0 : pmA0, pm1 = half ? pmB1 : pmA1;
-            const int ss0 = half ? ssB0 : ssA0, ss1 = half ? ssB1 : ssA1, tq0 = half ? tqB0 : tqA0, tq1 = half ? tqB1 : tqA1;
-            if (half * 64 < nbytes) {                                          // wave-uniform
-                bool c0 = false, c1 = false;
-                if (a0) {
-                    uint8_t ob = oseq[bi];
-                    resb[col0] = ob >> 4; resq[col0] = (uint8_t)tq0;
-                    c0 = !(__popc(pm0) == 1 && ss0 >= accept_score && tq0 >= p.moderate_q);
-                    if (a1) { resb[col0 + 1] = ob & 0xF; resq[col0 + 1] = (uint8_t)tq1; c1 = !(__popc(pm1) == 1 && ss1 >= accept_score && tq1 >= p.moderate_q); }
-                }
-                unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-                if (c0) cplx[n_cplx + lanes_below(m0)] = (uint16_t)col0;
-                n_cplx += __popcll(m0);
-                if (c1) cplx[n_cplx + lanes_below(m1)] = (uint16_t)(col0 + 1);
-                n_cplx += __popcll(m1);
+        for (int k = 0; k < 4; k++) {
+            cq[k] = false;
+            if (k < nval) {
+                const int sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
+                const int tnib = (t16 >> sh) & 0xF;
+                const int ss = (int)((ssum >> (8 * k)) & 0xFF) - (int)((cnt >> (8 * k)) & 0xFF) * p.score_bias;
+                const int tq = (tqm >> (8 * k)) & 0xFF;
+                resb[c4 + k] = (uint8_t)tnib; resq[c4 + k] = (uint8_t)tq;
+                cq[k] = !(((dacc >> sh) & 0xF) == 0 && ((0x8116u >> tnib) & 1u) && ss >= accept_score && tq >= p.moderate_q);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long mk = __ballot(cq[k]);
+            if (cq[k]) cplx[n_cplx + lanes_below(mk)] = (uint16_t)(c4 + k);
+            n_cplx += __popcll(mk);
         }
     } else
     for (int it = 0; it * 64 < nbytes; it++) {
@@ -1429,10 +1465,6 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         if (c1) cplx[n_cplx + lanes_below(m1)] = (uint16_t)(col0 + 1);
         n_cplx += __popcll(m1);
     }
-    if (__any(odd)) {                                                         // exotic nibble or qual >= 128 among the voters
-        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
-        return;
-    }
     WAVE_SYNC();
     // ---- pass B: the contested columns, one lane per column, full tallies + rule cascade + reference arbitration
     int minc = 0;
@@ -1456,7 +1488,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (ok_[u]) tally_add(t, nb_[u], qb_[u], sc_[u]);
+            for (int u = 0; u < 4; u++) if (ok_[u] && (!tally_add(t, nb_[u], qb_[u], sc_[u]) || (qb_[u] & 0x80))) odd = true;
         }
         if (actv) {
             int ref4 = 0;
@@ -1466,6 +1498,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         }
     }
     WAVE_SYNC();
+    if (__any(odd)) {                                                         // IUPAC nibble or qual >= 128 among the voters: generic kernel
+        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
+        return;
+    }
     minc = wave_sum(minc);
     bool restore = false;
     if (minc != 0) {                                                          // group.cpp:528-573
