@@ -172,9 +172,9 @@ __device__ __forceinline__ int d_qual2score(const DevParams &p, int q) {
 __device__ __forceinline__ bool d_is_umi_char(char c) { return c == 'A' || c == 'T' || c == 'C' || c == 'G' || c == '_'; }
 
 // BamUtil::getUMI(string, prefix) (bamutil.cpp:40-112).  Returns false where the reference throws.
-__device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start, int &len) {
-    int n = 0;
-    while (s[n]) n++;
+// `n` = strlen(s) when the caller already knows it (l_qname - 1), or -1.
+__device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start, int &len, int n = -1) {
+    if (n < 0) { n = 0; while (s[n]) n++; }
     start = 0; len = 0;
     if (p.prefix_len > 0) {
         int pos = -1;
@@ -187,22 +187,25 @@ __device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start
         if (pos < 0) return true;
         int st = pos + 2;
         if (st > n) return false;                      // substr(start) with start > size() throws
+        // every character after the last prefix character up to the end was examined by the backward scan; of those only a
+        // run of [ATCG_] right after st counts
         int l = 0;
         while (st + l < n && d_is_umi_char(s[st + l])) l++;
         start = st; len = l;
         return true;
     }
-    int sep = -1;
-    for (int i = n - 1; i >= 0; i--) if (s[i] == ':') { sep = i; break; }
+    int sep = -1, us = 0;
+    bool ok = true;
+    for (int i = n - 1; i >= 0; i--) {                   // one backward pass: find the last ':' and validate the tail on the way
+        char c = s[i];
+        if (c == ':') { sep = i; break; }
+        if (!d_is_umi_char(c)) ok = false;
+        if (c == '_') us++;
+    }
     if (sep < 0 || sep >= n - 1) return true;
     int st = sep + 1;
-    if (st < n - 1 && s[st] == '_') st++;
-    int us = 0;
-    for (int i = st; i < n; i++) {
-        char c = s[i];
-        if (!d_is_umi_char(c)) return true;
-        if (c == '_' && ++us > 1) return true;
-    }
+    if (st < n - 1 && s[st] == '_') { st++; us--; }      // one leading underscore is skipped, and not counted
+    if (!ok || us > 1) return true;
     start = st; len = n - st;
     return true;
 }

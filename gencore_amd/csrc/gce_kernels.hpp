@@ -107,7 +107,7 @@ __global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work
                 if (b.mi && b.mi_off[i] != 0xFFFFFFFFFFFFFFFFull) { src = b.mi + b.mi_off[i]; hm = 1; }
                 else src = b.qname + b.qname_off[i];
                 int s0, l0;
-                if (!d_umi_slice(src, p, s0, l0)) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); s0 = 0; l0 = 0; }
+                if (!d_umi_slice(src, p, s0, l0, hm ? -1 : (int)k.l_qname - 1)) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); s0 = 0; l0 = 0; }
                 w.umi_ptr[i] = src + s0; w.umi_len[i] = (uint16_t)l0; w.has_mi[i] = hm;
             }
         }
