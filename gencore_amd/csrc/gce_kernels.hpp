@@ -210,6 +210,8 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
     if (lane == 0) s_cnt[wv] = __popcll(m);
     __syncthreads();
     uint64_t h = ~0ull;
+    ClusterKey key; key.tid = -1; key.left = -1; key.right = 0;
+    uint32_t ikey = 0xFFFFFFFFu;
     if (cl) {
         unsigned int inblock = lanes_below(m) + 1;
         for (int q = 0; q < wv; q++) inblock += s_cnt[q];
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         const StreamInfo *si = w.si;
         unsigned int U = si->first_unmapped;
         bool seg_b = (U != NONE32) && ((unsigned)i > U);
-        ClusterKey key = d_key(k, p);
+        key = d_key(k, p);
         // first event of this segment whose walk takes the key (gencore.cpp:333-354):
         //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
         int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
@@ -232,7 +234,14 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         }
         int f = a + 1;                                                                      // 1-based; hi+1 if none
         uint32_t inst = (uint32_t)max(e, f - 1);
-        uint32_t ikey = inst | (seg_b ? 0x80000000u : 0u);
+        ikey = inst | (seg_b ? 0x80000000u : 0u);
+    }
+    // ---- neighbouring lanes with the same (key, instance) are one run of one cluster (sorted input): only the run head
+    //      probes the table and issues the CAS; the others copy its bucket.
+    const bool same_prev = lane > 0 && cl && __shfl_up((int)cl, 1) && __shfl_up(key.tid, 1) == key.tid && __shfl_up(key.left, 1) == key.left &&
+                           __shfl_up((long long)key.right, 1) == (long long)key.right && __shfl_up((int)ikey, 1) == (int)ikey;
+    const bool khead = cl && !same_prev;
+    if (khead) {
         uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
         h = d_key_hash(key, ikey, p) & w.tmask;
         for (;;) {
@@ -248,6 +257,12 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
             }
             h = (h + 1) & w.tmask;
         }
+    }
+    {
+        const unsigned long long kheads = __ballot(khead);
+        const int kh = 63 - __clzll((long long)(kheads & ((2ull << lane) - 1ull)));
+        const uint64_t hh = (uint64_t)__shfl((long long)h, kh < 0 ? 0 : kh);
+        if (cl) h = hh;
     }
     // ---- in-cluster rank: neighbouring lanes that landed in the same bucket (sorted input => runs) share ONE atomicAdd
     const uint64_t hprev = (uint64_t)__shfl_up((long long)h, 1);
