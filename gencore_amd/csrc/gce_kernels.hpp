@@ -203,7 +203,10 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
     bool cl = false;
     gce_core k;
     if (i < b.n) {
-        k = b.core[i];
+        union { gce_core c; uint4 q[2]; } u;                     // the 32-byte key record as two 16-byte loads (core[] is 16-byte aligned)
+        const uint4 *src = reinterpret_cast<const uint4 *>(b.core + i);
+        u.q[0] = src[0]; u.q[1] = src[1];
+        k = u.c;
         cl = d_classify(k) == CLS_CLUSTERED;
     }
     unsigned long long m = __ballot(cl);
@@ -225,12 +228,20 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         // first event of this segment whose walk takes the key (gencore.cpp:333-354):
         //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
         int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
+        auto cond = [&](int j) { int T = w.ev_tid[j], P = w.ev_pos[j]; return key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P); };
+        // The answer is almost always the read's own epoch or the next one (a fragment spans far less than 10,000 reads):
+        // probe there first, fall back to the binary search only when the probe window does not bracket it.
         int a = lo, z = hi;
+        int g = min(max(e, lo), hi);
+        if (g > lo && cond(g - 1)) z = g - 1;                                              // already flushable before its own epoch (odd isize)
+        else {
+            int steps = 0;
+            while (g < hi && steps < 4 && !cond(g)) { g++; steps++; }
+            if (g == hi || steps < 4 || cond(g)) { a = z = g; } else a = g + 1;
+        }
         while (a < z) {
             int mid = (a + z) >> 1;
-            int T = w.ev_tid[mid], P = w.ev_pos[mid];
-            bool cond = key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P);
-            if (cond) z = mid; else a = mid + 1;
+            if (cond(mid)) z = mid; else a = mid + 1;
         }
         int f = a + 1;                                                                      // 1-based; hi+1 if none
         uint32_t inst = (uint32_t)max(e, f - 1);
