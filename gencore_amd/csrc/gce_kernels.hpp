@@ -249,8 +249,10 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
     }
     // ---- neighbouring lanes with the same (key, instance) are one run of one cluster (sorted input): only the run head
     //      probes the table and issues the CAS; the others copy its bucket.
-    const bool same_prev = lane > 0 && cl && __shfl_up((int)cl, 1) && __shfl_up(key.tid, 1) == key.tid && __shfl_up(key.left, 1) == key.left &&
-                           __shfl_up((long long)key.right, 1) == (long long)key.right && __shfl_up((int)ikey, 1) == (int)ikey;
+    // (all shuffles are executed by every lane: a shuffle inside a divergent branch reads inactive source lanes as 0)
+    const int p_cl = __shfl_up((int)cl, 1), p_tid = __shfl_up(key.tid, 1), p_left = __shfl_up(key.left, 1), p_ik = __shfl_up((int)ikey, 1);
+    const long long p_right = __shfl_up((long long)key.right, 1);
+    const bool same_prev = lane > 0 && cl && p_cl && p_tid == key.tid && p_left == key.left && p_right == (long long)key.right && p_ik == (int)ikey;
     const bool khead = cl && !same_prev;
     if (khead) {
         uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
@@ -1492,35 +1494,54 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         n_cplx += __popcll(m1);
     }
     WAVE_SYNC();
-    // ---- pass B: the contested columns, one lane per column, full tallies + rule cascade + reference arbitration
+    // ---- pass B: the contested columns.  Work items = (column, voter): every lane fetches ONE voter's (base, qual, score) for
+    //      ONE contested column and adds it to that column's 5-bin tally in LDS (LDS atomics); then one lane per column runs
+    //      the rule cascade + reference arbitration.  32 columns per round.
     int minc = 0;
-    for (int base = 0; base < n_cplx; base += 64) {
-        const bool actv = base + lane < n_cplx;
-        const int col = actv ? cplx[base + lane] : 0;
-        Tally5 t; tally_clear(t);
-        for (unsigned long long m = vmask; m;) {
-            int vv[4], nb_[4], qb_[4], sc_[4]; bool ok_[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { vv[u] = m ? __ffsll((long long)m) - 1 : -1; if (m) m &= m - 1; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                ok_[u] = false; nb_[u] = 0; qb_[u] = 0; sc_[u] = 0;
-                if (vv[u] >= 0) {
-                    const int v = vv[u];
-                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
-                    const int rp = col + vld;
-                    ok_[u] = actv && rp >= 0 && rp < vlq;
-                    if (ok_[u]) { nb_[u] = d_nib(b.seq + vso, rp); qb_[u] = b.qual[vqo + rp]; sc_[u] = (int)(uint8_t)w.score[vqo + rp] - p.score_bias; }
+    {
+        uint32_t *tl = (uint32_t *)(s_res_wave + 2048);                     // [32 columns][5 bins][cnt, score, qualsum, topqual]
+        uint8_t *vlist = s_res_wave + 2048 + 32 * 5 * 4 * 4;                // voter lanes in ascending order
+        if (take) vlist[lanes_below(vmask)] = (uint8_t)lane;
+        const uint32_t magic = ((1u << 20) + (uint32_t)nvot - 1) / (uint32_t)nvot;      // item / nvot == (item * magic) >> 20 for item < 2^11
+        for (int cbase = 0; cbase < n_cplx; cbase += 32) {
+            const int ncol = min(32, n_cplx - cbase);
+            for (int k = lane; k < 32 * 5; k += 64) *(uint4 *)(tl + 4 * k) = make_uint4(0, 0, 0, 0);
+            WAVE_SYNC();
+            const int items = ncol * nvot;
+            for (int ibase = 0; ibase < items; ibase += 64) {             // wave-uniform trip count: every lane executes the
+                const int item = ibase + lane;                              // shuffles (an inactive source lane would read as 0)
+                const bool live = item < items;
+                const int it_ = live ? item : 0;
+                const int c = (int)(((uint32_t)it_ * magic) >> 20), kx = it_ - c * nvot;
+                const int vl = vlist[kx], col = cplx[cbase + c];
+                const uint64_t vso = (uint64_t)__shfl((long long)so, vl), vqo = (uint64_t)__shfl((long long)qo, vl);
+                const int vld = left_mode ? 0 : __shfl(ld, vl), vlq = __shfl(lq, vl);
+                const int rp = col + vld;
+                if (live && rp >= 0 && rp < vlq) {
+                    const int nb = d_nib(b.seq + vso, rp), q = b.qual[vqo + rp], sc = (int)(uint8_t)w.score[vqo + rp] - p.score_bias;
+                    const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
+                    if (bin < 0 || (q & 0x80)) odd = true;
+                    else {
+                        uint32_t *t4 = tl + (c * 5 + bin) * 4;
+                        atomicAdd(t4, 1u); atomicAdd(t4 + 1, (uint32_t)sc); atomicAdd(t4 + 2, (uint32_t)q); atomicMax(t4 + 3, (uint32_t)q);
+                    }
                 }
             }
+            WAVE_SYNC();
+            if (lane < ncol) {
+                const int col = cplx[cbase + lane];
+                Tally5 t; t.total = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (ok_[u] && (!tally_add(t, nb_[u], qb_[u], sc_[u]) || (qb_[u] & 0x80))) odd = true;
-        }
-        if (actv) {
-            int ref4 = 0;
-            if (ref) { int ro = ref_off_fast(ocig, o_nc, o_c0, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
-            ColOut r = decide_column(t, p, resb[col], ref4);
-            resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
+                for (int k = 0; k < 5; k++) {
+                    const uint4 v4 = *(const uint4 *)(tl + (lane * 5 + k) * 4);
+                    t.cnt[k] = (int)v4.x; t.ss[k] = (int)v4.y; t.qs[k] = (int)v4.z; t.tq[k] = (int)v4.w; t.total += (int)v4.y;
+                }
+                int ref4 = 0;
+                if (ref) { int ro = ref_off_fast(ocig, o_nc, o_c0, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
+                ColOut r = decide_column(t, p, resb[col], ref4);
+                resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
+            }
+            WAVE_SYNC();
         }
     }
     WAVE_SYNC();
@@ -1555,7 +1576,8 @@ __global__ void k_all_groups_to_fb(Work w, uint32_t n_groups, uint32_t n_slots) 
 
 // global-memory consensus for the groups on fb_list (both sides), grid-stride
 __global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048];   // per column: new base [512], new qual [512]; contested column list u16[512]
+    // per wave: new base [512], new qual [512], contested column list u16[512], pass-B tallies [32][5][4] u32, voter list [64]
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n = 2u * w.si->n_fb;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
