@@ -398,7 +398,7 @@ int gce_process(gce_engine *e) {
         }
         if (e->h_si.n_fb > 0 && e->h_si.error == 0) {              // global-memory path
             const uint32_t nfb = e->h_si.n_fb;
-            hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * 4)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
+            hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
             HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
             hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w);
             hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);

@@ -557,9 +557,37 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
     uint64_t nw[8];
     load_be_words<8>(nm, act ? nl : 0, nw);
     const int nwords = (wave_max(nl) + 7) >> 3;
-    // ---- order relations against every other read: LT (name strictly smaller), EQ (same name), LOW (smaller input index)
-    unsigned long long LT = 0, EQ = 0, LOW = 0;
+    // ---- same-name detection through a 64-bit hash of the name words (verified exactly below), LOW = smaller input index
+    uint64_t hsh = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < nwords) { hsh ^= nw[k]; hsh *= 0xFF51AFD7ED558CCDull; hsh ^= hsh >> 29; }
+    unsigned long long EQ = 0, LOW = 0;
     for (int j = 0; j < (int)n; j++) {
+        const uint64_t oh = rl64(hsh, j);
+        const uint32_t oj = (uint32_t)rl32((int)my, j);
+        if (oh == hsh && j != lane) EQ |= 1ull << j;
+        if (oj < my) LOW |= 1ull << j;
+    }
+    {   // exact verification of every hash match (all lanes run the shuffles); a false match sends the cluster to the generic kernel
+        bool bad = false;
+        const int rounds = wave_max(act ? __popcll(EQ) : 0);
+        unsigned long long rest = EQ;
+        for (int r = 0; r < rounds; r++) {
+            const int src = rest ? __ffsll((long long)rest) - 1 : lane;
+            rest &= rest - 1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (k < nwords) { const uint64_t o = (uint64_t)__shfl((long long)nw[k], src); if (o != nw[k]) bad = true; }
+        }
+        if (__any(bad)) { if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; return; }
+    }
+    // ---- pairs (cluster.cpp:260-273, pair.cpp:188-216): first read of a name = mLeft, last one = mRight
+    const bool first = act && !(EQ & LOW), last = act && !(EQ & ~LOW);
+    const unsigned long long FIRST = __ballot(first);
+    const uint32_t npairs = __popcll(FIRST);
+    // ---- map<string,Pair*> order: full lexicographic compares only against the first read of every OTHER name
+    unsigned long long LT = 0;
+    for (unsigned long long fm = FIRST; fm; fm &= fm - 1) {
+        const int j = __ffsll((long long)fm) - 1;
         int cmp = 0;                                        // sign of name_j - name_mine
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -568,16 +596,9 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
                 if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
             }
         }
-        uint32_t oj = (uint32_t)rl32((int)my, j);
         if (cmp < 0) LT |= 1ull << j;
-        if (cmp == 0 && j != lane) EQ |= 1ull << j;
-        if (oj < my) LOW |= 1ull << j;
     }
-    // ---- pairs (cluster.cpp:260-273, pair.cpp:188-216): first read of a name = mLeft, last one = mRight
-    const bool first = act && !(EQ & LOW), last = act && !(EQ & ~LOW);
-    const unsigned long long FIRST = __ballot(first);
-    const uint32_t npairs = __popcll(FIRST);
-    const uint32_t pidx = __popcll(LT & FIRST);             // distinct names before mine
+    const uint32_t pidx = __popcll(LT);                     // distinct names before mine
     if (act && !first) {                                    // setRight: UMI must equal the pair's current UMI if that is non-empty
         unsigned long long prev = EQ & LOW;                 // predecessor in arrival order = largest index among them
         uint32_t pv = NONE32; 
@@ -679,13 +700,13 @@ __device__ __forceinline__ void first_m_fast(const uint32_t *cig, int n, uint32_
     if (n >= 1 && cig_op(c0) == 0) { off = 0; len = cig_len(c0); return; }     // the common "150M" / leading-M case
     d_first_m(cig, n, off, len);
 }
-// global-memory form (reads longer than 160 bases): 16 lanes per pair, dword accesses straight to HBM
-__device__ void score_pair_global(const DevBatch &b, const DevParams &p, const Work &w, uint32_t L, uint32_t R, const ReadDesc &lk, int sl) {
+// global-memory form (reads longer than 160 bases): dword accesses straight to HBM, `stride` = 4 x lanes per pair
+__device__ void score_pair_global(const DevBatch &b, const DevParams &p, const Work &w, uint32_t L, uint32_t R, const ReadDesc &lk, int sl, int stride) {
     const uint64_t lqo = lk.qo;
     int8_t *ls = w.score + lqo;
     const int llen = lk.lq;
     if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < llen; i += stride) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     const ReadDesc rk = load_desc(w.rdesc, R);
@@ -695,8 +716,8 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
     const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
     if (!(lml > 0 && rml > 0)) {
         const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < llen; i += stride) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < rlen; i += stride) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     int dis = rk.pos - lk.pos, lstart, rstart, cmp;
@@ -707,7 +728,7 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
     // 4 consecutive bases per lane: one (unaligned) dword for quals/scores, one for the packed nibbles.
     // Device blobs are readable a few bytes past their end (contract of gce_submit_device; gce_submit pads).
     const int ov_end = lstart + cmp;
-    for (int l0 = sl * 4; l0 < llen; l0 += 64) {
+    for (int l0 = sl * 4; l0 < llen; l0 += stride) {
         const int n4 = min(4, llen - l0);
         const bool all_in = n4 == 4 && l0 >= lstart && l0 + 4 <= ov_end;
         const bool all_out = n4 == 4 && (l0 + 4 <= lstart || l0 >= ov_end || cmp <= 0);
@@ -752,7 +773,7 @@ __device__ void score_pair_global(const DevBatch &b, const DevParams &p, const W
         }
     }
     const int rov_end = rstart + cmp;
-    for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                                      // right bases outside the overlap
+    for (int r0 = sl * 4; r0 < rlen; r0 += stride) {                                      // right bases outside the overlap
         const int n4 = min(4, rlen - r0);
         if (n4 == 4 && (cmp <= 0 || r0 + 4 <= rstart || r0 >= rov_end)) *(u32_unaligned *)(rs + r0) = score4_plain(p, *(const u32_unaligned *)(rq + r0));
         else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)(d_qual2score(p, rq[r]) + p.score_bias); }
@@ -766,12 +787,14 @@ typedef uint4 uint4_unaligned __attribute__((aligned(1)));
 #define SC_SCORE 240
 #define SC_READ 400
 
-// LDS form: each quarter-wave stages its pair with ONE 16-byte load per lane and read (lanes 0-4 bases, 5-14 quals),
-// scores in LDS, and writes the score rows (and the rare rewritten qual rows) back with 16-byte stores.
+// LDS form: 8 lanes per pair, 8 pairs per wave.  Each pair is staged with 16-byte loads (5 chunks of bases + 10 of quals per
+// read), scored in LDS, and its score rows (and the rare rewritten qual rows) go back with 16-byte stores.
+#define SC_LPP 8            // lanes per pair
+#define SC_PPW (64 / SC_LPP) // pairs per wave
 __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pair[WAVES_PER_BLOCK][4][2 * SC_READ];
-    const int lane = lane_id(), sl = lane & 15, qd = lane >> 4, wv = threadIdx.x >> 6;
-    const uint32_t slot = ((blockIdx.x * WAVES_PER_BLOCK + wv) << 2) + qd;
+    __shared__ __attribute__((aligned(16))) uint8_t s_pair[WAVES_PER_BLOCK][SC_PPW][2 * SC_READ];
+    const int lane = lane_id(), sl = lane & (SC_LPP - 1), qd = lane / SC_LPP, wv = threadIdx.x >> 6;
+    const uint32_t slot = (blockIdx.x * WAVES_PER_BLOCK + wv) * SC_PPW + qd;
     if (slot >= n_slots) return;
     const uint32_t L = w.gpl[slot], R = w.gpr[slot];
     if (L == NONE32) return;
@@ -781,31 +804,31 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     int8_t *gls = w.score + lk.qo;
     if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
         const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < llen; i += 4 * SC_LPP) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     const ReadDesc rk = load_desc(w.rdesc, R);
     const int rlen = rk.lq;
-    if (llen > 160 || rlen > 160) { score_pair_global(b, p, w, L, R, lk, sl); return; }
+    if (llen > 160 || rlen > 160) { score_pair_global(b, p, w, L, R, lk, sl, 4 * SC_LPP); return; }
     int8_t *grs = w.score + rk.qo;
     const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
     if (!(lml > 0 && rml > 0)) {
         const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += 64) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        for (int i = sl * 4; i < rlen; i += 64) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < llen; i += 4 * SC_LPP) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
+        for (int i = sl * 4; i < rlen; i += 4 * SC_LPP) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)(p.s_moderate + p.score_bias); }
         return;
     }
     uint8_t *LL = s_pair[wv][qd], *RR = LL + SC_READ;
-    {   // stage: lanes 0..4 -> 80 bytes of bases, lanes 5..14 -> 160 bytes of quals (reads past lq are never used)
-        const uint8_t *ls_ = sl < 5 ? b.seq + lk.so + 16 * sl : b.qual + lk.qo + 16 * (sl - 5);
-        const uint8_t *rs_ = sl < 5 ? b.seq + rk.so + 16 * sl : b.qual + rk.qo + 16 * (sl - 5);
-        const int off = sl < 5 ? SC_SEQ + 16 * sl : SC_QUAL + 16 * (sl - 5);
-        const bool lneed = sl < 5 ? 32 * sl < llen : (sl < 15 && 16 * (sl - 5) < llen);
-        const bool rneed = sl < 5 ? 32 * sl < rlen : (sl < 15 && 16 * (sl - 5) < rlen);
+    // stage: 16-byte chunks 0..4 = 80 bytes of bases, 5..14 = 160 bytes of quals (bytes past lq are never used)
+    for (int ch = sl; ch < 15; ch += SC_LPP) {
+        const bool is_seq = ch < 5;
+        const int off = is_seq ? SC_SEQ + 16 * ch : SC_QUAL + 16 * (ch - 5);
+        const bool lneed = is_seq ? 32 * ch < llen : 16 * (ch - 5) < llen;
+        const bool rneed = is_seq ? 32 * ch < rlen : 16 * (ch - 5) < rlen;
         uint4 lv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
-        if (lneed) lv = *(const uint4_unaligned *)ls_;
-        if (rneed) rv = *(const uint4_unaligned *)rs_;
-        if (sl < 15) { *(uint4 *)(LL + off) = lv; *(uint4 *)(RR + off) = rv; }
+        if (lneed) lv = *(const uint4_unaligned *)(is_seq ? b.seq + lk.so + 16 * ch : b.qual + lk.qo + 16 * (ch - 5));
+        if (rneed) rv = *(const uint4_unaligned *)(is_seq ? b.seq + rk.so + 16 * ch : b.qual + rk.qo + 16 * (ch - 5));
+        *(uint4 *)(LL + off) = lv; *(uint4 *)(RR + off) = rv;
     }
     WAVE_SYNC();
     int dis = rk.pos - lk.pos, lstart, rstart, cmp;
@@ -813,7 +836,7 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
     const int ov_end = lstart + cmp, rov_end = rstart + cmp;
     bool dirty = false;
-    for (int l0 = sl * 4; l0 < llen; l0 += 64) {                               // left read, 4 bases per lane (aligned LDS dwords)
+    for (int l0 = sl * 4; l0 < llen; l0 += 4 * SC_LPP) {                       // left read, 4 bases per lane (aligned LDS dwords)
         const uint32_t ql4 = *(const uint32_t *)(LL + SC_QUAL + l0);
         uint32_t s4 = 0, nq4 = ql4;
 #pragma unroll
@@ -837,7 +860,7 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
         if (nq4 != ql4) *(uint32_t *)(LL + SC_QUAL + l0) = nq4;
     }
     // NOTE: the loop above reads RR quals of overlap positions before (possibly) rewriting them, one lane per position.
-    for (int r0 = sl * 4; r0 < rlen; r0 += 64) {                               // right bases outside the overlap
+    for (int r0 = sl * 4; r0 < rlen; r0 += 4 * SC_LPP) {                       // right bases outside the overlap
         const uint32_t qr4 = *(const uint32_t *)(RR + SC_QUAL + r0);
 #pragma unroll
         for (int k = 0; k < 4; k++) { const int r = r0 + k; if (r < rlen && !(r >= rstart && r < rov_end)) RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, (qr4 >> (8 * k)) & 0xFF) + p.score_bias); }
@@ -847,17 +870,13 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     // write back: full 16-byte chunks, then the tail bytes (the rows of the next read start right after lq)
     {
         const int lfull = llen >> 4, rfull = rlen >> 4;
-        if (sl < lfull) *(uint4_unaligned *)(gls + 16 * sl) = *(const uint4 *)(LL + SC_SCORE + 16 * sl);
-        if (sl < rfull) *(uint4_unaligned *)(grs + 16 * sl) = *(const uint4 *)(RR + SC_SCORE + 16 * sl);
-        if (lfull * 16 + sl < llen) gls[lfull * 16 + sl] = (int8_t)LL[SC_SCORE + lfull * 16 + sl];
-        if (rfull * 16 + sl < rlen) grs[rfull * 16 + sl] = (int8_t)RR[SC_SCORE + rfull * 16 + sl];
-        if (any_dirty) {
-            uint8_t *glq = b.qual + lk.qo, *grq = b.qual + rk.qo;
-            if (sl < lfull) *(uint4_unaligned *)(glq + 16 * sl) = *(const uint4 *)(LL + SC_QUAL + 16 * sl);
-            if (sl < rfull) *(uint4_unaligned *)(grq + 16 * sl) = *(const uint4 *)(RR + SC_QUAL + 16 * sl);
-            if (lfull * 16 + sl < llen) glq[lfull * 16 + sl] = LL[SC_QUAL + lfull * 16 + sl];
-            if (rfull * 16 + sl < rlen) grq[rfull * 16 + sl] = RR[SC_QUAL + rfull * 16 + sl];
+        uint8_t *glq = b.qual + lk.qo, *grq = b.qual + rk.qo;
+        for (int ch = sl; ch < 10; ch += SC_LPP) {
+            if (ch < lfull) { *(uint4_unaligned *)(gls + 16 * ch) = *(const uint4 *)(LL + SC_SCORE + 16 * ch); if (any_dirty) *(uint4_unaligned *)(glq + 16 * ch) = *(const uint4 *)(LL + SC_QUAL + 16 * ch); }
+            if (ch < rfull) { *(uint4_unaligned *)(grs + 16 * ch) = *(const uint4 *)(RR + SC_SCORE + 16 * ch); if (any_dirty) *(uint4_unaligned *)(grq + 16 * ch) = *(const uint4 *)(RR + SC_QUAL + 16 * ch); }
         }
+        for (int t = lfull * 16 + sl; t < llen; t += SC_LPP) { gls[t] = (int8_t)LL[SC_SCORE + t]; if (any_dirty) glq[t] = LL[SC_QUAL + t]; }
+        for (int t = rfull * 16 + sl; t < rlen; t += SC_LPP) { grs[t] = (int8_t)RR[SC_SCORE + t]; if (any_dirty) grq[t] = RR[SC_QUAL + t]; }
     }
 }
 
