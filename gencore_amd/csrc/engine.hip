@@ -50,7 +50,7 @@ struct gce_engine {
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi;
     // work buffers
-    DevBuf cls, umi_ptr, umi_len, has_mi, rdesc, slot, rank, score, out_flag, qname_src, nm_new, fr, rr, mate, out_index;
+    DevBuf cls, umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, qname_src, nm_new, fr, rr, mate, out_index;
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
@@ -124,7 +124,7 @@ void gce_destroy(gce_engine *e) {
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
-                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc,
+                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
@@ -292,6 +292,10 @@ int gce_process(gce_engine *e) {
         int mn = std::min(std::min(p.s_high, p.s_moderate), std::min(p.s_low, p.s_bad)), mx = std::max(std::max(p.s_high, p.s_moderate), std::max(p.s_low, p.s_bad));
         p.score_bias = std::max(0, 3 - mn); p.score_max = std::max(0, mx + 4);
         if (p.score_max + p.score_bias > 255) return fail(e, GCE_ERR_INVALID, "score constants out of range");
+        auto by = [&](int sc) { return (uint32_t)((sc + p.score_bias) & 0xFF); };
+        p.q2s_lut = by(p.s_bad) | by(p.s_low) << 8 | by(p.s_moderate) << 16 | by(p.s_high) << 24;
+        p.thr_low4 = 0x01010101u * (uint32_t)(p.low_q & 0xFF); p.thr_mod4 = 0x01010101u * (uint32_t)(p.moderate_q & 0xFF); p.thr_high4 = 0x01010101u * (uint32_t)(p.high_q & 0xFF);
+        p.q2s_swar_ok = p.low_q >= 0 && p.low_q <= p.moderate_q && p.moderate_q <= p.high_q && p.high_q <= 127;
     }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
@@ -308,7 +312,7 @@ int gce_process(gce_engine *e) {
     w.tmask = T - 1;
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
-    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDesc)); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
+    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDesc)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
     ENS(out_flag, n1); ENS(qname_src, n1 * 4); ENS(nm_new, n1 * 4); ENS(fr, n1 * 2); ENS(rr, n1 * 2); ENS(mate, n1 * 4); ENS(out_index, n1 * 4);
     ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
@@ -318,7 +322,7 @@ int gce_process(gce_engine *e) {
     w.slow_list = e->slow_list.as<uint32_t>();
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, (size_t)(nblk_T > nblk_N ? nblk_T : nblk_N) * 8 + 8); ENS(si, sizeof(StreamInfo));
-    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>();
+    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.qname_src = e->qname_src.as<uint32_t>(); w.nm_new = e->nm_new.as<int32_t>();
     w.fr = e->fr.as<int16_t>(); w.rr = e->rr.as<int16_t>(); w.mate = e->mate.as<uint32_t>(); w.out_index = e->out_index.as<uint32_t>();
@@ -384,6 +388,7 @@ int gce_process(gce_engine *e) {
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     if (NG > 0 && e->h_si.error == 0) {
         if (e->fused_groups) HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
+        HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
         hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
         if (e->fused_groups) {
             // fused LDS group kernels, three LDS tiers by pairs per group: (0,8], (8,16], (16,32]; larger groups go to fb_list

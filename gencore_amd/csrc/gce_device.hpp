@@ -31,6 +31,9 @@ struct DevParams {
     int32_t s_high, s_moderate, s_low, s_bad;
     int32_t skip_low_complexity_thr, duplex_only, disable_duplex, period;
     int32_t score_bias, score_max;    // score bytes are stored as score + score_bias (>= 0); score_max = largest possible score
+    uint32_t q2s_lut;                 // (s_bad, s_low, s_moderate, s_high) + score_bias, one byte each: index = #thresholds passed
+    uint32_t thr_low4, thr_mod4, thr_high4;   // the three quality thresholds replicated in 4 bytes
+    int32_t q2s_swar_ok;              // thresholds nested and <= 127: qual2score of 4 packed quals in ~13 VALU ops
     double score_percent_req;
     char prefix[32];
     int32_t prefix_len;
@@ -166,6 +169,28 @@ __device__ __forceinline__ int d_ref_nib(const uint8_t *ref, int64_t pos) {
 // Pair::qual2score (pair.cpp:77-86)
 __device__ __forceinline__ int d_qual2score(const DevParams &p, int q) {
     return q >= p.high_q ? p.s_high : q >= p.moderate_q ? p.s_moderate : q >= p.low_q ? p.s_low : p.s_bad;
+}
+
+// Pair::qual2score on four packed quals (each < 128): count the thresholds passed per byte, then one byte-permute through
+// the 4-entry score table.  Result bytes are score + score_bias.
+__device__ __forceinline__ uint32_t d_q2s4_biased(const DevParams &p, uint32_t q4) {
+    if (p.q2s_swar_ok) {
+        const uint32_t t = q4 | 0x80808080u;
+        const uint32_t c = (((t - p.thr_low4) & 0x80808080u) >> 7) + (((t - p.thr_mod4) & 0x80808080u) >> 7) + (((t - p.thr_high4) & 0x80808080u) >> 7);
+        return __builtin_amdgcn_perm(0u, p.q2s_lut, c);
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r |= (uint32_t)((d_qual2score(p, (q4 >> (8 * k)) & 0xFF) + p.score_bias) & 0xFF) << (8 * k);
+    return r;
+}
+#define GCE_PATCH_CONST 0xFFFFFFFFu
+// Score of base `pos` of a read (pair.cpp:88-172): constant for a read scored without a usable mate, the stored overlap patch
+// inside [start, start+len), qual2score(qual) everywhere else.  patch = start | len << 16.
+__device__ __forceinline__ int d_score_at(const DevParams &p, const int8_t *score_row, uint32_t patch, int pos, int q) {
+    if (patch == GCE_PATCH_CONST) return p.s_moderate;
+    if ((unsigned)(pos - (int)(patch & 0xFFFF)) < (patch >> 16)) return (int)(uint8_t)score_row[pos] - p.score_bias;
+    return d_qual2score(p, q);
 }
 
 // ---------------------------------------------------------------------------------------------------- UMI

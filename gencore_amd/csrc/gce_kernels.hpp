@@ -24,6 +24,7 @@ struct Work {
     uint8_t *cls;
     const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
     ReadDesc *rdesc;
+    uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
     uint32_t *slot, *rank;
     int8_t *score;                       // parallel to qual
     // outputs per read
@@ -690,193 +691,42 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 // CIGAR -> bases, so four independent chains share one wave and every level of the chain is issued as one batch.
 // Pairs of groups that never reach a vote get scores too; nothing reads them and no qual is touched for a mate-less
 // pair, so the result is identical to the reference's lazy evaluation.
-__device__ __forceinline__ uint32_t score4_plain(const DevParams &p, uint32_t q4) {
-    uint32_t s4 = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) s4 |= (uint32_t)((d_qual2score(p, (q4 >> (8 * k)) & 0xFF) + p.score_bias) & 0xFF) << (8 * k);
-    return s4;
-}
-__device__ __forceinline__ void first_m_fast(const uint32_t *cig, int n, uint32_t c0, int &off, int &len) {
-    if (n >= 1 && cig_op(c0) == 0) { off = 0; len = cig_len(c0); return; }     // the common "150M" / leading-M case
-    d_first_m(cig, n, off, len);
-}
-// global-memory form (reads longer than 160 bases): dword accesses straight to HBM, `stride` = 4 x lanes per pair
-__device__ void score_pair_global(const DevBatch &b, const DevParams &p, const Work &w, uint32_t L, uint32_t R, const ReadDesc &lk, int sl, int stride) {
-    const uint64_t lqo = lk.qo;
-    int8_t *ls = w.score + lqo;
-    const int llen = lk.lq;
-    if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
-        for (int i = sl * 4; i < llen; i += stride) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF); else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        return;
-    }
-    const ReadDesc rk = load_desc(w.rdesc, R);
-    const uint64_t rqo = rk.qo, lso = lk.so, rso = rk.so;
-    int8_t *rs = w.score + rqo;
-    const int rlen = rk.lq;
-    const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
-    if (!(lml > 0 && rml > 0)) {
-        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += stride) { if (i + 4 <= llen) *(u32_unaligned *)(ls + i) = six; else for (int k = i; k < llen; k++) ls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        for (int i = sl * 4; i < rlen; i += stride) { if (i + 4 <= rlen) *(u32_unaligned *)(rs + i) = six; else for (int k = i; k < rlen; k++) rs[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        return;
-    }
-    int dis = rk.pos - lk.pos, lstart, rstart, cmp;
-    if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
-    else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
-    const uint8_t *lseq = b.seq + lso, *rseq = b.seq + rso;
-    uint8_t *lq = b.qual + lqo, *rq = b.qual + rqo;
-    // 4 consecutive bases per lane: one (unaligned) dword for quals/scores, one for the packed nibbles.
-    // Device blobs are readable a few bytes past their end (contract of gce_submit_device; gce_submit pads).
-    const int ov_end = lstart + cmp;
-    for (int l0 = sl * 4; l0 < llen; l0 += stride) {
-        const int n4 = min(4, llen - l0);
-        const bool all_in = n4 == 4 && l0 >= lstart && l0 + 4 <= ov_end;
-        const bool all_out = n4 == 4 && (l0 + 4 <= lstart || l0 >= ov_end || cmp <= 0);
-        if (all_out) {
-            *(u32_unaligned *)(ls + l0) = score4_plain(p, *(const u32_unaligned *)(lq + l0));
-        } else if (all_in) {
-            const int r0 = rstart + (l0 - lstart);
-            uint32_t ql4 = *(const u32_unaligned *)(lq + l0), qr4 = *(const u32_unaligned *)(rq + r0);
-            uint32_t ln4 = *(const u32_unaligned *)(lseq + (l0 >> 1)), rn4 = *(const u32_unaligned *)(rseq + (r0 >> 1));
-            uint32_t sl4 = 0, sr4 = 0, nql4 = ql4, nqr4 = qr4;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int lp = (l0 & 1) + k, rp = (r0 & 1) + k;                       // nibble index inside the loaded dword
-                const int lb = (ln4 >> (8 * (lp >> 1) + ((lp & 1) ? 0 : 4))) & 0xF, rb = (rn4 >> (8 * (rp >> 1) + ((rp & 1) ? 0 : 4))) & 0xF;
-                const int ql = (ql4 >> (8 * k)) & 0xFF, qr = (qr4 >> (8 * k)) & 0xFF;
-                int s_l, s_r;
-                if (lb == rb) { s_l = s_r = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; }   // pair.cpp:148-154
-                else {                                                                  // pair.cpp:155-168
-                    const int nl = max(0, ql - qr), nr = max(0, qr - ql);
-                    nql4 = (nql4 & ~(0xFFu << (8 * k))) | ((uint32_t)nl << (8 * k));
-                    nqr4 = (nqr4 & ~(0xFFu << (8 * k))) | ((uint32_t)nr << (8 * k));
-                    if (ql >= qr) { s_l = d_qual2score(p, ql - qr) - 3; s_r = 0; } else { s_l = 0; s_r = d_qual2score(p, qr - ql) - 3; }
-                }
-                sl4 |= (uint32_t)((s_l + p.score_bias) & 0xFF) << (8 * k); sr4 |= (uint32_t)((s_r + p.score_bias) & 0xFF) << (8 * k);
-            }
-            *(u32_unaligned *)(ls + l0) = sl4; *(u32_unaligned *)(rs + r0) = sr4;
-            if (nql4 != ql4) *(u32_unaligned *)(lq + l0) = nql4;
-            if (nqr4 != qr4) *(u32_unaligned *)(rq + r0) = nqr4;
-        } else {
-            for (int k = 0; k < n4; k++) {
-                const int l = l0 + k, ql = lq[l];
-                if (l >= lstart && l < ov_end) {
-                    const int r = rstart + (l - lstart), qr = rq[r];
-                    if (d_nib(lseq, l) == d_nib(rseq, r)) { int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4 + p.score_bias; ls[l] = (int8_t)sc; rs[r] = (int8_t)sc; }
-                    else {
-                        lq[l] = (uint8_t)max(0, ql - qr); rq[r] = (uint8_t)max(0, qr - ql);
-                        if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3 + p.score_bias); rs[r] = (int8_t)p.score_bias; }
-                        else { ls[l] = (int8_t)p.score_bias; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
-                    }
-                } else ls[l] = (int8_t)(d_qual2score(p, ql) + p.score_bias);
-            }
-        }
-    }
-    const int rov_end = rstart + cmp;
-    for (int r0 = sl * 4; r0 < rlen; r0 += stride) {                                      // right bases outside the overlap
-        const int n4 = min(4, rlen - r0);
-        if (n4 == 4 && (cmp <= 0 || r0 + 4 <= rstart || r0 >= rov_end)) *(u32_unaligned *)(rs + r0) = score4_plain(p, *(const u32_unaligned *)(rq + r0));
-        else for (int k = 0; k < n4; k++) { const int r = r0 + k; if (!(r >= rstart && r < rov_end)) rs[r] = (int8_t)(d_qual2score(p, rq[r]) + p.score_bias); }
-    }
-}
-
-
-typedef uint4 uint4_unaligned __attribute__((aligned(1)));
-#define SC_SEQ 0
-#define SC_QUAL 80
-#define SC_SCORE 240
-#define SC_READ 400
-
-// LDS form: 8 lanes per pair, 8 pairs per wave.  Each pair is staged with 16-byte loads (5 chunks of bases + 10 of quals per
-// read), scored in LDS, and its score rows (and the rare rewritten qual rows) go back with 16-byte stores.
-#define SC_LPP 8            // lanes per pair
+#define SC_LPP 8             // lanes per pair
 #define SC_PPW (64 / SC_LPP) // pairs per wave
+// Only the mate-overlap region needs work: outside it a score is qual2score(qual) of an untouched qual, which the vote kernels
+// derive on the fly (d_q2s4_biased / d_score_at).  Per pair this kernel writes the two reads' patch descriptors and, for
+// overlapping pairs, the overlap scores (match: qual2score((lq+rq)/2)+4; mismatch: quals rewritten to max(0, own - mate),
+// the stronger side gets qual2score(|diff|)-3, the other 0).  8 lanes per pair, one overlap base per lane and step.
 __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pair[WAVES_PER_BLOCK][SC_PPW][2 * SC_READ];
     const int lane = lane_id(), sl = lane & (SC_LPP - 1), qd = lane / SC_LPP, wv = threadIdx.x >> 6;
     const uint32_t slot = (blockIdx.x * WAVES_PER_BLOCK + wv) * SC_PPW + qd;
     if (slot >= n_slots) return;
     const uint32_t L = w.gpl[slot], R = w.gpr[slot];
     if (L == NONE32) return;
     if (use_flags && !w.slot_flag[slot]) return;                               // only pairs of groups on the global-memory path
-    const ReadDesc lk = load_desc(w.rdesc, L);
-    const int llen = lk.lq;
-    int8_t *gls = w.score + lk.qo;
-    if (R == NONE32) {                                                          // pair.cpp:89-105 (memset only)
-        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += 4 * SC_LPP) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        return;
-    }
-    const ReadDesc rk = load_desc(w.rdesc, R);
-    const int rlen = rk.lq;
-    if (llen > 160 || rlen > 160) { score_pair_global(b, p, w, L, R, lk, sl, 4 * SC_LPP); return; }
-    int8_t *grs = w.score + rk.qo;
-    const int lmo = lk.mo, lml = lk.ml, rmo = rk.mo, rml = rk.ml;
-    if (!(lml > 0 && rml > 0)) {
-        const uint32_t six = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
-        for (int i = sl * 4; i < llen; i += 4 * SC_LPP) { if (i + 4 <= llen) *(u32_unaligned *)(gls + i) = six; else for (int k = i; k < llen; k++) gls[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        for (int i = sl * 4; i < rlen; i += 4 * SC_LPP) { if (i + 4 <= rlen) *(u32_unaligned *)(grs + i) = six; else for (int k = i; k < rlen; k++) grs[k] = (int8_t)(p.s_moderate + p.score_bias); }
-        return;
-    }
-    uint8_t *LL = s_pair[wv][qd], *RR = LL + SC_READ;
-    // stage: 16-byte chunks 0..4 = 80 bytes of bases, 5..14 = 160 bytes of quals (bytes past lq are never used)
-    for (int ch = sl; ch < 15; ch += SC_LPP) {
-        const bool is_seq = ch < 5;
-        const int off = is_seq ? SC_SEQ + 16 * ch : SC_QUAL + 16 * (ch - 5);
-        const bool lneed = is_seq ? 32 * ch < llen : 16 * (ch - 5) < llen;
-        const bool rneed = is_seq ? 32 * ch < rlen : 16 * (ch - 5) < rlen;
-        uint4 lv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
-        if (lneed) lv = *(const uint4_unaligned *)(is_seq ? b.seq + lk.so + 16 * ch : b.qual + lk.qo + 16 * (ch - 5));
-        if (rneed) rv = *(const uint4_unaligned *)(is_seq ? b.seq + rk.so + 16 * ch : b.qual + rk.qo + 16 * (ch - 5));
-        *(uint4 *)(LL + off) = lv; *(uint4 *)(RR + off) = rv;
-    }
-    WAVE_SYNC();
-    int dis = rk.pos - lk.pos, lstart, rstart, cmp;
-    if (dis >= 0) { lstart = lmo + dis; rstart = rmo; cmp = min(lml - dis, rml); }
-    else { lstart = lmo; rstart = rmo - dis; cmp = min(lml, rml + dis); }
-    const int ov_end = lstart + cmp, rov_end = rstart + cmp;
-    bool dirty = false;
-    for (int l0 = sl * 4; l0 < llen; l0 += 4 * SC_LPP) {                       // left read, 4 bases per lane (aligned LDS dwords)
-        const uint32_t ql4 = *(const uint32_t *)(LL + SC_QUAL + l0);
-        uint32_t s4 = 0, nq4 = ql4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int l = l0 + k, ql = (ql4 >> (8 * k)) & 0xFF;
-            int sc;
-            if (l >= lstart && l < ov_end) {
-                const int r = rstart + (l - lstart), qr = RR[SC_QUAL + r];
-                const int lb = (LL[l >> 1] >> ((l & 1) ? 0 : 4)) & 0xF, rb = (RR[r >> 1] >> ((r & 1) ? 0 : 4)) & 0xF;
-                if (lb == rb) { sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4; RR[SC_SCORE + r] = (uint8_t)(sc + p.score_bias); }     // pair.cpp:148-154
-                else {                                                          // pair.cpp:155-168: quals rewritten
-                    nq4 = (nq4 & ~(0xFFu << (8 * k))) | ((uint32_t)max(0, ql - qr) << (8 * k));
-                    RR[SC_QUAL + r] = (uint8_t)max(0, qr - ql); dirty = true;
-                    if (ql >= qr) { sc = d_qual2score(p, ql - qr) - 3; RR[SC_SCORE + r] = (uint8_t)p.score_bias; }
-                    else { sc = 0; RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
-                }
-            } else sc = d_qual2score(p, ql);
-            s4 |= (uint32_t)((sc + p.score_bias) & 0xFF) << (8 * k);
+    if (R == NONE32) { if (sl == 0) w.spatch[L] = GCE_PATCH_CONST; return; }   // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
+    const ReadDesc lk = load_desc(w.rdesc, L), rk = load_desc(w.rdesc, R);
+    if (!(lk.ml > 0 && rk.ml > 0)) { if (sl == 0) { w.spatch[L] = GCE_PATCH_CONST; w.spatch[R] = GCE_PATCH_CONST; } return; }
+    int dis = rk.pos - lk.pos, lstart, rstart, cmp;                            // pair.cpp:108-120
+    if (dis >= 0) { lstart = lk.mo + dis; rstart = rk.mo; cmp = min(lk.ml - dis, rk.ml); }
+    else { lstart = lk.mo; rstart = rk.mo - dis; cmp = min(lk.ml, rk.ml + dis); }
+    if (cmp <= 0) return;                                                      // no overlap: both reads are pure qual2score
+    if (lk.lq > 65535 || rk.lq > 65535) { raise_error(w.si, GCE_ERR_INVALID, L); return; }
+    if (sl == 0) { w.spatch[L] = (uint32_t)lstart | ((uint32_t)cmp << 16); w.spatch[R] = (uint32_t)rstart | ((uint32_t)cmp << 16); }
+    const uint8_t *lseq = b.seq + lk.so, *rseq = b.seq + rk.so;
+    uint8_t *lq = b.qual + lk.qo, *rq = b.qual + rk.qo;
+    int8_t *ls = w.score + lk.qo, *rs = w.score + rk.qo;
+    for (int i = sl; i < cmp; i += SC_LPP) {
+        const int l = lstart + i, r = rstart + i;
+        const int ql = lq[l], qr = rq[r];
+        if (d_nib(lseq, l) == d_nib(rseq, r)) {                               // pair.cpp:148-154
+            const int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4 + p.score_bias;
+            ls[l] = (int8_t)sc; rs[r] = (int8_t)sc;
+        } else {                                                              // pair.cpp:155-168: quals rewritten in place
+            lq[l] = (uint8_t)max(0, ql - qr); rq[r] = (uint8_t)max(0, qr - ql);
+            if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3 + p.score_bias); rs[r] = (int8_t)p.score_bias; }
+            else { ls[l] = (int8_t)p.score_bias; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
         }
-        *(uint32_t *)(LL + SC_SCORE + l0) = s4;
-        if (nq4 != ql4) *(uint32_t *)(LL + SC_QUAL + l0) = nq4;
-    }
-    // NOTE: the loop above reads RR quals of overlap positions before (possibly) rewriting them, one lane per position.
-    for (int r0 = sl * 4; r0 < rlen; r0 += 4 * SC_LPP) {                       // right bases outside the overlap
-        const uint32_t qr4 = *(const uint32_t *)(RR + SC_QUAL + r0);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const int r = r0 + k; if (r < rlen && !(r >= rstart && r < rov_end)) RR[SC_SCORE + r] = (uint8_t)(d_qual2score(p, (qr4 >> (8 * k)) & 0xFF) + p.score_bias); }
-    }
-    const bool any_dirty = __any(dirty) && true;                               // per wave is enough (a clean pair rewrites identical bytes)
-    WAVE_SYNC();
-    // write back: full 16-byte chunks, then the tail bytes (the rows of the next read start right after lq)
-    {
-        const int lfull = llen >> 4, rfull = rlen >> 4;
-        uint8_t *glq = b.qual + lk.qo, *grq = b.qual + rk.qo;
-        for (int ch = sl; ch < 10; ch += SC_LPP) {
-            if (ch < lfull) { *(uint4_unaligned *)(gls + 16 * ch) = *(const uint4 *)(LL + SC_SCORE + 16 * ch); if (any_dirty) *(uint4_unaligned *)(glq + 16 * ch) = *(const uint4 *)(LL + SC_QUAL + 16 * ch); }
-            if (ch < rfull) { *(uint4_unaligned *)(grs + 16 * ch) = *(const uint4 *)(RR + SC_SCORE + 16 * ch); if (any_dirty) *(uint4_unaligned *)(grq + 16 * ch) = *(const uint4 *)(RR + SC_QUAL + 16 * ch); }
-        }
-        for (int t = lfull * 16 + sl; t < llen; t += SC_LPP) { gls[t] = (int8_t)LL[SC_SCORE + t]; if (any_dirty) glq[t] = LL[SC_QUAL + t]; }
-        for (int t = rfull * 16 + sl; t < rlen; t += SC_LPP) { grs[t] = (int8_t)RR[SC_SCORE + t]; if (any_dirty) grq[t] = RR[SC_QUAL + t]; }
     }
 }
 
@@ -907,7 +757,7 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
         uint64_t qo = b.qual_off[r];
         int base = d_nib(b.seq + b.seq_off[r], rp);
         int qu = b.qual[qo + rp];
-        int sc = (int)(uint8_t)w.score[qo + rp] - p.score_bias;
+        int sc = d_score_at(p, w.score + qo, w.spatch[r], rp, qu);
         uint32_t t0 = t[(base * 3) * 64];
         uint32_t cnt = (t0 & 0xFFFF) + 1, tq = t0 >> 16;
         if ((uint32_t)qu > tq) tq = qu;
@@ -1319,8 +1169,9 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     uint32_t rd = lane < (int)np ? side[begin + lane] : NONE32;
     const bool has = rd != NONE32;
     int pos = 0, lq = 0, nc = 0, rrp = 0; uint32_t c0 = 0; uint64_t cigo = 0, so = 0, qo = 0;
-    int isz = 0;
+    int isz = 0; uint32_t patch = 0;
     if (has) {
+        patch = w.spatch[rd];
         const ReadDesc k = load_desc(w.rdesc, rd);
         pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen;
         if (nc > 1 || (nc == 1 && cig_op(c0) != 0)) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
@@ -1419,12 +1270,23 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 if (vv[u] >= 0) {                                              // wave-uniform
                     const int v = vv[u];
                     const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+                    const uint32_t vpatch = (uint32_t)rl32((int)patch, v);
                     const int r0 = c4 + vld;
                     if (act) {
                         if (r0 >= 0 && r0 + nval <= vlq) {                     // the whole unit lies inside the voter
                             s16[u] = *(const u16_unaligned *)(b.seq + vso + (r0 >> 1));
                             q4[u] = *(const u32_unaligned *)(b.qual + vqo + r0);
-                            sc4[u] = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + r0);
+                            // scores (vpatch is wave-uniform): qual2score of the four quals; a constant for a read scored without a
+                            // usable mate; the stored bytes inside the voter's mate-overlap patch
+                            if (vpatch == 0u) sc4[u] = d_q2s4_biased(p, q4[u]);
+                            else if (vpatch == GCE_PATCH_CONST) sc4[u] = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
+                            else {
+                                const int ps = (int)(vpatch & 0xFFFF), pe = ps + (int)(vpatch >> 16);
+                                const int a_ = max(ps - r0, 0), z_ = min(pe - r0, 4);          // bytes [a_, z_) of the unit are patch
+                                const uint32_t pmk = z_ > a_ ? ((z_ >= 4 ? 0xFFFFFFFFu : ((1u << (8 * z_)) - 1u)) & ~((1u << (8 * a_)) - 1u)) : 0u;
+                                const uint32_t st4 = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + r0);
+                                sc4[u] = (d_q2s4_biased(p, q4[u]) & ~pmk) | (st4 & pmk);
+                            }
                             vm[u] = bmask;
                         } else {                                               // unit straddles an end of the voter: byte by byte
                             uint32_t sx = t16;
@@ -1434,7 +1296,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                                     const int nb = d_nib(b.seq + vso, rp), sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
                                     sx = (sx & ~(0xFu << sh)) | ((uint32_t)nb << sh);
                                     q4[u] |= (uint32_t)b.qual[vqo + rp] << (8 * k);
-                                    sc4[u] |= (uint32_t)(uint8_t)w.score[vqo + rp] << (8 * k);
+                                    sc4[u] |= (uint32_t)((d_score_at(p, w.score + vqo, vpatch, rp, b.qual[vqo + rp]) + p.score_bias) & 0xFF) << (8 * k);
                                     vm[u] |= 0xFFu << (8 * k);
                                 }
                             }
@@ -1485,17 +1347,18 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
             const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
             const int r0 = col0 + vld, r1 = r0 + 1;
             const uint8_t *vs = b.seq + vso; const uint8_t *vq = b.qual + vqo; const int8_t *vsc = w.score + vqo;
+            const uint32_t vpatch = (uint32_t)rl32((int)patch, v);
             const bool in0 = a0 && r0 >= 0 && r0 < vlq, in1 = a1 && r1 >= 0 && r1 < vlq;
             if (in0 && in1 && !(r0 & 1)) {                                   // aligned pair of columns: one seq byte, 2+2 bytes
                 uint8_t sb = vs[r0 >> 1];
-                uint16_t qq = *(const u16_unaligned *)(vq + r0), sc = *(const u16_unaligned *)(vsc + r0);
+                uint16_t qq = *(const u16_unaligned *)(vq + r0);
                 int q0 = qq & 0xFF, q1 = qq >> 8;
                 pm0 |= 1u << (sb >> 4); pm1 |= 1u << (sb & 0xF);
-                ss0 += (int)(sc & 0xFF) - p.score_bias; ss1 += (int)(sc >> 8) - p.score_bias;
+                ss0 += d_score_at(p, vsc, vpatch, r0, q0); ss1 += d_score_at(p, vsc, vpatch, r1, q1);
                 tq0 = max(tq0, q0); tq1 = max(tq1, q1); qor |= q0 | q1;
             } else {
-                if (in0) { int q0 = vq[r0]; pm0 |= 1u << d_nib(vs, r0); ss0 += (int)(uint8_t)vsc[r0] - p.score_bias; tq0 = max(tq0, q0); qor |= q0; }
-                if (in1) { int q1 = vq[r1]; pm1 |= 1u << d_nib(vs, r1); ss1 += (int)(uint8_t)vsc[r1] - p.score_bias; tq1 = max(tq1, q1); qor |= q1; }
+                if (in0) { int q0 = vq[r0]; pm0 |= 1u << d_nib(vs, r0); ss0 += d_score_at(p, vsc, vpatch, r0, q0); tq0 = max(tq0, q0); qor |= q0; }
+                if (in1) { int q1 = vq[r1]; pm1 |= 1u << d_nib(vs, r1); ss1 += d_score_at(p, vsc, vpatch, r1, q1); tq1 = max(tq1, q1); qor |= q1; }
             }
         }
         if ((qor & 0x80) || ((pm0 | pm1) & ~0x8116u)) odd = true;            // qual >= 128 or a nibble outside {1,2,4,8,15}
@@ -1535,9 +1398,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 const int vl = vlist[kx], col = cplx[cbase + c];
                 const uint64_t vso = (uint64_t)__shfl((long long)so, vl), vqo = (uint64_t)__shfl((long long)qo, vl);
                 const int vld = left_mode ? 0 : __shfl(ld, vl), vlq = __shfl(lq, vl);
+                const uint32_t vpatch = (uint32_t)__shfl((int)patch, vl);
                 const int rp = col + vld;
                 if (live && rp >= 0 && rp < vlq) {
-                    const int nb = d_nib(b.seq + vso, rp), q = b.qual[vqo + rp], sc = (int)(uint8_t)w.score[vqo + rp] - p.score_bias;
+                    const int nb = d_nib(b.seq + vso, rp), q = b.qual[vqo + rp], sc = d_score_at(p, w.score + vqo, vpatch, rp, q);
                     const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
                     if (bin < 0 || (q & 0x80)) odd = true;
                     else {
