@@ -171,8 +171,8 @@ typedef struct gce_timing {
     double cluster_ms;           /* clustering scan (key + hash partition), the roofline kernel  */
     double csr_ms;               /* bucket offsets + scatter */
     double pairing_ms;           /* mate pairing + UMI grouping per cluster */
-    double score_ms;             /* Pair::computeScore */
-    double consensus_ms;         /* template pick + column vote */
+    double score_ms;             /* Pair::computeScore (mate-overlap patches) */
+    double consensus_ms;         /* template pick + column vote (fast + generic kernels) */
     double finish_ms;            /* duplex merge, filter, tags, stats */
     int64_t n_clusters, n_groups, n_pairs;
 } gce_timing;

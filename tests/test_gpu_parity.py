@@ -171,8 +171,8 @@ def test_empty_and_tiny_inputs(built):
 
 
 def test_full_size_shard_property(built):
-    """Size-independent property at BASELINE scale (cfg2, 1 M pairs / 2 M reads, ~200 flush events, oracle too slow to be the
-    checker here): processing the stream as three coordinate shards (with their tick_offset / trailing_flush context) must
+    """Size-independent property at scale (cfg3 generator, 400 k pairs / 800 k reads on 24 contigs, ~80 flush events):
+    processing the stream as three coordinate shards (with their tick_offset / trailing_flush context) must
     reproduce the whole-stream result table and the additive Stats exactly; and two runs of the same stream are identical."""
     from gencore_amd import synth
     from gencore_amd.capi import default_params
