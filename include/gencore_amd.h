@@ -104,7 +104,9 @@ typedef struct gce_params {
 /* A batch of reads in INPUT ORDER (coordinate-sorted), struct-of-arrays.  Offsets are start offsets, lengths
  * come from gce_core (l_qname, n_cigar, l_qseq).  seq is BAM 4-bit packed (high nibble = even base,
  * src/bamutil.cpp:173-186), qual is raw Phred.  seq/qual are MUTATED IN PLACE exactly where the reference
- * mutates its bam1_t records (src/pair.cpp:562-563, src/group.cpp:560-574,604-605, src/cluster.cpp:275-288). */
+ * mutates its bam1_t records (src/pair.cpp:562-563, src/group.cpp:560-574,604-605, src/cluster.cpp:275-288).
+ * Device buffers (gce_submit_device): `core` must be 16-byte aligned and every blob readable 16 bytes past its end
+ * (vector loads of the last read); gce_submit pads its own copies.  Reads longer than 65535 bases are rejected. */
 typedef struct gce_batch {
     int64_t         n_reads;
     const gce_core *core;        /* [n] */
