@@ -76,8 +76,14 @@ def main():
         assert lib.gce_set_reference(eng, tid, nib.data_ptr(), ln) == 0
 
     n_copies = args.steps + args.warmup
-    seqs = [t["seq"].clone() for _ in range(n_copies)]
-    quals = [t["qual"].clone() for _ in range(n_copies)]
+
+    def padded_clone(x):                                    # device blobs must be readable 16 bytes past their end
+        y = torch.zeros(x.numel() + 64, dtype=x.dtype, device=x.device)
+        y[:x.numel()].copy_(x)
+        return y
+    seqs = [padded_clone(t["seq"]) for _ in range(n_copies)]
+    quals = [padded_clone(t["qual"]) for _ in range(n_copies)]
+    t["qname"] = padded_clone(t["qname"])
 
     def make_batch(k):
         b = GceBatch()

@@ -1458,7 +1458,7 @@ __global__ void k_all_groups_to_fb(Work w, uint32_t n_groups, uint32_t n_slots) 
 }
 
 // global-memory consensus for the groups on fb_list (both sides), grid-stride
-__global__ __launch_bounds__(256) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     // per wave: new base [512], new qual [512], contested column list u16[512], pass-B tallies [32][5][4] u32, voter list [64]
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
