@@ -1259,6 +1259,9 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         uint32_t t16 = 0;
         if (act) t16 = *(const u16_unaligned *)(oseq + 2 * lane);
         uint32_t dacc = 0, ssum = 0, tqm = 0, qor = 0, cnt = 0;
+        const int s_min = min(min(p.s_high, p.s_moderate), min(p.s_low, p.s_bad));
+        const bool lower_bound_ok = nvot * s_min >= accept_score;      // heuristic only: any lower bound keeps the result exact
+        const uint32_t smin4 = 0x01010101u * (uint32_t)((s_min + p.score_bias) & 0xFF);
         unsigned long long m = vmask;
         while (m) {
             int vv[4]; uint32_t s16[4], q4[4], sc4[4], vm[4];
@@ -1278,14 +1281,17 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                             q4[u] = *(const u32_unaligned *)(b.qual + vqo + r0);
                             // scores (vpatch is wave-uniform): qual2score of the four quals; a constant for a read scored without a
                             // usable mate; the stored bytes inside the voter's mate-overlap patch
-                            if (vpatch == 0u) sc4[u] = d_q2s4_biased(p, q4[u]);
+                            // `lower_bound_ok` (wave-uniform): qual2score(q) >= min(s_*), and voters x min(s_*) already reaches
+                            // baseScoreReq, so the constant lower bound decides the early accept exactly (true sum >= bound);
+                            // columns that fail any test are recomputed exactly in pass B either way.
+                            if (vpatch == 0u) sc4[u] = lower_bound_ok ? smin4 : d_q2s4_biased(p, q4[u]);
                             else if (vpatch == GCE_PATCH_CONST) sc4[u] = 0x01010101u * (uint32_t)((p.s_moderate + p.score_bias) & 0xFF);
                             else {
                                 const int ps = (int)(vpatch & 0xFFFF), pe = ps + (int)(vpatch >> 16);
                                 const int a_ = max(ps - r0, 0), z_ = min(pe - r0, 4);          // bytes [a_, z_) of the unit are patch
                                 const uint32_t pmk = z_ > a_ ? ((z_ >= 4 ? 0xFFFFFFFFu : ((1u << (8 * z_)) - 1u)) & ~((1u << (8 * a_)) - 1u)) : 0u;
                                 const uint32_t st4 = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + r0);
-                                sc4[u] = (d_q2s4_biased(p, q4[u]) & ~pmk) | (st4 & pmk);
+                                sc4[u] = ((lower_bound_ok ? smin4 : d_q2s4_biased(p, q4[u])) & ~pmk) | (st4 & pmk);
                             }
                             vm[u] = bmask;
                         } else {                                               // unit straddles an end of the voter: byte by byte
