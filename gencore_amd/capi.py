@@ -114,7 +114,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GCE_LIB") or LIB_PATH          # GCE_LIB: A/B another build of the same ABI (tools/ab.sh)
     if not os.path.exists(p):
         raise OSError("libgencore_amd.so not built at %s — run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
     lib = C.CDLL(p, mode=C.RTLD_GLOBAL)

@@ -308,8 +308,10 @@ int gce_process(gce_engine *e) {
     w.n_chunks = n_chunks;
     const int64_t max_events = (p.tick_offset % p.period + N) / p.period + 2;
     w.max_events = (int)max_events;
-    uint64_t T = 1024; while (T < 2 * (uint64_t)n1) T <<= 1;
-    w.tmask = T - 1;
+    // buckets: 1.25 x reads (worst case, every read its own cluster, still probes at load 0.8; typical load is a few percent).
+    // Every per-step pass over the table (clear, count scan, offsets) is proportional to T, so T is not rounded to a power of two.
+    uint64_t T = ((uint64_t)n1 + (uint64_t)n1 / 4 + 2 * SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
+    w.tsize = T; w.tinv = 1.0 / (double)T;
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
     ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDesc)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
@@ -348,7 +350,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
     }
     HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
-    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)n_chunks), dim3(CHUNK), 0, s, b, p, w);
+    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)cdiv(n_chunks, CL_U)), dim3(CHUNK), 0, s, b, p, w);
     HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
     // ---- bucket offsets + compact cluster list.  cl_* arrays are sized by N (a cluster has >= 1 read).
     ENS(cl_slot, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);

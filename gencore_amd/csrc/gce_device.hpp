@@ -330,6 +330,17 @@ __device__ __forceinline__ uint64_t d_key_hash(const ClusterKey &k, uint32_t ins
     return ((g + (uint64_t)(uint32_t)k.left) << 1) | (m & 1);
 }
 
+// x mod T for a table size that is not a power of two: double-reciprocal quotient estimate (exact after one correction
+// step while x < 2^52, which covers every genome-linear bucket index); anything larger takes the 64-bit remainder.
+__device__ __forceinline__ uint64_t d_bucket(uint64_t x, uint64_t T, double tinv) {
+    if (x >> 52) return x % T;
+    const uint64_t q = (uint64_t)((double)x * tinv);
+    long long r = (long long)(x - q * T);
+    while (r < 0) r += (long long)T;
+    while (r >= (long long)T) r -= (long long)T;
+    return (uint64_t)r;
+}
+
 // padded in-memory l_qname (htslib l_extranul)
 __device__ __forceinline__ int d_lqname_pad(const gce_core &c) { return ((int)c.l_qname + 3) & ~3; }
 

@@ -35,7 +35,7 @@ struct Work {
     // events
     int32_t *ev_tid, *ev_pos; uint32_t *ev_read; int max_events;
     // hash table
-    uint64_t *table; uint32_t *tcount, *toff; uint64_t tmask;
+    uint64_t *table; uint32_t *tcount, *toff; uint64_t tsize; double tinv;      // tsize buckets (any size, not a power of two)
     // clusters
     uint32_t *cl_slot, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
     // cluster-local arrays (indexed by cl_start + k)
@@ -197,102 +197,156 @@ __device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *
     return ((int)(inst + 1) <= si->n_events) ? THR_PROPER : THR_NEVER;
 }
 
+// CL_U consecutive 256-read chunks per block, one read of each per thread, written stage by stage so that the CL_U
+// dependent chains (key record -> flush events -> bucket probe -> CAS -> owner check -> rank atomic) overlap their
+// memory round trips: the scan is bound by latency x occupancy, not by issue.
+#define CL_U 4
 __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
-    __shared__ unsigned int s_cnt[WAVES_PER_BLOCK];
+    __shared__ unsigned int s_cnt[CL_U][WAVES_PER_BLOCK];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    int64_t i = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
-    bool cl = false;
-    gce_core k;
-    if (i < b.n) {
-        union { gce_core c; uint4 q[2]; } u;                     // the 32-byte key record as two 16-byte loads (core[] is 16-byte aligned)
-        const uint4 *src = reinterpret_cast<const uint4 *>(b.core + i);
-        u.q[0] = src[0]; u.q[1] = src[1];
-        k = u.c;
-        cl = d_classify(k) == CLS_CLUSTERED;
+    const StreamInfo *si = w.si;
+    const unsigned int first_unm = si->first_unmapped;
+    const int n_ev_a = si->n_events_a, n_ev = si->n_events;
+    const long long per = p.period;
+    int64_t idx[CL_U]; bool cl[CL_U]; gce_core k[CL_U]; unsigned long long m[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        idx[u] = ((int64_t)blockIdx.x * CL_U + u) * CHUNK + threadIdx.x;
+        union { gce_core c; uint4 q[2]; } t;                     // the 32-byte key record as two 16-byte loads (core[] is 16-byte aligned)
+        t.q[0] = make_uint4(0, 0, 0, 0); t.q[1] = t.q[0];
+        if (idx[u] < b.n) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + idx[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
+        k[u] = t.c;
     }
-    unsigned long long m = __ballot(cl);
-    if (lane == 0) s_cnt[wv] = __popcll(m);
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        cl[u] = idx[u] < b.n && d_classify(k[u]) == CLS_CLUSTERED;
+        m[u] = __ballot(cl[u]);
+        if (lane == 0) s_cnt[u][wv] = __popcll(m[u]);
+    }
     __syncthreads();
-    uint64_t h = ~0ull;
-    ClusterKey key; key.tid = -1; key.left = -1; key.right = 0;
-    uint32_t ikey = 0xFFFFFFFFu;
-    if (cl) {
-        unsigned int inblock = lanes_below(m) + 1;
-        for (int q = 0; q < wv; q++) inblock += s_cnt[q];
-        long long per = p.period;
-        long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x] + inblock;      // the reference's `tick` after ++
-        int e = (int)((tick - 1) / per - p.tick_offset / per);                              // flush events before this read
-        const StreamInfo *si = w.si;
-        unsigned int U = si->first_unmapped;
-        bool seg_b = (U != NONE32) && ((unsigned)i > U);
-        key = d_key(k, p);
-        // first event of this segment whose walk takes the key (gencore.cpp:333-354):
-        //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
-        int lo = seg_b ? si->n_events_a : 0, hi = seg_b ? si->n_events : si->n_events_a;   // events [lo, hi) 0-based
-        auto cond = [&](int j) { int T = w.ev_tid[j], P = w.ev_pos[j]; return key.tid < T || (key.tid == T && key.left < P && key.right < (long long)P); };
-        // The answer is almost always the read's own epoch or the next one (a fragment spans far less than 10,000 reads):
-        // probe there first, fall back to the binary search only when the probe window does not bracket it.
-        int a = lo, z = hi;
-        int g = min(max(e, lo), hi);
-        if (g > lo && cond(g - 1)) z = g - 1;                                              // already flushable before its own epoch (odd isize)
-        else {
-            int steps = 0;
-            while (g < hi && steps < 4 && !cond(g)) { g++; steps++; }
-            if (g == hi || steps < 4 || cond(g)) { a = z = g; } else a = g + 1;
+    // ---- instance of each read: events before it (own epoch) vs. the first event whose walk takes its key
+    ClusterKey key[CL_U]; uint32_t ikey[CL_U]; int e_[CL_U], lo[CL_U], hi[CL_U], g[CL_U];
+    int T0[CL_U], P0[CL_U], T1[CL_U], P1[CL_U], T2[CL_U], P2[CL_U];
+    const int ev_last = max(n_ev - 1, 0);
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        key[u].tid = -1; key[u].left = -1; key[u].right = 0; ikey[u] = 0xFFFFFFFFu; e_[u] = 0; lo[u] = hi[u] = g[u] = 0;
+        T0[u] = P0[u] = T1[u] = P1[u] = T2[u] = P2[u] = 0;
+        if (cl[u]) {
+            unsigned int inblock = lanes_below(m[u]) + 1;
+            for (int q = 0; q < wv; q++) inblock += s_cnt[u][q];
+            const long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x * CL_U + u] + inblock;   // the reference's `tick` after ++
+            e_[u] = (int)((tick - 1) / per - p.tick_offset / per);                          // flush events before this read
+            const bool seg_b = (first_unm != NONE32) && ((unsigned)idx[u] > first_unm);
+            key[u] = d_key(k[u], p);
+            lo[u] = seg_b ? n_ev_a : 0; hi[u] = seg_b ? n_ev : n_ev_a;                      // events [lo, hi) 0-based
+            g[u] = min(max(e_[u], lo[u]), hi[u]);
+            ikey[u] = seg_b ? 0x80000000u : 0u;
+            // the answer is almost always the read's own epoch or the next one: fetch the three probes at once
+            const int j0 = min(max(g[u] - 1, 0), ev_last), j1 = min(g[u], ev_last), j2 = min(g[u] + 1, ev_last);
+            T0[u] = w.ev_tid[j0]; P0[u] = w.ev_pos[j0]; T1[u] = w.ev_tid[j1]; P1[u] = w.ev_pos[j1]; T2[u] = w.ev_tid[j2]; P2[u] = w.ev_pos[j2];
         }
-        while (a < z) {
-            int mid = (a + z) >> 1;
-            if (cond(mid)) z = mid; else a = mid + 1;
+    }
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        if (cl[u]) {
+            // first event of this segment whose walk takes the key (gencore.cpp:333-354):
+            //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
+            const ClusterKey ky = key[u];
+            auto takes = [&](int T, int P) { return ky.tid < T || (ky.tid == T && ky.left < P && ky.right < (long long)P); };
+            int a, z;
+            const int gg = g[u], l_ = lo[u], h_ = hi[u];
+            if (gg > l_ && takes(T0[u], P0[u])) { a = l_; z = gg - 1; }                    // already flushable before its own epoch (odd isize)
+            else if (gg >= h_ || takes(T1[u], P1[u])) a = z = gg;
+            else if (gg + 1 >= h_ || takes(T2[u], P2[u])) a = z = gg + 1;
+            else { a = gg + 2; z = h_; }
+            while (a < z) {
+                const int mid = (a + z) >> 1;
+                if (takes(w.ev_tid[mid], w.ev_pos[mid])) z = mid; else a = mid + 1;
+            }
+            const int f = a + 1;                                                            // 1-based; hi+1 if none
+            ikey[u] |= (uint32_t)max(e_[u], f - 1);
         }
-        int f = a + 1;                                                                      // 1-based; hi+1 if none
-        uint32_t inst = (uint32_t)max(e, f - 1);
-        ikey = inst | (seg_b ? 0x80000000u : 0u);
     }
     // ---- neighbouring lanes with the same (key, instance) are one run of one cluster (sorted input): only the run head
     //      probes the table and issues the CAS; the others copy its bucket.
     // (all shuffles are executed by every lane: a shuffle inside a divergent branch reads inactive source lanes as 0)
-    const int p_cl = __shfl_up((int)cl, 1), p_tid = __shfl_up(key.tid, 1), p_left = __shfl_up(key.left, 1), p_ik = __shfl_up((int)ikey, 1);
-    const long long p_right = __shfl_up((long long)key.right, 1);
-    const bool same_prev = lane > 0 && cl && p_cl && p_tid == key.tid && p_left == key.left && p_right == (long long)key.right && p_ik == (int)ikey;
-    const bool khead = cl && !same_prev;
-    if (khead) {
-        uint64_t mine = ((uint64_t)ikey << 32) | (uint32_t)i;
-        h = d_key_hash(key, ikey, p) & w.tmask;
-        for (;;) {
-            uint64_t cur = w.table[h];
-            if (cur == EMPTY64) {
-                cur = atomicCAS((unsigned long long *)&w.table[h], (unsigned long long)EMPTY64, (unsigned long long)mine);
-                if (cur == EMPTY64) break;                                                  // claimed: this read owns the bucket
+    bool khead[CL_U], done[CL_U]; uint64_t h[CL_U], cur[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        const int p_cl = __shfl_up((int)cl[u], 1), p_tid = __shfl_up(key[u].tid, 1), p_left = __shfl_up(key[u].left, 1), p_ik = __shfl_up((int)ikey[u], 1);
+        const long long p_right = __shfl_up((long long)key[u].right, 1);
+        const bool same_prev = lane > 0 && cl[u] && p_cl && p_tid == key[u].tid && p_left == key[u].left && p_right == (long long)key[u].right && p_ik == (int)ikey[u];
+        khead[u] = cl[u] && !same_prev;
+        h[u] = ~0ull; cur[u] = 0; done[u] = !khead[u];
+        if (khead[u]) { h[u] = d_bucket(d_key_hash(key[u], ikey[u], p), w.tsize, w.tinv); cur[u] = w.table[h[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CL_U; u++)                                                         // first probe: claim an empty bucket
+        if (khead[u] && cur[u] == EMPTY64) {
+            const uint64_t mine = ((uint64_t)ikey[u] << 32) | (uint32_t)idx[u];
+            cur[u] = atomicCAS((unsigned long long *)&w.table[h[u]], (unsigned long long)EMPTY64, (unsigned long long)mine);
+            if (cur[u] == EMPTY64) done[u] = true;                                          // claimed: this read owns the bucket
+        }
+    gce_core oc[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {                                                       // occupied by the same instance: whose key is it?
+        union { gce_core c; uint4 q[2]; } t;
+        t.q[0] = make_uint4(0, 0, 0, 0); t.q[1] = t.q[0];
+        if (!done[u] && (uint32_t)(cur[u] >> 32) == ikey[u]) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + (uint32_t)cur[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
+        oc[u] = t.c;
+    }
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        if (!done[u] && (uint32_t)(cur[u] >> 32) == ikey[u]) {
+            const ClusterKey ok = d_key(oc[u], p);
+            if (ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right) done[u] = true;
+        }
+        if (!done[u]) {                                                                     // collision: linear probing (rare)
+            const uint64_t mine = ((uint64_t)ikey[u] << 32) | (uint32_t)idx[u];
+            uint64_t hh = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
+            for (;;) {
+                uint64_t c = w.table[hh];
+                if (c == EMPTY64) {
+                    c = atomicCAS((unsigned long long *)&w.table[hh], (unsigned long long)EMPTY64, (unsigned long long)mine);
+                    if (c == EMPTY64) break;
+                }
+                if ((uint32_t)(c >> 32) == ikey[u]) {
+                    const gce_core o2 = b.core[(uint32_t)c];
+                    const ClusterKey ok = d_key(o2, p);
+                    if (ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right) break;
+                }
+                hh = hh + 1 == w.tsize ? 0 : hh + 1;
             }
-            if ((uint32_t)(cur >> 32) == ikey) {
-                gce_core oc = b.core[(uint32_t)cur];
-                ClusterKey ok = d_key(oc, p);
-                if (ok.tid == key.tid && ok.left == key.left && ok.right == key.right) break;
-            }
-            h = (h + 1) & w.tmask;
+            h[u] = hh;
         }
     }
-    {
-        const unsigned long long kheads = __ballot(khead);
-        const int kh = 63 - __clzll((long long)(kheads & ((2ull << lane) - 1ull)));
-        const uint64_t hh = (uint64_t)__shfl((long long)h, kh < 0 ? 0 : kh);
-        if (cl) h = hh;
-    }
     // ---- in-cluster rank: neighbouring lanes that landed in the same bucket (sorted input => runs) share ONE atomicAdd
-    const uint64_t hprev = (uint64_t)__shfl_up((long long)h, 1);
-    const bool head = cl && (lane == 0 || hprev != h);
-    const unsigned long long heads = __ballot(head), bounds = __ballot(head || !cl);
-    uint32_t rbase = 0;
-    if (head) {
-        unsigned long long later = bounds & ~((2ull << lane) - 1ull);
-        int next = later ? __ffsll((long long)later) - 1 : 64;
-        rbase = atomicAdd(&w.tcount[h], (unsigned)(next - lane));
+    uint32_t rbase[CL_U]; int hl[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        const unsigned long long kheads = __ballot(khead[u]);
+        const int kh = 63 - __clzll((long long)(kheads & ((2ull << lane) - 1ull)));
+        const uint64_t hh = (uint64_t)__shfl((long long)h[u], kh < 0 ? 0 : kh);
+        if (cl[u]) h[u] = hh;
+        const uint64_t hprev = (uint64_t)__shfl_up((long long)h[u], 1);
+        const bool head = cl[u] && (lane == 0 || hprev != h[u]);
+        const unsigned long long heads = __ballot(head), bounds = __ballot(head || !cl[u]);
+        rbase[u] = 0;
+        if (head) {
+            const unsigned long long later = bounds & ~((2ull << lane) - 1ull);
+            const int next = later ? __ffsll((long long)later) - 1 : 64;
+            rbase[u] = atomicAdd(&w.tcount[h[u]], (unsigned)(next - lane));
+        }
+        hl[u] = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));                // my run's head lane (valid when cl)
     }
-    const int hl = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));            // my run's head lane (valid when cl)
-    const uint32_t hb = (uint32_t)__shfl((int)rbase, hl < 0 ? 0 : hl);
-    if (i < b.n) {
-        if (cl) { w.slot[i] = (uint32_t)h; w.rank[i] = hb + (uint32_t)(lane - hl); }
-        else w.slot[i] = NONE32;
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        const uint32_t hb = (uint32_t)__shfl((int)rbase[u], hl[u] < 0 ? 0 : hl[u]);
+        if (idx[u] < b.n) {
+            if (cl[u]) { w.slot[idx[u]] = (uint32_t)h[u]; w.rank[idx[u]] = hb + (uint32_t)(lane - hl[u]); }
+            else w.slot[idx[u]] = NONE32;
+        }
     }
 }
 

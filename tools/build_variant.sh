@@ -1,0 +1,7 @@
+#!/bin/bash
+# build libgencore_amd.so of another git revision into ab/<name>.so for tools/ab.sh:  tools/build_variant.sh <git-ref> <name>
+set -e
+REF=$1; NAME=$2; D=$(mktemp -d)
+git -C /root/repo archive "$REF" gencore_amd/csrc include | tar -x -C "$D"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$D/gencore_amd/csrc/engine.hip" -o "/root/repo/ab/$NAME.so"
+rm -rf "$D"; echo "built ab/$NAME.so from $REF"
