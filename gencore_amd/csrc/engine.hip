@@ -54,7 +54,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf slow_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    DevBuf slow_list, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -128,7 +128,7 @@ void gce_destroy(gce_engine *e) {
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -382,9 +382,9 @@ int gce_process(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(fb_list, g1 * 4); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(fb_list, g1 * 4); ENS(gen_list, g1 * 8); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
-    w.fb_list = e->fb_list.as<uint32_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
+    w.fb_list = e->fb_list.as<uint32_t>(); w.gen_list = e->gen_list.as<uint32_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
     w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
@@ -400,14 +400,14 @@ int gce_process(gce_engine *e) {
             if ((rc = read_si(e)) != GCE_OK) return rc;
             HIPCHK(hipGetLastError());
         } else {
-            hipLaunchKernelGGL(k_all_groups_to_fb, dim3(cdiv(N, 256)), dim3(256), 0, s, w, NG, (uint32_t)N);
-            e->h_si.n_fb = NG;
+            e->h_si.n_fb = NG;                                       // every group, in order: the list itself is not materialised
         }
         if (e->h_si.n_fb > 0 && e->h_si.error == 0) {              // global-memory path
             const uint32_t nfb = e->h_si.n_fb;
             hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
             HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w);
+            hipLaunchKernelGGL(k_consensus_lean, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, 2u * nfb, e->fused_groups ? 0 : 1);
+            hipLaunchKernelGGL(k_consensus_fast, dim3(4096), dim3(256), 0, s, b, p, w);
             hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         } else HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));

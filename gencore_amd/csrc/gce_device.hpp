@@ -54,7 +54,7 @@ struct __attribute__((aligned(16))) ReadDesc {
     uint32_t c0;              // first CIGAR word (0 if none)
     int32_t pos, lq, isize;
     int32_t mo, ml;           // BamUtil::getMOffsetAndLen: first M block (bamutil.cpp:316-336)
-    uint16_t nc; uint16_t pad; int32_t rlen;   // n_cigar, bam_cigar2rlen
+    uint16_t nc; uint16_t tid16; int32_t rlen; // n_cigar; tid (0xFFFF = read it from the core record); bam_cigar2rlen
 };
 
 // three 16-byte loads instead of a dozen field loads
@@ -77,7 +77,7 @@ struct StreamInfo {
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_fb;                   // groups handed from the fused LDS kernel to the global-memory path
-    unsigned int pad1;
+    unsigned int n_gen;                  // group sides the lean consensus kernel handed to the full one
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];

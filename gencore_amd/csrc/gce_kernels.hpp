@@ -43,6 +43,7 @@ struct Work {
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
+    uint32_t *gen_list;                  // (group*2 + side) entries the lean consensus instantiation handed to the full one
     uint32_t *fb_list; uint8_t *slot_flag;   // groups the fused LDS kernel handed to the global-memory path; their pair slots
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     // generic scan scratch
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work
             w.qname_src[i] = (uint32_t)i; w.nm_new[i] = -1; w.fr[i] = -1; w.rr[i] = -1; w.mate[i] = NONE32;
             if (c == CLS_CLUSTERED) {
                 ReadDesc d;
-                d.so = b.seq_off[i]; d.qo = b.qual_off[i]; d.pos = k.pos; d.lq = k.l_qseq; d.isize = k.isize; d.nc = k.n_cigar; d.pad = 0;
+                d.so = b.seq_off[i]; d.qo = b.qual_off[i]; d.pos = k.pos; d.lq = k.l_qseq; d.isize = k.isize; d.nc = k.n_cigar; d.tid16 = (uint16_t)((uint32_t)k.tid < 0xFFFFu ? k.tid : 0xFFFF);
                 const uint32_t *cg = b.cigar + b.cigar_off[i];
                 d.c0 = k.n_cigar ? cg[0] : 0;
                 if (k.n_cigar == 1) { int op = cig_op(d.c0), ln = cig_len(d.c0); d.mo = 0; d.ml = op == 0 ? ln : 0; d.rlen = ln * consumes_ref(op); }
@@ -675,6 +676,12 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
         uint64_t uw[3] = {0, 0, 0}; int ulen = 0;
         if (pact) { uint32_t ur = w.pu[start + lane]; ulen = w.umi_len[ur]; load_be_words<3>(w.umi_ptr[ur], ulen, uw); }
         int cnt = 0, urank = 0;                              // umiCount[umi], and the rank of my UMI in std::string order
+        if (wave_max(ulen) <= 8) {                           // every UMI fits the first word (the usual 6-8 bp barcode)
+            for (int q = 0; q < (int)npairs; q++) {
+                const uint64_t a0 = rl64(uw[0], q); const int al = rl32(ulen, q);
+                cnt += (a0 == uw[0] && al == ulen); urank += (a0 != uw[0] ? a0 < uw[0] : al < ulen);
+            }
+        } else
         for (int q = 0; q < (int)npairs; q++) {
             uint64_t a0 = rl64(uw[0], q), a1 = rl64(uw[1], q), a2 = rl64(uw[2], q); int al = rl32(ulen, q);
             bool eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
@@ -1207,6 +1214,10 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
+// LEAN = the instantiation for the usual group side: every read carries the same single-op CIGAR and length ("150M" x depth)
+// and the packed-byte vote applies.  All CIGAR walking, per-voter range checks and the generic column loop are compiled out;
+// a side that does not qualify is appended to gen_list and taken by the full instantiation in a second launch.
+template <bool LEAN>
 __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
@@ -1223,12 +1234,12 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     uint32_t rd = lane < (int)np ? side[begin + lane] : NONE32;
     const bool has = rd != NONE32;
     int pos = 0, lq = 0, nc = 0, rrp = 0; uint32_t c0 = 0; uint64_t cigo = 0, so = 0, qo = 0;
-    int isz = 0; uint32_t patch = 0;
+    int isz = 0; uint32_t patch = 0; int tid16 = 0;
     if (has) {
         patch = w.spatch[rd];
         const ReadDesc k = load_desc(w.rdesc, rd);
-        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen;
-        if (nc > 1 || (nc == 1 && cig_op(c0) != 0)) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
+        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen; tid16 = k.tid16;
+        if (!LEAN && (nc > 1 || (nc == 1 && cig_op(c0) != 0))) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
     }
     const unsigned long long hmask = __ballot(has);
     if (!hmask) { if (lane == 0) rp_out[gi] = NONE32; return; }              // no read on this side: "no majority" / out == NULL
@@ -1245,8 +1256,9 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const int first_has = __ffsll((long long)hmask) - 1;
     const uint32_t c0f = (uint32_t)rl32((int)c0, first_has); const int lqf = rl32(lq, first_has);
     const bool uniform = !__any(has && (nc != 1 || c0 != c0f || lq != lqf)) && (is_left || left_mode);
+    if (LEAN && !uniform) { if (lane == 0) w.gen_list[atomicAdd(&w.si->n_gen, 1u)] = gi * 2 + (is_left ? 0 : 1); return; }
     int best, bc;
-    if (uniform) { best = first_has; bc = __popcll(hmask); }
+    if (LEAN || uniform) { best = first_has; bc = __popcll(hmask); }
     else {
         int cb = has ? 1 : 0;
         for (unsigned long long m = hmask; m; m &= m - 1) {
@@ -1270,20 +1282,22 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const uint32_t *ocig = b.cigar + o_cigo;
     // ---- voters and lenDiff (group.cpp:287-313,339-348)
     bool take = false; int ld = 0;
-    if (uniform) take = has;                                                  // identical CIGARs: every read votes, lenDiff 0
+    if (LEAN || uniform) take = has;                                          // identical CIGARs: every read votes, lenDiff 0
     else if (has) {
         take = lane == best || part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, left_mode);
         if (take) { ld = lq - o_lq; if (ld != 0 && pos == o_pos && part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, true)) ld = 0; }
     }
     const unsigned long long vmask = __ballot(take);
     int len = o_lq;
-    if (o_nc == 0) len = wave_min(take ? lq : 0x7FFFFFFF);                    // group.cpp:354-360
+    if (!LEAN && o_nc == 0) len = wave_min(take ? lq : 0x7FFFFFFF);           // group.cpp:354-360
     const int nbytes = (len + 1) >> 1;
     if (nbytes > 256) {                                                       // very long template: generic kernel
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
-    const int o_isz = rl32(isz, best), o_tid = b.core[out].tid;
+    const int o_isz = rl32(isz, best), o_t16 = rl32(tid16, best), o_tid = o_t16 != 0xFFFF ? o_t16 : b.core[out].tid;
+    // NM of the template (group.cpp:528-573), needed only at the very end: fetched now, off the critical path
+    const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
     const uint8_t *ref = nullptr; int64_t ref_len = 0;
     if (o_isz != 0 && o_tid >= 0 && o_tid < p.n_ref) {                       // group.cpp:362-367 -> Reference::getData
         const uint8_t *rdp = p.ref_data[o_tid];
@@ -1298,9 +1312,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     //      base unchanged, qual = max qual.  Everything else is queued for the full 16-bin rule cascade (pass B).
     const int accept_score = max(p.base_score_req, 1);
     int n_cplx = 0; bool odd = false;
-    const bool even_ld = left_mode || !__any(take && (ld & 1));              // every voter's columns stay byte aligned
+    const bool even_ld = LEAN || left_mode || !__any(take && (ld & 1));      // every voter's columns stay byte aligned
     const int nvot = __popcll(vmask);
-    if (even_ld && len <= 256 && nvot * (p.score_max + p.score_bias) <= 255) {
+    const bool swar_ok = even_ld && len <= 256 && nvot * (p.score_max + p.score_bias) <= 255 && p.q2s_swar_ok && accept_score + nvot * p.score_bias <= 255;
+    if (LEAN && !swar_ok) { if (lane == 0) w.gen_list[atomicAdd(&w.si->n_gen, 1u)] = gi * 2 + (is_left ? 0 : 1); return; }
+    if (LEAN || swar_ok) {
         // SWAR form: one lane = 4 consecutive columns = 2 packed-base bytes + 4 quals + 4 scores, i.e. three loads per voter.
         //   unanimity  : XOR of the voter's two base bytes with the template's, OR-accumulated (a zero nibble = all agree)
         //   score sum  : packed byte add (scores are stored biased >= 0 and nv * max < 256, so bytes never carry)
@@ -1326,11 +1342,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 s16[u] = t16; q4[u] = 0; sc4[u] = 0; vm[u] = 0;
                 if (vv[u] >= 0) {                                              // wave-uniform
                     const int v = vv[u];
-                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
+                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = (LEAN || left_mode) ? 0 : rl32(ld, v), vlq = LEAN ? len : rl32(lq, v);
                     const uint32_t vpatch = (uint32_t)rl32((int)patch, v);
                     const int r0 = c4 + vld;
                     if (act) {
-                        if (r0 >= 0 && r0 + nval <= vlq) {                     // the whole unit lies inside the voter
+                        if (LEAN || (r0 >= 0 && r0 + nval <= vlq)) {                     // the whole unit lies inside the voter
                             s16[u] = *(const u16_unaligned *)(b.seq + vso + (r0 >> 1));
                             q4[u] = *(const u32_unaligned *)(b.qual + vqo + r0);
                             // scores (vpatch is wave-uniform): qual2score of the four quals; a constant for a read scored without a
@@ -1379,17 +1395,29 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         }
         if (qor & 0x80808080u) odd = true;
         bool cq[4];
+        {
+            // the four columns of the lane decided on packed bytes (byte k = column c4 + k; bit 7 of a byte = that column's flag)
+            //   nibble pairs (hi = even column) -> one nibble per byte in column order: v_perm of the two masked halves
+            const uint32_t tn4 = __builtin_amdgcn_perm(0u, ((t16 >> 4) & 0x0F0Fu) | ((t16 & 0x0F0Fu) << 16), 0x03010200u);
+            const uint32_t dn4 = __builtin_amdgcn_perm(0u, ((dacc >> 4) & 0x0F0Fu) | ((dacc & 0x0F0Fu) << 16), 0x03010200u);
+            const uint32_t differ = (dn4 + 0x7F7F7F7Fu) & 0x80808080u;                       // some voter shows another nibble
+            //   template nibble in {1,2,4,8,15}: two 8-entry byte tables selected by bit 3
+            const uint32_t sel = tn4 & 0x07070707u;
+            const uint32_t v_lo = __builtin_amdgcn_perm(0x000000FFu, 0x00FFFF00u, sel);      // 1,2,4
+            const uint32_t v_hi = __builtin_amdgcn_perm(0xFF000000u, 0x000000FFu, sel);      // 8,15
+            const uint32_t hi8 = ((tn4 >> 3) & 0x01010101u) * 0xFFu;
+            const uint32_t valid = (v_hi & hi8) | (v_lo & ~hi8);
+            //   top quality >= moderate (bytes < 128, checked above)
+            const uint32_t ge_q = ((tqm | 0x80808080u) - 0x01010101u * (uint32_t)p.moderate_q) & 0x80808080u;
+            //   score sum >= baseScoreReq:  biased sum >= accept + count * bias, compared in two 16-bit halves per parity
+            const uint32_t rhs = cnt * (uint32_t)p.score_bias + 0x01010101u * (uint32_t)accept_score;
+            const uint32_t ge_e = (((ssum & 0x00FF00FFu) | 0x01000100u) - (rhs & 0x00FF00FFu)) & 0x01000100u;
+            const uint32_t ge_o = ((((ssum >> 8) & 0x00FF00FFu) | 0x01000100u) - ((rhs >> 8) & 0x00FF00FFu)) & 0x01000100u;
+            const uint32_t ge_s = (ge_e >> 1) | (ge_o << 7);
+            const uint32_t contested = ~(ge_q & ge_s & ~differ & valid) & bmask & 0x80808080u;
+            if (act) { *(uint32_t *)(resb + c4) = tn4; *(uint32_t *)(resq + c4) = tqm; }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            cq[k] = false;
-            if (k < nval) {
-                const int sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
-                const int tnib = (t16 >> sh) & 0xF;
-                const int ss = (int)((ssum >> (8 * k)) & 0xFF) - (int)((cnt >> (8 * k)) & 0xFF) * p.score_bias;
-                const int tq = (tqm >> (8 * k)) & 0xFF;
-                resb[c4 + k] = (uint8_t)tnib; resq[c4 + k] = (uint8_t)tq;
-                cq[k] = !(((dacc >> sh) & 0xF) == 0 && ((0x8116u >> tnib) & 1u) && ss >= accept_score && tq >= p.moderate_q);
-            }
+            for (int k = 0; k < 4; k++) cq[k] = (contested >> (8 * k + 7)) & 1u;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1449,6 +1477,12 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
             const int ncol = min(32, n_cplx - cbase);
             for (int k = lane; k < 32 * 5; k += 64) *(uint4 *)(tl + 4 * k) = make_uint4(0, 0, 0, 0);
             WAVE_SYNC();
+            // the reference base of each contested column: requested before the voters' bytes so that both are in flight together
+            int ref4 = 0;
+            if (ref && lane < ncol) {
+                const int ro = ref_off_fast(ocig, o_nc, o_c0, cplx[cbase + lane]);
+                if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro);
+            }
             const int items = ncol * nvot;
             for (int ibase = 0; ibase < items; ibase += 64) {             // wave-uniform trip count: every lane executes the
                 const int item = ibase + lane;                              // shuffles (an inactive source lane would read as 0)
@@ -1457,10 +1491,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 const int c = (int)(((uint32_t)it_ * magic) >> 20), kx = it_ - c * nvot;
                 const int vl = vlist[kx], col = cplx[cbase + c];
                 const uint64_t vso = (uint64_t)__shfl((long long)so, vl), vqo = (uint64_t)__shfl((long long)qo, vl);
-                const int vld = left_mode ? 0 : __shfl(ld, vl), vlq = __shfl(lq, vl);
+                const int vld = (LEAN || left_mode) ? 0 : __shfl(ld, vl), vlq = LEAN ? len : __shfl(lq, vl);
                 const uint32_t vpatch = (uint32_t)__shfl((int)patch, vl);
                 const int rp = col + vld;
-                if (live && rp >= 0 && rp < vlq) {
+                if (live && (LEAN || (rp >= 0 && rp < vlq))) {
                     const int nb = d_nib(b.seq + vso, rp), q = b.qual[vqo + rp], sc = d_score_at(p, w.score + vqo, vpatch, rp, q);
                     const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
                     if (bin < 0 || (q & 0x80)) odd = true;
@@ -1479,8 +1513,6 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                     const uint4 v4 = *(const uint4 *)(tl + (lane * 5 + k) * 4);
                     t.cnt[k] = (int)v4.x; t.ss[k] = (int)v4.y; t.qs[k] = (int)v4.z; t.tq[k] = (int)v4.w; t.total += (int)v4.y;
                 }
-                int ref4 = 0;
-                if (ref) { int ro = ref_off_fast(ocig, o_nc, o_c0, col); if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro); }
                 ColOut r = decide_column(t, p, resb[col], ref4);
                 resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
             }
@@ -1495,9 +1527,9 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     minc = wave_sum(minc);
     bool restore = false;
     if (minc != 0) {                                                          // group.cpp:528-573
-        if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+        if (o_nm_type == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
         else if (minc > 5) restore = true;
-        else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+        else if (lane == 0) { int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
     }
     if (!restore) {
         for (int bi = lane; bi < nbytes; bi += 64) {
@@ -1509,22 +1541,24 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     if (lane == 0) rp_out[gi] = out;
 }
 
-// default pipeline: every group takes the global-memory path
-__global__ void k_all_groups_to_fb(Work w, uint32_t n_groups, uint32_t n_slots) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_groups) w.fb_list[i] = i;
-    if (i < n_slots) w.slot_flag[i] = 1;
-    if (i == 0) w.si->n_fb = n_groups;
-}
-
-// global-memory consensus for the groups on fb_list (both sides), grid-stride
-__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+// global-memory consensus, one wave per (group, side).
+//   k_consensus_lean: every side of every group on the list (`identity`: all groups in order, the default pipeline; otherwise
+//                     fb_list, the groups the fused LDS kernel handed over); non-qualifying sides go to gen_list
+//   k_consensus_fast: the full instantiation over gen_list (grid-stride, count read on the device)
+__global__ __launch_bounds__(256, 6) void k_consensus_lean(DevBatch b, DevParams p, Work w, uint32_t n_items, int identity) {
     // per wave: new base [512], new qual [512], contested column list u16[512], pass-B tallies [32][5][4] u32, voter list [64]
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t n = 2u * w.si->n_fb;
+    const uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (idx < n_items) consensus_fast_side<true>(b, p, w, identity ? (idx >> 1) : w.fb_list[idx >> 1], !(idx & 1), s_res[wv], lane);
+}
+__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t n = w.si->n_gen;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
-        consensus_fast_side(b, p, w, w.fb_list[idx >> 1], !(idx & 1), s_res[wv], lane);
+        const uint32_t e = w.gen_list[idx];
+        consensus_fast_side<false>(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
         WAVE_SYNC();
     }
 }
