@@ -655,26 +655,53 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
         if (cmp < 0) LT |= 1ull << j;
     }
     const uint32_t pidx = __popcll(LT);                     // distinct names before mine
-    if (act && !first) {                                    // setRight: UMI must equal the pair's current UMI if that is non-empty
-        unsigned long long prev = EQ & LOW;                 // predecessor in arrival order = largest index among them
-        uint32_t pv = NONE32; 
-        for (unsigned long long m = prev; m; m &= m - 1) { uint32_t o = w.members[start + (__ffsll((long long)m) - 1)]; if (pv == NONE32 || o > pv) pv = o; }
-        if (w.umi_len[pv] != 0 && !d_bytes_equal(w.umi_ptr[pv], w.umi_len[pv], w.umi_ptr[my], w.umi_len[my])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
-    }
-    if (act) {
-        if (first) { w.pl[start + pidx] = my; if (last) w.pr[start + pidx] = NONE32; }
-        if (last && !first) w.pr[start + pidx] = my;
-        if (last) w.pu[start + pidx] = my;
+    // every read's UMI as big-endian words in registers (<= 24 bytes, checked above): no byte loops over global memory below
+    uint64_t ruw[3];
+    load_be_words<3>(act ? w.umi_ptr[my] : nullptr, act ? ul : 0, ruw);
+    {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty.  The pair's current
+        // read is the predecessor in arrival order = the largest read index among the same-name reads before mine.
+        unsigned long long prev = act ? (EQ & LOW) : 0ull;
+        const int rounds = wave_max(__popcll(prev));
+        int plane = -1; uint32_t pv = 0;
+        for (int r = 0; r < rounds; r++) {                  // (all lanes run the shuffles)
+            const bool has = prev != 0;
+            const int src = has ? __ffsll((long long)prev) - 1 : lane;
+            prev &= prev - 1;
+            const uint32_t o = (uint32_t)__shfl((int)my, src);
+            if (has && (plane < 0 || o > pv)) { pv = o; plane = src; }
+        }
+        if (rounds > 0) {
+            const int src = plane < 0 ? lane : plane;
+            const uint64_t q0 = (uint64_t)__shfl((long long)ruw[0], src), q1 = (uint64_t)__shfl((long long)ruw[1], src), q2 = (uint64_t)__shfl((long long)ruw[2], src);
+            const int qul = __shfl(ul, src);
+            if (plane >= 0 && qul != 0 && !(qul == ul && q0 == ruw[0] && q1 == ruw[1] && q2 == ruw[2])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
+        }
     }
     const int any_umi = __any(act && last && ul > 0);
-    WAVE_SYNC();
-    // ---- lanes now stand for pairs (qname order)
+    // ---- lanes now stand for pairs (qname order): every read pushes its fields to the lane of its pair (ds_permute).
+    //      Lanes that have nothing to send aim at lane 63, which is a pair lane only when all 64 reads are mate-less
+    //      singletons -- and then every lane sends.  Unwritten destination lanes read 0.
     const bool pact = lane < (int)npairs;
     uint32_t L = NONE32, R = NONE32, g_of = 0, ngroups = 1;
-    if (pact) { L = w.pl[start + lane]; R = w.pr[start + lane]; }
+    {
+        const int to_first = (first ? (int)pidx : 63) << 2, to_right = ((last && !first) ? (int)pidx : 63) << 2;
+        L = (uint32_t)__builtin_amdgcn_ds_permute(to_first, first ? (int)(my + 1u) : 0) - 1u;
+        R = (uint32_t)__builtin_amdgcn_ds_permute(to_right, (last && !first) ? (int)(my + 1u) : 0) - 1u;
+        if (!pact) { L = NONE32; R = NONE32; }
+    }
     if (any_umi) {                                           // greedy UMI grouping (cluster.cpp:57-100)
-        uint64_t uw[3] = {0, 0, 0}; int ulen = 0;
-        if (pact) { uint32_t ur = w.pu[start + lane]; ulen = w.umi_len[ur]; load_be_words<3>(w.umi_ptr[ur], ulen, uw); }
+        uint64_t uw[3]; int ulen;
+        {
+            const int to_last = (last ? (int)pidx : 63) << 2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(to_last, last ? (int)(uint32_t)ruw[k] : 0);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(to_last, last ? (int)(uint32_t)(ruw[k] >> 32) : 0);
+                uw[k] = pact ? (((uint64_t)hi << 32) | lo) : 0ull;
+            }
+            ulen = __builtin_amdgcn_ds_permute(to_last, last ? ul : 0);
+            if (!pact) ulen = 0;
+        }
         int cnt = 0, urank = 0;                              // umiCount[umi], and the rank of my UMI in std::string order
         if (wave_max(ulen) <= 8) {                           // every UMI fits the first word (the usual 6-8 bp barcode)
             for (int q = 0; q < (int)npairs; q++) {
