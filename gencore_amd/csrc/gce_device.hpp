@@ -163,7 +163,7 @@ __device__ __forceinline__ int d_ref_nib(const uint8_t *ref, int64_t pos) {
     int b = ref[pos >> 1];
     int code = (pos & 1) ? (b >> 4) : (b & 0xF);     // FASTA code: A=1,T=2,C=3,G=4
     // -> BAM nibble: A=1, T=8, C=2, G=4
-    return code == 1 ? 1 : code == 2 ? 8 : code == 3 ? 2 : code == 4 ? 4 : 0;
+    return (int)((0x42810u >> (4 * (code < 5 ? code : 5))) & 0xFu);   // nibble table {0,1,8,2,4}, 0 beyond
 }
 
 // Pair::qual2score (pair.cpp:77-86)

@@ -1237,6 +1237,56 @@ __device__ __forceinline__ ColOut decide_column(const Tally5 &t, const DevParams
     return r;
 }
 
+// decide_column with the (score, qual-sum, bin index) triple of every bin packed into one 32-bit key, so that "last bin with
+// the lexicographic maximum" is a plain unsigned max:  key = (score + off) << 17 | qualsum << 4 | index.
+//   off = voters x score_bias makes every score sum non-negative;  <= 64 voters, score_max + bias <= 255, quals < 128
+//   (callers send anything else to the generic kernel)  =>  14 + 13 + 4 bits.
+// The eleven absent bins (0, 0) are represented by their last member: index 14, or 13 once 14 itself is the top.
+__device__ __forceinline__ ColOut decide_column_packed(const Tally5 &t, const DevParams &p, int out_base, int ref4) {
+    const int IDX[5] = {1, 2, 4, 8, 15};
+    const int off = (t.cnt[0] + t.cnt[1] + t.cnt[2] + t.cnt[3] + t.cnt[4]) * p.score_bias;
+    uint32_t key[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) key[k] = ((uint32_t)(t.ss[k] + off) << 17) | ((uint32_t)t.qs[k] << 4) | (uint32_t)IDX[k];
+    const uint32_t kabs = ((uint32_t)off << 17) | 14u;
+    const uint32_t tk = max(max(max(key[0], key[1]), max(key[2], key[3])), max(key[4], kabs));
+    int top = (int)(tk & 15u);
+    uint32_t sk = top == 14 ? kabs - 1u : kabs;
+#pragma unroll
+    for (int k = 0; k < 5; k++) sk = max(sk, IDX[k] == top ? 0u : key[k]);
+    const int sec = (int)(sk & 15u);
+    const int top_s = (int)(tk >> 17) - off, sec_q = (int)((sk >> 4) & 0x1FFFu);
+    int top_num = 0, top_qual = 0, sec_num = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { if (IDX[k] == top) { top_num = t.cnt[k]; top_qual = t.tq[k]; } if (IDX[k] == sec) sec_num = t.cnt[k]; }
+    ColOut r; r.base = out_base; r.minc = 0;
+    bool need = false;
+    if (sec_num == 0) {                                                       // group.cpp:421-428
+        if (top_s >= p.base_score_req && top_qual >= p.moderate_q) { r.qual = top_qual; return r; }
+        need = true;
+    }
+    if (sec_num == 1) {                                                       // group.cpp:442-457
+        if (sec_q <= p.low_q) { if (top_num < 2 && top_qual < p.high_q) need = true; }
+        else { if (top_num < 3 || top_qual < p.high_q) need = true; }
+    }
+    if (sec_num > 1 && ((double)top_s < p.score_percent_req * (double)t.total || top_qual < p.moderate_q)) need = true;   // :460-464
+    if (top_s < p.base_score_req || top_qual <= p.low_q) need = true;         // :466-467
+    if (need && ref4 != 0) {                                                  // :470-501 (ref4 is one of 1,2,4,8)
+        int rbq = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (IDX[k] == ref4) rbq = t.tq[k];        // highest quality among the ref-consistent voters (< 128 here)
+        if (rbq >= p.high_q) top = ref4;
+        if (top_qual < p.moderate_q) top = ref4;
+        if (top == ref4) top_qual = rbq;
+    }
+    if (out_base != top) {                                                    // :503-524
+        r.base = top;
+        if (ref4 != 0) { if (out_base == ref4) r.minc = 1; else if (top == ref4) r.minc = -1; }
+    }
+    r.qual = top_qual;
+    return r;
+}
+
 typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
@@ -1540,7 +1590,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                     const uint4 v4 = *(const uint4 *)(tl + (lane * 5 + k) * 4);
                     t.cnt[k] = (int)v4.x; t.ss[k] = (int)v4.y; t.qs[k] = (int)v4.z; t.tq[k] = (int)v4.w; t.total += (int)v4.y;
                 }
-                ColOut r = decide_column(t, p, resb[col], ref4);
+                ColOut r = decide_column_packed(t, p, resb[col], ref4);
                 resb[col] = (uint8_t)r.base; resq[col] = (uint8_t)r.qual; minc += r.minc;
             }
             WAVE_SYNC();

@@ -7,7 +7,7 @@ f=glob.glob('gpurun_out/exp/e$x/**/*counter_collection.csv',recursive=True)
 acc=collections.defaultdict(float)
 for fn in f:
     for r in csv.DictReader(open(fn)):
-        if r['Kernel_Name'].startswith('k_consensus_fast'):
+        if r['Kernel_Name'].startswith('k_consensus_lean'):
             acc[r['Counter_Name']]+=float(r['Counter_Value'])
 w=acc.get('SQ_WAVES',1)
 print('EXP $x', {k: round(v/w,1) for k,v in acc.items()}, 'waves', w)
