@@ -198,7 +198,81 @@ __device__ __forceinline__ bool d_is_umi_char(char c) { return c == 'A' || c == 
 
 // BamUtil::getUMI(string, prefix) (bamutil.cpp:40-112).  Returns false where the reference throws.
 // `n` = strlen(s) when the caller already knows it (l_qname - 1), or -1.
+// ---- packed-byte helpers for the name parsers: masks carry 0x80 in every selected byte of a 64-bit word
+typedef uint64_t u64_unaligned_t __attribute__((aligned(1)));
+__device__ __forceinline__ uint64_t d_zero_bytes(uint64_t x) {          // exact: 0x80 where the byte of x is zero
+    const uint64_t m = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((x & m) + m) | x | m);
+}
+__device__ __forceinline__ uint64_t d_eq_bytes(uint64_t w, char c) { return d_zero_bytes(w ^ (0x0101010101010101ull * (uint8_t)c)); }
+__device__ __forceinline__ uint64_t d_umi_bytes(uint64_t w) {            // [ATCG_]
+    return d_eq_bytes(w, 'A') | d_eq_bytes(w, 'T') | d_eq_bytes(w, 'C') | d_eq_bytes(w, 'G') | d_eq_bytes(w, '_');
+}
+// bytes lo <= j < hi of word k of the window (j = 8k + byte), as a full-byte mask
+__device__ __forceinline__ uint64_t d_range_bytes(int lo, int hi, int k) {
+    const int a = min(max(lo - 8 * k, 0), 8), z = min(max(hi - 8 * k, 0), 8);
+    const uint64_t upto_z = z >= 8 ? ~0ull : ((1ull << (8 * z)) - 1ull), upto_a = a >= 8 ? ~0ull : ((1ull << (8 * a)) - 1ull);
+    return upto_z & ~upto_a;
+}
+
+__device__ inline bool d_umi_slice_bytes(const char *s, const DevParams &p, int &start, int &len, int n);
+
+// BamUtil::getUMI(string, prefix) on the LAST 32 BYTES of a name held in four registers (bamutil.cpp:40-112): the prefix
+// character / ':' that anchors the UMI is practically always inside that window, and the scans become a handful of packed
+// compares instead of two divergent byte loops per read.  Anything the window cannot answer takes the byte walk.
+// Reads up to 7 bytes past s[n-1]: device blobs are readable 16 bytes past their end (include/gencore_amd.h).
 __device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start, int &len, int n = -1) {
+    if (n < 0 || p.prefix_len > 4) return d_umi_slice_bytes(s, p, start, len, n);
+    const int base = n > 32 ? n - 32 : 0, nwin = n - base;
+    uint64_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = 8 * k < nwin ? *(const u64_unaligned_t *)(s + base + 8 * k) : 0ull;
+    start = 0; len = 0;
+    uint64_t anchor[4];                                                    // prefix characters, or ':'
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t h = 0;
+        if (p.prefix_len > 0) { for (int c = 0; c < p.prefix_len; c++) h |= d_eq_bytes(w[k], p.prefix[c]); }
+        else h = d_eq_bytes(w[k], ':');
+        anchor[k] = h & d_range_bytes(0, nwin, k);
+    }
+    int wpos = -1;                                                         // window index of the last anchor byte
+#pragma unroll
+    for (int k = 3; k >= 0; k--) if (wpos < 0 && anchor[k]) wpos = 8 * k + ((63 - __clzll((long long)anchor[k])) >> 3);
+    if (wpos < 0) {
+        if (base == 0) return true;                                        // no anchor anywhere: no UMI
+        return d_umi_slice_bytes(s, p, start, len, n);                     // anchor (if any) in front of the window
+    }
+    if (p.prefix_len > 0) {
+        const int wst = wpos + 2;                                          // find_last_of + 2 (bamutil.cpp:47-50)
+        if (base + wst > n) return false;                                  // substr(start) with start > size() throws
+        int l = nwin - wst;                                                // run of [ATCG_] from wst, ended by the first other byte
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const uint64_t stop = ~d_umi_bytes(w[k]) & 0x8080808080808080ull & d_range_bytes(wst, nwin, k);
+            if (stop) l = 8 * k + ((__ffsll((long long)stop) - 1) >> 3) - wst;
+        }
+        start = base + wst; len = l;
+        return true;
+    }
+    // no prefix: text after the last ':' if it is all [ATCG_] with at most one '_' (bamutil.cpp:65-111)
+    const int sep = base + wpos;
+    if (sep >= n - 1) return true;
+    bool ok = true; int us = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t tail = d_range_bytes(wpos + 1, nwin, k);
+        if (~d_umi_bytes(w[k]) & 0x8080808080808080ull & tail) ok = false;
+        us += __popcll(d_eq_bytes(w[k], '_') & tail);
+    }
+    int st = sep + 1;
+    { const int j = wpos + 1; const char c = (char)(w[j >> 3] >> (8 * (j & 7))); if (st < n - 1 && c == '_') { st++; us--; } }
+    if (!ok || us > 1) return true;
+    start = st; len = n - st;
+    return true;
+}
+
+__device__ inline bool d_umi_slice_bytes(const char *s, const DevParams &p, int &start, int &len, int n) {
     if (n < 0) { n = 0; while (s[n]) n++; }
     start = 0; len = 0;
     if (p.prefix_len > 0) {
