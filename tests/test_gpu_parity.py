@@ -158,6 +158,33 @@ def test_error_codes_match_reference_fatal_paths(built):
     assert want.status == -12
 
 
+@pytest.mark.parametrize("prefix", ["UMI", ""])
+def test_umi_parse_window_edges(built, prefix):
+    """BamUtil::getUMI edge cases around the engine's 32-byte register window (anchor in front of the window, at its first
+    byte, missing, run cut by a foreign character, duplex UMIs, underscore rules of the no-prefix form): every name is one
+    pair of one cluster, so the parsed UMIs decide the grouping and the FR tags, which must match the oracle."""
+    from gencore_amd.batch import ReadBatch
+    from gencore_amd.capi import default_params
+    tl = np.asarray([100000], np.uint32)
+    seq = "ACGTACGTACGTACGTACGT"
+    if prefix:
+        names = ["r1:UMI_ACGTAC", "r2:UMI_ACGTAC", "r3:UMI_ACGTAA", "UMI_ACGT" + "x" * 40, "UMI_ACGT" + "y" * 24, "UMI_ACGT" + "z" * 23,
+                 "k" * 50, "kk", "abcUA", "q:UMI_ACGTxACGT", "d1:UMI_ACGT_TTGA", "d2:UMI_TTGA_ACGT", "w" * 22 + ":UMI_ACGTAC",
+                 "w" * 21 + ":UMI_ACGTAC", "w" * 23 + ":UMI_ACGTAC", "e:UMI_", "f:UMI_ACGTAC:tail", "g" * 40 + ":UMI_GGGGGGGGGGGGGGGGGGGG"]
+    else:
+        names = ["a:b:ACGT", "a:c:ACGT", "a:d:ACGA", "a:b:ACGT_TTGA", "a:e:TTGA_ACGT", "a:b:_ACGT", "a:b:AC_GT_TT", "a:b:ACGX", "abc", "abc:",
+                 ":" + "A" * 40, "n" * 45, "n" * 30 + ":ACGT", "m" * 27 + ":ACGT", "m" * 28 + ":ACGT", "m" * 26 + ":ACGT", "p:q:__A", "p:q:_"]
+    recs = []
+    for nm in names:
+        recs.append(dict(qname=nm, flag=99, tid=0, pos=100, cigar="20M", mtid=0, mpos=130, isize=50, seq=seq, qual=[37] * 20, nm=0))
+    for nm in names:
+        recs.append(dict(qname=nm, flag=147, tid=0, pos=130, cigar="20M", mtid=0, mpos=100, isize=-50, seq=seq, qual=[37] * 20, nm=0))
+    for thr in (0, 1, 2):
+        prm = default_params(n_targets=1, target_len=tl.ctypes.data, umi_prefix=prefix, proper_umi_diff_threshold=thr, flush_period=7)
+        got, want = run_both(ReadBatch.from_records(recs), prm, [])
+        assert want.status == 0 and got.out_flag.sum() > 0
+
+
 def test_empty_and_tiny_inputs(built):
     from gencore_amd.batch import ReadBatch
     from gencore_amd.capi import default_params
