@@ -11,6 +11,7 @@
 
 #include "gce_kernels.hpp"
 #include "gce_fused.hpp"
+#include "gce_lean2.hpp"
 
 namespace {
 
@@ -54,7 +55,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf slow_list, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    DevBuf slow_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -128,7 +129,7 @@ void gce_destroy(gce_engine *e) {
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -323,7 +324,7 @@ int gce_process(gce_engine *e) {
     ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
     w.slow_list = e->slow_list.as<uint32_t>();
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
-    ENS(scan_part, (size_t)(nblk_T > nblk_N ? nblk_T : nblk_N) * 8 + 8); ENS(si, sizeof(StreamInfo));
+    ENS(scan_part, (size_t)(nblk_T > 2 * nblk_N ? nblk_T : 2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
     w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.qname_src = e->qname_src.as<uint32_t>(); w.nm_new = e->nm_new.as<int32_t>();
@@ -382,15 +383,16 @@ int gce_process(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(fb_list, g1 * 4); ENS(gen_list, g1 * 8); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(fb_list, g1 * 4); ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
-    w.fb_list = e->fb_list.as<uint32_t>(); w.gen_list = e->gen_list.as<uint32_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
+    w.fb_list = e->fb_list.as<uint32_t>(); w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
     w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     if (NG > 0 && e->h_si.error == 0) {
         if (e->fused_groups) HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
         HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
+        HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
         hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
         if (e->fused_groups) {
             // fused LDS group kernels, three LDS tiers by pairs per group: (0,8], (8,16], (16,32]; larger groups go to fb_list
@@ -406,7 +408,15 @@ int gce_process(gce_engine *e) {
             const uint32_t nfb = e->h_si.n_fb;
             hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
             HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-            hipLaunchKernelGGL(k_consensus_lean, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, 2u * nfb, e->fused_groups ? 0 : 1);
+            static const bool lean_pairs = !(getenv("GCE_LEAN2") && atoi(getenv("GCE_LEAN2")) == 0);    // 0: one wave per side instead of per group
+            if (lean_pairs) hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, nfb, e->fused_groups ? 0 : 1);
+            else hipLaunchKernelGGL(k_consensus_lean, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, 2u * nfb, e->fused_groups ? 0 : 1);
+            {   // compact the flagged sides into gen_list
+                const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
+                hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
+                hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
+                hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
+            }
             hipLaunchKernelGGL(k_consensus_fast, dim3(4096), dim3(256), 0, s, b, p, w);
             hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         } else HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));

@@ -77,8 +77,9 @@ struct StreamInfo {
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_fb;                   // groups handed from the fused LDS kernel to the global-memory path
-    unsigned int n_gen;                  // group sides the lean consensus kernel handed to the full one
+    unsigned int pad1;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
+    unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
 };

@@ -43,7 +43,8 @@ struct Work {
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
-    uint32_t *gen_list;                  // (group*2 + side) entries the lean consensus instantiation handed to the full one
+    uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
+                                          // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
     uint32_t *fb_list; uint8_t *slot_flag;   // groups the fused LDS kernel handed to the global-memory path; their pair slots
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     // generic scan scratch
@@ -1293,7 +1294,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
 // LEAN = the instantiation for the usual group side: every read carries the same single-op CIGAR and length ("150M" x depth)
 // and the packed-byte vote applies.  All CIGAR walking, per-voter range checks and the generic column loop are compiled out;
-// a side that does not qualify is appended to gen_list and taken by the full instantiation in a second launch.
+// a side that does not qualify is flagged (gen_flag -> gen_list) and taken by the full instantiation in a second launch.
 template <bool LEAN>
 __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
@@ -1333,7 +1334,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const int first_has = __ffsll((long long)hmask) - 1;
     const uint32_t c0f = (uint32_t)rl32((int)c0, first_has); const int lqf = rl32(lq, first_has);
     const bool uniform = !__any(has && (nc != 1 || c0 != c0f || lq != lqf)) && (is_left || left_mode);
-    if (LEAN && !uniform) { if (lane == 0) w.gen_list[atomicAdd(&w.si->n_gen, 1u)] = gi * 2 + (is_left ? 0 : 1); return; }
+    if (LEAN && !uniform) { if (lane == 0) w.gen_flag[gi * 2 + (is_left ? 0 : 1)] = 1; return; }
     int best, bc;
     if (LEAN || uniform) { best = first_has; bc = __popcll(hmask); }
     else {
@@ -1392,7 +1393,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const bool even_ld = LEAN || left_mode || !__any(take && (ld & 1));      // every voter's columns stay byte aligned
     const int nvot = __popcll(vmask);
     const bool swar_ok = even_ld && len <= 256 && nvot * (p.score_max + p.score_bias) <= 255 && p.q2s_swar_ok && accept_score + nvot * p.score_bias <= 255;
-    if (LEAN && !swar_ok) { if (lane == 0) w.gen_list[atomicAdd(&w.si->n_gen, 1u)] = gi * 2 + (is_left ? 0 : 1); return; }
+    if (LEAN && !swar_ok) { if (lane == 0) w.gen_flag[gi * 2 + (is_left ? 0 : 1)] = 1; return; }
     if (LEAN || swar_ok) {
         // SWAR form: one lane = 4 consecutive columns = 2 packed-base bytes + 4 quals + 4 scores, i.e. three loads per voter.
         //   unanimity  : XOR of the voter's two base bytes with the template's, OR-accumulated (a zero nibble = all agree)
@@ -1632,7 +1633,7 @@ __global__ __launch_bounds__(256, 6) void k_consensus_lean(DevBatch b, DevParams
 __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t n = w.si->n_gen;
+    const uint32_t n = (uint32_t)w.si->n_gen_items;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t e = w.gen_list[idx];
         consensus_fast_side<false>(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
