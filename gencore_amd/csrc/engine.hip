@@ -55,7 +55,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf slow_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    DevBuf k64, slow_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -129,7 +129,7 @@ void gce_destroy(gce_engine *e) {
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->slow_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -320,7 +320,7 @@ int gce_process(gce_engine *e) {
     ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
     ENS(table, T * 8); ENS(tcount, T * 4); ENS(toff, T * 4);
-    ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
+    ENS(k64, n1 * 24); ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
     ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
     w.slow_list = e->slow_list.as<uint32_t>();
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
@@ -332,7 +332,7 @@ int gce_process(gce_engine *e) {
     w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
     w.table = e->table.as<uint64_t>(); w.tcount = e->tcount.as<uint32_t>(); w.toff = e->toff.as<uint32_t>();
-    w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
+    w.k64 = e->k64.as<uint64_t>(); w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
     w.pu = e->pu.as<uint32_t>(); w.pg = e->pg.as<uint32_t>(); w.gpl = e->gpl.as<uint32_t>(); w.gpr = e->gpr.as<uint32_t>();
     w.grp_begin = e->grp_begin.as<uint32_t>(); w.grp_n = e->grp_n.as<uint32_t>();
     w.scan_part = e->scan_part.as<uint64_t>(); w.si = e->si.as<StreamInfo>();

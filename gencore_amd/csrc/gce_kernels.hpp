@@ -40,6 +40,7 @@ struct Work {
     uint32_t *cl_slot, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
     // cluster-local arrays (indexed by cl_start + k)
     uint32_t *members, *sorted, *pl, *pr, *pu, *pg, *gpl, *gpr, *grp_begin, *grp_n;
+    uint64_t *k64;                       // generic pairing scratch: 3 words per read (name window / UMI words)
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
@@ -430,6 +431,24 @@ __global__ void k_scatter(int64_t n, Work w) {
 // ===================================================================================================== pairing + UMI grouping
 __device__ __forceinline__ const char *d_qname(const DevBatch &b, uint32_t r) { return b.qname + b.qname_off[r]; }
 
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint64_t d_bswap64(uint64_t x) { return __builtin_bswap64(x); }
+// up to 8*NW bytes of a string as big-endian words, zero padded: integer order == strcmp order
+template <int NW>
+__device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (&wd)[NW]) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint64_t v = 0;
+        int rem = len - 8 * k;
+        if (rem > 0) {
+            v = *(const u64_unaligned *)(s + 8 * k);
+            if (rem < 8) v &= (1ull << (8 * rem)) - 1ull;
+            v = d_bswap64(v);
+        }
+        wd[k] = v;
+    }
+}
 // generic path: any cluster size / name length, cluster-local global scratch
 __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
@@ -441,17 +460,45 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
     }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     // ---- (a) order the cluster's reads by (qname, input index): map<string,Pair*> order + arrival order (cluster.cpp:260-273)
+    //      Rank = number of reads that sort before mine.  The names of a cluster share a long prefix (instrument, run, flowcell);
+    //      16 bytes after the cluster's common prefix, as two big-endian words per read in scratch, decide almost every
+    //      comparison in registers; equal windows (mates, near-identical names) fall back to strcmp.
+    uint64_t *kw = w.k64 + (size_t)start * 3;
+    {
+        const char *n0 = d_qname(b, w.members[start]);
+        int cp = 0x7FFFFFFF;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const char *mq = d_qname(b, w.members[start + i]);
+            int l = 0;
+            while (n0[l] && n0[l] == mq[l]) l++;
+            cp = min(cp, l);
+        }
+        cp = wave_min(cp);
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t my = w.members[start + i];
+            const int nl = (int)b.core[my].l_qname - 1;
+            uint64_t k2[2];
+            load_be_words<2>(d_qname(b, my) + cp, max(nl - cp, 0), k2);
+            kw[2 * i] = k2[0]; kw[2 * i + 1] = k2[1];
+        }
+    }
+    WAVE_SYNC();
     for (uint32_t base = 0; base < n; base += 64) {
         uint32_t i = base + lane;
         if (i < n) {
             uint32_t my = w.members[start + i];
             const char *mq = d_qname(b, my);
+            const uint64_t m0 = kw[2 * i], m1 = kw[2 * i + 1];
             uint32_t rk = 0;
             for (uint32_t j = 0; j < n; j++) {
-                uint32_t o = w.members[start + j];
-                if (o == my) continue;
-                int cmp = d_strcmp(d_qname(b, o), mq);
-                if (cmp < 0 || (cmp == 0 && o < my)) rk++;
+                const uint64_t o0 = kw[2 * j], o1 = kw[2 * j + 1];
+                bool lt = o0 < m0 || (o0 == m0 && o1 < m1);
+                if (o0 == m0 && o1 == m1 && j != i) {
+                    const uint32_t o = w.members[start + j];
+                    const int cmp = d_strcmp(d_qname(b, o), mq);
+                    lt = cmp < 0 || (cmp == 0 && o < my);
+                }
+                rk += lt;
             }
             w.sorted[start + rk] = my;
         }
@@ -492,10 +539,25 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
         ngroups = 1;
     } else {
         uint32_t *pc = w.sorted;                 // reuse: per-pair count of identical UMIs (umiCount)
+        // UMIs of <= 24 bytes as three zero-padded words per pair in scratch: equal words <=> equal strings
+        bool longu = false;
+        for (uint32_t i = lane; i < npairs; i += 64) {
+            const uint32_t ui = w.pu[start + i]; const int ul = w.umi_len[ui];
+            uint64_t u3[3];
+            load_be_words<3>(w.umi_ptr[ui], min(ul, 24), u3);
+            kw[3 * i] = u3[0]; kw[3 * i + 1] = u3[1]; kw[3 * i + 2] = u3[2];
+            if (ul > 24) longu = true;
+        }
+        longu = __any(longu);
+        WAVE_SYNC();
         for (uint32_t i = lane; i < npairs; i += 64) {
             uint32_t ui = w.pu[start + i];
             const char *up = w.umi_ptr[ui]; int ul = w.umi_len[ui];
             uint32_t cnt = 0;
+            if (!longu) {
+                const uint64_t a0 = kw[3 * i], a1 = kw[3 * i + 1], a2 = kw[3 * i + 2];
+                for (uint32_t j = 0; j < npairs; j++) cnt += (kw[3 * j] == a0 && kw[3 * j + 1] == a1 && kw[3 * j + 2] == a2);
+            } else
             for (uint32_t j = 0; j < npairs; j++) { uint32_t uj = w.pu[start + j]; cnt += d_bytes_equal(up, ul, w.umi_ptr[uj], w.umi_len[uj]); }
             pc[start + i] = cnt;
             w.pg[start + i] = NONE32;
@@ -567,24 +629,6 @@ __global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, W
     }
 }
 
-typedef uint64_t u64_unaligned __attribute__((aligned(1)));
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-__device__ __forceinline__ uint64_t d_bswap64(uint64_t x) { return __builtin_bswap64(x); }
-// up to 8*NW bytes of a string as big-endian words, zero padded: integer order == strcmp order
-template <int NW>
-__device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (&wd)[NW]) {
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        uint64_t v = 0;
-        int rem = len - 8 * k;
-        if (rem > 0) {
-            v = *(const u64_unaligned *)(s + 8 * k);
-            if (rem < 8) v &= (1ull << (8 * rem)) - 1ull;
-            v = d_bswap64(v);
-        }
-        wd[k] = v;
-    }
-}
 __device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
     x |= x >> 4; x |= x >> 2; x |= x >> 1;
     return __popcll(x & 0x0101010101010101ull);
