@@ -484,22 +484,27 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
     }
     WAVE_SYNC();
     for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t i = base + lane;
-        if (i < n) {
-            uint32_t my = w.members[start + i];
-            const char *mq = d_qname(b, my);
-            const uint64_t m0 = kw[2 * i], m1 = kw[2 * i + 1];
-            uint32_t rk = 0;
-            for (uint32_t j = 0; j < n; j++) {
-                const uint64_t o0 = kw[2 * j], o1 = kw[2 * j + 1];
-                bool lt = o0 < m0 || (o0 == m0 && o1 < m1);
-                if (o0 == m0 && o1 == m1 && j != i) {
-                    const uint32_t o = w.members[start + j];
-                    const int cmp = d_strcmp(d_qname(b, o), mq);
-                    lt = cmp < 0 || (cmp == 0 && o < my);
-                }
-                rk += lt;
+        const uint32_t i = base + lane;
+        const bool mine = i < n;
+        const uint32_t my = mine ? w.members[start + i] : NONE32;
+        const char *mq = mine ? d_qname(b, my) : nullptr;
+        const uint64_t m0 = mine ? kw[2 * i] : 0ull, m1 = mine ? kw[2 * i + 1] : 0ull;
+        uint32_t rk = 0, ntie = 0, t1 = 0, t2 = 0;                           // equal windows (the mate, as a rule) are settled after the scan,
+        for (uint32_t jb = 0; jb < n; jb += 64) {                             // every lane on its own: 64 windows per memory round trip, then
+            const uint32_t jj = jb + lane;                                    // register broadcasts
+            const uint64_t c0 = jj < n ? kw[2 * jj] : 0ull, c1 = jj < n ? kw[2 * jj + 1] : 0ull;
+            const int lim = (int)min(64u, n - jb);
+            for (int t = 0; t < lim; t++) {
+                const uint64_t o0 = rl64(c0, t), o1 = rl64(c1, t);
+                const uint32_t j = jb + t;
+                rk += (o0 < m0 || (o0 == m0 && o1 < m1));
+                if (o0 == m0 && o1 == m1 && j != i) { if (ntie == 0) t1 = j; else if (ntie == 1) t2 = j; ntie++; }
             }
+        }
+        if (mine) {
+            auto before = [&](uint32_t j) { const uint32_t o = w.members[start + j]; const int cmp = d_strcmp(d_qname(b, o), mq); return cmp < 0 || (cmp == 0 && o < my); };
+            if (ntie <= 2) { if (ntie >= 1) rk += before(t1); if (ntie == 2) rk += before(t2); }
+            else for (uint32_t j = 0; j < n; j++) if (j != i && kw[2 * j] == m0 && kw[2 * j + 1] == m1) rk += before(j);
             w.sorted[start + rk] = my;
         }
     }
@@ -556,7 +561,12 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
             uint32_t cnt = 0;
             if (!longu) {
                 const uint64_t a0 = kw[3 * i], a1 = kw[3 * i + 1], a2 = kw[3 * i + 2];
-                for (uint32_t j = 0; j < npairs; j++) cnt += (kw[3 * j] == a0 && kw[3 * j + 1] == a1 && kw[3 * j + 2] == a2);
+                for (uint32_t j = 0; j + 3 < npairs; j += 4) {                    // four independent loads in flight per step
+                    const uint64_t x0 = kw[3 * j], x1 = kw[3 * j + 1], x2 = kw[3 * j + 2], y0 = kw[3 * j + 3], y1 = kw[3 * j + 4], y2 = kw[3 * j + 5];
+                    const uint64_t z0 = kw[3 * j + 6], z1 = kw[3 * j + 7], z2 = kw[3 * j + 8], v0 = kw[3 * j + 9], v1 = kw[3 * j + 10], v2 = kw[3 * j + 11];
+                    cnt += (x0 == a0 && x1 == a1 && x2 == a2) + (y0 == a0 && y1 == a1 && y2 == a2) + (z0 == a0 && z1 == a1 && z2 == a2) + (v0 == a0 && v1 == a1 && v2 == a2);
+                }
+                for (uint32_t j = npairs & ~3u; j < npairs; j++) cnt += (kw[3 * j] == a0 && kw[3 * j + 1] == a1 && kw[3 * j + 2] == a2);
             } else
             for (uint32_t j = 0; j < npairs; j++) { uint32_t uj = w.pu[start + j]; cnt += d_bytes_equal(up, ul, w.umi_ptr[uj], w.umi_len[uj]); }
             pc[start + i] = cnt;
