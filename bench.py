@@ -160,12 +160,24 @@ def main():
         v["frac"] = v["achieved_gbs"] / HBM_PEAK_GBS
     phase_ms = {k: avg[k] for k in ("prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "total_ms")}
     dom = "consensus" if kernels["consensus"]["ms"] >= kernels["cluster"]["ms"] else "cluster"
+    # HBM traffic of the dominant phase from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    # same command: profiles/hbm_traffic.json, tools/hbm_summary.py): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950.  Quoted only for the workload it was measured on; PMC counters cannot be read inside this process.
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tj) and args.workload == "cfg3" and args.pairs is None:
+        kk = json.load(open(tj))["kernels"]
+        names = {"consensus": ("k_score", "k_consensus_lean2", "k_consensus_lean", "k_consensus_fast", "k_consensus_slow"), "cluster": ("k_cluster",)}
+        def tr(ns):
+            return sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in ns if n in kk)
+        traffic = {k: tr(v) for k, v in names.items()}
     roofline = dict(bound="hbm", kernel={"consensus": "k_score+k_consensus (Pair::computeScore + Group::makeConsensus)",
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(kernels[dom]["frac"], 5), traffic=None,
+                    frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
                     clustering_scan=dict(achieved=round(kernels["cluster"]["achieved_gbs"], 2), frac=round(kernels["cluster"]["frac"], 5),
-                                         ms=round(kernels["cluster"]["ms"], 4)),
+                                         ms=round(kernels["cluster"]["ms"], 4), algorithmic_bytes=round(cluster_bytes),
+                                         traffic=(round(traffic["cluster"]) if traffic else None)),
                     phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3))
 
     # ------------------------------------------------------------------ CPU baseline: the oracle port, 1 thread, bounded sample

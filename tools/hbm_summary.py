@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Summarise the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of tools/profile_round.sh
+into profiles/<tag>_hbm_traffic.csv and profiles/hbm_traffic.json (the per-launch figures bench.py quotes in roofline.traffic).
+    python tools/hbm_summary.py gpurun_out/r01g profiles/r01_g "<command note>"
+Counter units: KB per dispatch as reported by rocprofv3.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of
+wide coalesced reads (the x2 column); WRITE_SIZE and narrow access widths are uncalibrated, so both columns are given."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d):
+    acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):
+                k = k[5:]
+            if not k.startswith("k_"):
+                continue
+            acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return {k: (acc[k] / cnt[k], cnt[k]) for k in acc}
+
+
+def main():
+    src, dst, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+    fe, wr = per_kernel(src + "_pmc_FETCH_SIZE"), per_kernel(src + "_pmc_WRITE_SIZE")
+    rows = sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, (0, 0))[0] + wr.get(k, (0, 0))[0]))
+    with open(dst + "_hbm_traffic.csv", "w") as f:
+        f.write("# HBM traffic per dispatch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only)\n")
+        f.write("# %s\n" % note)
+        f.write("# fetch_x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md); WRITE_SIZE and narrow reads are uncalibrated\n")
+        f.write("kernel,dispatches,fetch_MB,fetch_MB_x2,write_MB\n")
+        for k in rows:
+            f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, fe.get(k, (0, 0))[1] or wr.get(k, (0, 0))[1], fe.get(k, (0, 0))[0] / 1e3, 2 * fe.get(k, (0, 0))[0] / 1e3, wr.get(k, (0, 0))[0] / 1e3))
+    js = {k: {"fetch_bytes": fe.get(k, (0, 0))[0] * 1e3, "fetch_bytes_x2": 2e3 * fe.get(k, (0, 0))[0], "write_bytes": wr.get(k, (0, 0))[0] * 1e3} for k in rows}
+    json.dump({"note": note, "kernels": js}, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)
+    print(open(dst + "_hbm_traffic.csv").read())
+
+
+if __name__ == "__main__":
+    main()
