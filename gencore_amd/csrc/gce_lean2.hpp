@@ -6,8 +6,9 @@
 // voter list, masks, loop bounds) becomes half-uniform: kept in VGPRs, broadcast inside a half with ds_bpermute, and every
 // loop runs to the larger of the two halves' trip counts under per-lane predicates.
 //
-// Scope = the lean case of gce_kernels.hpp: <= 32 pairs, every read of a side carries the same single-M CIGAR and length
-// (right side: equal positions as well, i.e. leftReadMode), packed-byte vote applicable.  A side that does not qualify is
+// Scope: <= 32 pairs; the side's reads are one class with the same single-M CIGAR and length, plus at most a minority of reads
+// that are provably unrelated to it (a soft clip or indel: see the classification below); right side: equal positions, i.e.
+// leftReadMode; packed-byte vote applicable.  A side that does not qualify is
 // flagged for the full per-side kernel; the other half carries on.
 //
 // One lane = 8 consecutive columns = 4 packed-base bytes + 8 quals + 8 scores (32 lanes x 8 = 256 columns).
@@ -81,14 +82,23 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     const uint32_t hm = half_ballot(has, h);                                  // the reads of my side
     bool done = hm == 0;                                                      // nothing (more) to do for this half
     uint32_t result = NONE32; bool write_result = true;                       // what lane 0 of the half stores into rp_left / rp_right
-    const int fl = hb + (hm ? __ffs((int)hm) - 1 : 0);                        // first read present = the template of a uniform side
+    // The side's majority class = CIGAR and length of its first single-M read.  group.cpp:177-261 collapse to "containedBy = class
+    // size for the class, template = its first read in qname order, voters = the class" when
+    //   - every other read is provably unrelated to the class: it has >= 2 CIGAR ops (so it is part of no class read) and its first
+    //     op is not an M block of >= len bases (so no class read is part of it; lean sides are always in leftReadMode) -- a soft
+    //     clip or an indel among "150M" reads, typically -- and there are fewer of them than class reads (containedBy <= their
+    //     number), and
+    //   - right side: all positions are equal (leftReadMode, group.cpp:177-194).
+    const uint32_t single = half_ballot(has && nc == 1 && cig_op(c0) == 0, h);
+    const int fl = hb + (single ? __ffs((int)single) - 1 : 0);                // the template
     const uint32_t o_c0 = (uint32_t)__shfl((int)c0, fl); const int len = __shfl(lq, fl), o_pos = __shfl(pos, fl);
-    // uniform side: one single-M CIGAR, one length (and, right side, one position: leftReadMode), group.cpp:177-261 collapse to
-    // containedBy = #reads for every read and template = first read in qname order
-    const bool nonuni = has && (nc != 1 || c0 != o_c0 || lq != len || (h == 1 && pos != o_pos));
-    const int nvot = __popc(hm);
+    const bool major = has && nc == 1 && c0 == o_c0 && lq == len;
+    const uint32_t vm = half_ballot(major, h);                                // the voters
+    const bool unfit = has && ((!major && (nc < 2 || (cig_op(c0) == 0 && cig_len(c0) >= len))) || (h == 1 && pos != o_pos));
+    const int nvot = __popc(vm);
     const int accept_score = max(p.base_score_req, 1);
-    bool to_gen = !done && (half_ballot(nonuni, h) != 0 || cig_op(o_c0) != 0 || len > 256 || !p.q2s_swar_ok ||
+    const uint32_t unfit_m = half_ballot(unfit, h);
+    bool to_gen = !done && (single == 0 || unfit_m != 0 || nvot <= __popc(hm) - nvot || len > 256 || !p.q2s_swar_ok ||
                             nvot * (p.score_max + p.score_bias) > 255 || accept_score + nvot * p.score_bias > 255);
     if (to_gen) {
         if (hl == 0) w.gen_flag[gi * 2 + h] = 1;                               // (a flag, compacted afterwards: one shared counter would serialise)
@@ -120,7 +130,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     uint16_t *cplx = (uint16_t *)(sh + 512);
     uint32_t *tl = (uint32_t *)(sh + 1024);                                   // [16 columns][5 bins][cnt, score, qualsum, topqual]
     uint8_t *vlist = sh + 1024 + 16 * 5 * 16;                                 // voter lanes (absolute) in ascending order
-    if (has) vlist[__popc(hm & ((1u << hl) - 1u))] = (uint8_t)lane;
+    if (major) vlist[__popc(vm & ((1u << hl) - 1u))] = (uint8_t)lane;
     const int nv_max = max(__builtin_amdgcn_readlane(done ? 0 : nvot, 0), __builtin_amdgcn_readlane(done ? 0 : nvot, 32));
     WAVE_SYNC();
     // ---- pass A: every column.  Early accept (group.cpp:421-428) for a column whose voters all show the template's A/C/G/T/N
