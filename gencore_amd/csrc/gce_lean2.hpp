@@ -7,8 +7,8 @@
 // loop runs to the larger of the two halves' trip counts under per-lane predicates.
 //
 // Scope: <= 32 pairs; the side's reads are one class with the same single-M CIGAR and length, plus at most a minority of reads
-// that are provably unrelated to it (a soft clip or indel: see the classification below); right side: equal positions, i.e.
-// leftReadMode; packed-byte vote applicable.  A side that does not qualify is
+// that are provably unrelated to it (a soft clip or indel: see the classification below) -- or one class with the same 2-/3-op
+// CIGAR and nothing else; right side: equal positions, i.e. leftReadMode; packed-byte vote applicable.  A side that does not qualify is
 // flagged for the full per-side kernel; the other half carries on.
 //
 // One lane = 8 consecutive columns = 4 packed-base bytes + 8 quals + 8 scores (32 lanes x 8 = 256 columns).
@@ -90,15 +90,21 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     //     number), and
     //   - right side: all positions are equal (leftReadMode, group.cpp:177-194).
     const uint32_t single = half_ballot(has && nc == 1 && cig_op(c0) == 0, h);
-    const int fl = hb + (single ? __ffs((int)single) - 1 : 0);                // the template
-    const uint32_t o_c0 = (uint32_t)__shfl((int)c0, fl); const int len = __shfl(lq, fl), o_pos = __shfl(pos, fl);
-    const bool major = has && nc == 1 && c0 == o_c0 && lq == len;
+    // No single-M read at all: the side may still be one class with a 2- or 3-op CIGAR (all duplicates of a molecule carry its
+    // soft clip or indel).  Then every read must belong to the class; the remaining CIGAR words are fetched for the comparison.
+    const bool multi = single == 0;
+    uint32_t cw1 = 0, cw2 = 0;
+    if (has && multi && nc >= 2 && nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[rd]; cw1 = cg[1]; if (nc == 3) cw2 = cg[2]; }
+    const int fl = hb + (multi ? (hm ? __ffs((int)hm) - 1 : 0) : __ffs((int)single) - 1);             // the template
+    const uint32_t o_c0 = (uint32_t)__shfl((int)c0, fl), o_cw1 = (uint32_t)__shfl((int)cw1, fl), o_cw2 = (uint32_t)__shfl((int)cw2, fl);
+    const int len = __shfl(lq, fl), o_pos = __shfl(pos, fl), o_nc = __shfl(nc, fl);
+    const bool major = has && nc == o_nc && c0 == o_c0 && cw1 == o_cw1 && cw2 == o_cw2 && lq == len;
     const uint32_t vm = half_ballot(major, h);                                // the voters
-    const bool unfit = has && ((!major && (nc < 2 || (cig_op(c0) == 0 && cig_len(c0) >= len))) || (h == 1 && pos != o_pos));
+    const bool unfit = has && ((!major && (multi || nc < 2 || (cig_op(c0) == 0 && cig_len(c0) >= len))) || (h == 1 && pos != o_pos) || o_nc > 3 || o_nc < 1);
     const int nvot = __popc(vm);
     const int accept_score = max(p.base_score_req, 1);
     const uint32_t unfit_m = half_ballot(unfit, h);
-    bool to_gen = !done && (single == 0 || unfit_m != 0 || nvot <= __popc(hm) - nvot || len > 256 || !p.q2s_swar_ok ||
+    bool to_gen = !done && (unfit_m != 0 || nvot <= __popc(hm) - nvot || len > 256 || !p.q2s_swar_ok ||
                             nvot * (p.score_max + p.score_bias) > 255 || accept_score + nvot * p.score_bias > 255);
     if (to_gen) {
         if (hl == 0) w.gen_flag[gi * 2 + h] = 1;                               // (a flag, compacted afterwards: one shared counter would serialise)
@@ -120,7 +126,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
         const int o_tid = o_t16 != 0xFFFF ? o_t16 : b.core[out].tid;
         if (o_isz != 0 && o_tid >= 0 && o_tid < p.n_ref) {                    // group.cpp:362-367 -> Reference::getData
             const uint8_t *rdp = p.ref_data[o_tid];
-            const int64_t need_len = (int64_t)((len - 1) < cig_len(o_c0) ? (len - 1) : -1) + 1;
+            const int64_t need_len = (int64_t)(o_nc == 1 ? ((len - 1) < cig_len(o_c0) ? (len - 1) : -1) : d_ref_offset(b.cigar + b.cigar_off[out], o_nc, len - 1)) + 1;
             if (rdp && (int64_t)o_pos + need_len < p.ref_len[o_tid]) { ref = rdp; ref_len = p.ref_len[o_tid]; }
         }
     }
@@ -207,7 +213,9 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             int ref4 = 0;                                                     // requested before the voters' bytes: both in flight together
             if (ref && hl < ncol) {
                 const int col = cplx[cbase + hl];
-                if (col < cig_len(o_c0) && (int64_t)o_pos + col < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + col);
+                // (a 2-/3-op class walks its CIGAR from memory: rare, and it keeps two registers free for everyone else)
+                const int ro = o_nc == 1 ? (col < cig_len(o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[out], o_nc, col);
+                if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro);
             }
             const int items = ncol * nvot;
             const int it_max = max(__builtin_amdgcn_readlane(items, 0), __builtin_amdgcn_readlane(items, 32));
