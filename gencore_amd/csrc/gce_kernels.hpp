@@ -668,24 +668,35 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
     uint64_t nw[8];
     load_be_words<8>(nm, act ? nl : 0, nw);
     const int nwords = (wave_max(nl) + 7) >> 3;
-    // ---- same-name detection through a 64-bit hash of the name words (verified exactly below), LOW = smaller input index
-    uint64_t hsh = 0x9E3779B97F4A7C15ull;
+    // ---- same-name detection through a 32-bit add-rotate-xor hash of the name words.  It is only a filter: every match is verified
+    //      word by word below, and a false match sends the cluster to the generic kernel.  EQ = the other reads of my name (one
+    //      ballot per read gives a whole name class at once), LOW = those of them that arrived earlier (smaller input index).
+    uint32_t h32 = 0x9E3779B9u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) if (k < nwords) { hsh ^= nw[k]; hsh *= 0xFF51AFD7ED558CCDull; hsh ^= hsh >> 29; }
+    for (int k = 0; k < 8; k++) if (k < nwords) {
+        const uint32_t lo = (uint32_t)nw[k], hi = (uint32_t)(nw[k] >> 32);
+        h32 = (__builtin_rotateleft32(h32, 5) ^ lo) + hi;
+        h32 = __builtin_rotateleft32(h32, 11) ^ (hi + 0x7F4A7C15u);
+    }
+    h32 ^= h32 >> 15;
+    const unsigned long long ACT = __ballot(act);
     unsigned long long EQ = 0, LOW = 0;
     for (int j = 0; j < (int)n; j++) {
-        const uint64_t oh = rl64(hsh, j);
-        const uint32_t oj = (uint32_t)rl32((int)my, j);
-        if (oh == hsh && j != lane) EQ |= 1ull << j;
-        if (oj < my) LOW |= 1ull << j;
+        const uint32_t oh = (uint32_t)rl32((int)h32, j);
+        const unsigned long long cls = __ballot(h32 == oh) & ACT;
+        if (h32 == oh) EQ = cls;
     }
-    {   // exact verification of every hash match (all lanes run the shuffles); a false match sends the cluster to the generic kernel
+    EQ &= ~(1ull << lane);
+    {   // exact verification of every hash match (all lanes run the shuffles)
         bool bad = false;
         const int rounds = wave_max(act ? __popcll(EQ) : 0);
-        unsigned long long rest = EQ;
+        unsigned long long rest = act ? EQ : 0ull;
         for (int r = 0; r < rounds; r++) {
-            const int src = rest ? __ffsll((long long)rest) - 1 : lane;
+            const bool has = rest != 0;
+            const int src = has ? __ffsll((long long)rest) - 1 : lane;
             rest &= rest - 1;
+            const uint32_t oj = (uint32_t)__shfl((int)my, src);
+            if (has && oj < my) LOW |= 1ull << src;
 #pragma unroll
             for (int k = 0; k < 8; k++) if (k < nwords) { const uint64_t o = (uint64_t)__shfl((long long)nw[k], src); if (o != nw[k]) bad = true; }
         }
