@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t accept4(const DevParams &p, uint32_t t16, ui
     return ~(ge_q & ge_s & ~differ & valid) & bmask & 0x80808080u;
 }
 
-#define L2_HALF_BYTES 2336      // per half: new base [256], new qual [256], contested columns u16[256], tallies [16][5][4] u32, voter lanes [32]
+#define L2_HALF_BYTES 2368      // per half: new base [256], new qual [256], contested columns u16[256], tallies [16][5][4] u32, voter lanes [32], {reference pointer, length, template pos / first CIGAR word / op count}
 
 __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, uint8_t *s_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
@@ -119,10 +119,10 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
         return;
     }
     const int nbytes = (len + 1) >> 1;
-    int o_nm_type = 0, o_nm = 0;
+    uint8_t *sh = s_wave + h * L2_HALF_BYTES;
+    unsigned long long *refslot = (unsigned long long *)(sh + 2336);          // {reference pointer, length}: parked in LDS until pass B
     const uint8_t *ref = nullptr; int64_t ref_len = 0;
     if (!done) {
-        o_nm_type = b.nm_type[out]; o_nm = b.nm[out];                         // group.cpp:528-573, used at the very end
         const int o_tid = o_t16 != 0xFFFF ? o_t16 : b.core[out].tid;
         if (o_isz != 0 && o_tid >= 0 && o_tid < p.n_ref) {                    // group.cpp:362-367 -> Reference::getData
             const uint8_t *rdp = p.ref_data[o_tid];
@@ -130,8 +130,8 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             if (rdp && (int64_t)o_pos + need_len < p.ref_len[o_tid]) { ref = rdp; ref_len = p.ref_len[o_tid]; }
         }
     }
+    if (hl == 0) { refslot[0] = (unsigned long long)ref; refslot[1] = (unsigned long long)ref_len; ((int *)refslot)[4] = o_pos; ((uint32_t *)refslot)[5] = o_c0; ((int *)refslot)[6] = o_nc; }
     uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
-    uint8_t *sh = s_wave + h * L2_HALF_BYTES;
     uint8_t *resb = sh, *resq = sh + 256;
     uint16_t *cplx = (uint16_t *)(sh + 512);
     uint32_t *tl = (uint32_t *)(sh + 1024);                                   // [16 columns][5 bins][cnt, score, qualsum, topqual]
@@ -211,6 +211,8 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             for (int k = hl; k < 16 * 5; k += 32) *(uint4 *)(tl + 4 * k) = make_uint4(0, 0, 0, 0);
             WAVE_SYNC();
             int ref4 = 0;                                                     // requested before the voters' bytes: both in flight together
+            const uint8_t *ref = (const uint8_t *)refslot[0]; const int64_t ref_len = (int64_t)refslot[1];
+            const int o_pos = ((const int *)refslot)[4], o_nc = ((const int *)refslot)[6]; const uint32_t o_c0 = ((const uint32_t *)refslot)[5];
             if (ref && hl < ncol) {
                 const int col = cplx[cbase + hl];
                 // (a 2-/3-op class walks its CIGAR from memory: rare, and it keeps two registers free for everyone else)
@@ -262,6 +264,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     if (!done) {
         bool restore = false;
         if (minc != 0) {                                                      // group.cpp:528-573
+            const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
             if (o_nm_type == 0) { if (hl == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
             else if (minc > 5) restore = true;
             else if (hl == 0) { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
