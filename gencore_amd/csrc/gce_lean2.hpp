@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t accept4(const DevParams &p, uint32_t t16, ui
     return ~(ge_q & ge_s & ~differ & valid) & bmask & 0x80808080u;
 }
 
-#define L2_HALF_BYTES 2368      // per half: new base [256], new qual [256], contested columns u16[256], tallies [16][5][4] u32, voter lanes [32], {reference pointer, length, template pos / first CIGAR word / op count}
+#define L2_HALF_BYTES 2400      // per half: new base [256], new qual [256], contested columns u16[256], tallies [16][5][4] u32, voter lanes [32], {reference pointer, length, template pos / first CIGAR word / op count}
 
 __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, uint8_t *s_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
@@ -131,7 +131,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
         }
     }
     if (hl == 0) { refslot[0] = (unsigned long long)ref; refslot[1] = (unsigned long long)ref_len; ((int *)refslot)[4] = o_pos; ((uint32_t *)refslot)[5] = o_c0; ((int *)refslot)[6] = o_nc; }
-    uint8_t *oseq = b.seq + o_so, *oqual = b.qual + o_qo;
+    if (hl == 0) { refslot[4] = o_so; refslot[5] = o_qo; ((uint32_t *)refslot)[7] = out; }       // template offsets + read: reloaded for the write-back
     uint8_t *resb = sh, *resq = sh + 256;
     uint16_t *cplx = (uint16_t *)(sh + 512);
     uint32_t *tl = (uint32_t *)(sh + 1024);                                   // [16 columns][5 bins][cnt, score, qualsum, topqual]
@@ -147,7 +147,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     const uint32_t nmask = nval >= 8 ? 0xFFFFFFFFu : (((1u << (8 * (nval >> 1))) - 1u) | ((nval & 1) ? (0xF0u << (8 * (nval >> 1))) : 0u));
     const uint32_t bm_lo = byte_range4(0, nval), bm_hi = byte_range4(0, nval - 4);
     uint32_t t32 = 0;
-    if (act) t32 = *(const u32_unaligned *)(oseq + 4 * hl);
+    if (act) t32 = *(const u32_unaligned *)(b.seq + o_so + 4 * hl);
     uint32_t dacc = 0, ss_lo = 0, ss_hi = 0, tq_lo = 0, tq_hi = 0, qor = 0;
     const int s_min = min(min(p.s_high, p.s_moderate), min(p.s_low, p.s_bad));
     const bool lower_bound_ok = nvot * s_min >= accept_score;                 // heuristic only: any lower bound keeps the result exact
@@ -216,7 +216,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             if (ref && hl < ncol) {
                 const int col = cplx[cbase + hl];
                 // (a 2-/3-op class walks its CIGAR from memory: rare, and it keeps two registers free for everyone else)
-                const int ro = o_nc == 1 ? (col < cig_len(o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[out], o_nc, col);
+                const int ro = o_nc == 1 ? (col < cig_len(o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[((const uint32_t *)refslot)[7]], o_nc, col);
                 if (ro >= 0 && (int64_t)o_pos + ro < ref_len) ref4 = d_ref_nib(ref, (int64_t)o_pos + ro);
             }
             const int items = ncol * nvot;
@@ -262,6 +262,8 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     }
     minc = half_sum(done ? 0 : minc);
     if (!done) {
+        const uint32_t out = ((const uint32_t *)refslot)[7];
+        uint8_t *oseq = b.seq + refslot[4], *oqual = b.qual + refslot[5];
         bool restore = false;
         if (minc != 0) {                                                      // group.cpp:528-573
             const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
