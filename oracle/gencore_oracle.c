@@ -3,8 +3,10 @@
  * OpenGene/gencore v0.17.2 (reference tree /root/reference, read-only).
  *
  * TEST INFRASTRUCTURE ONLY (see gencore_oracle.h).  PARITY PINNING: get_umi / umi_diff / is_duplex are pinned by
- * the reference's own known-answer vectors; everything else is "parity unpinned" (the reference cannot be built
- * here: it needs htslib, which is absent, and stand-in headers are not allowed).
+ * the reference's own known-answer vectors, and is_duplex additionally against the reference's own tokenizer
+ * (src/util.h is the one file of the path that compiles without htslib: oracle/ref_probe -> oracle/_ref/libref_util.so);
+ * everything else is "parity unpinned" (the reference cannot be built here: it needs htslib, which is absent, and
+ * stand-in headers are not allowed).
  *
  * The stream driver below SIMULATES the reference literally — a pending-cluster set, a tick counter, a flush
  * walk every `flush_period` clustered reads — rather than using the closed form the HIP engine uses for the

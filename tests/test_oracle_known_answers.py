@@ -93,3 +93,32 @@ def test_reference_packing_matches_fastareader_layout(oracle):
     # FastaReader::to4bits: A=1,T=2,C=3,G=4, other=0; LOW nibble = even position (src/fastareader.cpp:106-113,139-152)
     got = oracle.pack_reference("ATCGN")
     assert got.tolist() == [1 | (2 << 4), 3 | (4 << 4), 0]
+
+
+def test_is_duplex_against_the_reference_tokenizer(oracle):
+    """The one reference file on the path that compiles without htslib is src/util.h; oracle/ref_probe builds its `split`
+    (the tokenizer behind Cluster::isDuplex, cluster.cpp:246-258) from the reference source in place into
+    oracle/_ref/libref_util.so.  The oracle's restatement must agree with it on every UMI shape, including the odd ones
+    (leading / trailing / doubled underscores, empty strings)."""
+    import ctypes as C
+    import itertools
+    import os
+    import random
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_util.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_util.so not built (needs /root/reference at build time)")
+    ref = C.CDLL(so)
+    ref.ref_is_duplex.argtypes = [C.c_char_p, C.c_char_p]
+    ref.ref_split.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(256)
+    assert ref.ref_split(b"_A__B_", b"_", buf, 256) == 4 and buf.value == b"A\n\nB\n"      # leading sep skipped, trailing one adds ""
+    alphabet = ["", "A", "AC", "_", "__", "A_", "_A", "A_C", "AC_GT", "GT_AC", "A__C", "_A_C", "A_C_", "A_C_G", "ACGT_TTGA", "TTGA_ACGT"]
+    cases = list(itertools.product(alphabet, alphabet))
+    rng = random.Random(7)
+    for _ in range(3000):
+        mk = lambda: "".join(rng.choice("ACGT_") for _ in range(rng.randint(0, 9)))
+        a = mk()
+        b = mk() if rng.random() < 0.5 else "_".join(reversed(a.split("_")))
+        cases.append((a, b))
+    for a, b in cases:
+        assert oracle.is_duplex(a, b) == bool(ref.ref_is_duplex(a.encode(), b.encode())), (a, b)
