@@ -896,30 +896,42 @@ struct VoteCtx {
 struct ColResult { int base, qual, new_base_written, minc, diff; };
 
 // One column of Group::makeConsensus (group.cpp:369-526) for column `col` of the template.
-__device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base, int lane) {
+__device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base, int lane, bool active = true) {
     const DevBatch &b = *v.b; const DevParams &p = *v.p; const Work &w = *v.w;
     uint32_t *t = v.tally + lane;
 #pragma unroll
     for (int k = 0; k < 48; k++) t[k * 64] = 0;
     int total = 0;
-    for (uint32_t q = 0; q < v.nv; q++) {
-        uint32_t r = v.voters[v.vbase + q];              // voter list (scratch)
-        int ld = (int)v.vld[v.vbase + q];
-        int rl = b.core[r].l_qseq;
-        int rp = v.left_mode ? col : col + ld;
-        if (rp < 0 || rp >= rl) continue;                // out of range is UB in the reference; skipped (same as oracle)
-        uint64_t qo = b.qual_off[r];
-        int base = d_nib(b.seq + b.seq_off[r], rp);
-        int qu = b.qual[qo + rp];
-        int sc = d_score_at(p, w.score + qo, w.spatch[r], rp, qu);
-        uint32_t t0 = t[(base * 3) * 64];
-        uint32_t cnt = (t0 & 0xFFFF) + 1, tq = t0 >> 16;
-        if ((uint32_t)qu > tq) tq = qu;
-        t[(base * 3) * 64] = cnt | (tq << 16);
-        t[(base * 3 + 1) * 64] += (uint32_t)sc;
-        t[(base * 3 + 2) * 64] += (uint32_t)qu;
-        total += sc;
+    // voters in chunks of 64: every lane fetches one voter's offsets / length / patch (the dependent part of the chain, once per
+    // chunk), the inner loop broadcasts them from registers, so a voter costs one round trip for its bytes instead of three.
+    // (This function is called from wave-uniform code only: all lanes run the broadcasts.)
+    for (uint32_t qb = 0; qb < v.nv; qb += 64) {
+        const uint32_t qq = qb + (uint32_t)lane;
+        uint64_t m_so = 0, m_qo = 0; int m_rl = 0, m_ld = 0; uint32_t m_patch = 0;
+        if (qq < v.nv) {
+            const uint32_t r = v.voters[v.vbase + qq];
+            m_ld = (int)v.vld[v.vbase + qq]; m_rl = b.core[r].l_qseq; m_so = b.seq_off[r]; m_qo = b.qual_off[r]; m_patch = w.spatch[r];
+        }
+        const int lim = (int)min(64u, v.nv - qb);
+        for (int tq_ = 0; tq_ < lim; tq_++) {
+            const uint64_t so = rl64(m_so, tq_), qo = rl64(m_qo, tq_);
+            const int rl = rl32(m_rl, tq_), ld = rl32(m_ld, tq_); const uint32_t patch = (uint32_t)rl32((int)m_patch, tq_);
+            const int rp = v.left_mode ? col : col + ld;
+            if (active && rp >= 0 && rp < rl) {                 // out of range is UB in the reference; skipped (same as oracle)
+                int base = d_nib(b.seq + so, rp);
+                int qu = b.qual[qo + rp];
+                int sc = d_score_at(p, w.score + qo, patch, rp, qu);
+                uint32_t t0 = t[(base * 3) * 64];
+                uint32_t cnt = (t0 & 0xFFFF) + 1, tq = t0 >> 16;
+                if ((uint32_t)qu > tq) tq = qu;
+                t[(base * 3) * 64] = cnt | (tq << 16);
+                t[(base * 3 + 1) * 64] += (uint32_t)sc;
+                t[(base * 3 + 2) * 64] += (uint32_t)qu;
+                total += sc;
+            }
+        }
     }
+    if (!active) { ColResult none; none.base = out_base; none.qual = 0; none.new_base_written = 0; none.minc = 0; none.diff = 0; return none; }
     // top / second base: lexicographic max of (score, sum of quals), the LATER bin wins ties (group.cpp:394-416, quirk Q6)
     int top = 0, top_s = -0x7FFFFFFF, top_q = 0;
     for (int bb = 0; bb < 16; bb++) {
@@ -1028,6 +1040,80 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
     // ---- containedBy (group.cpp:196-233)
     uint32_t *contained = is_left ? w.sorted : w.pg;
     uint32_t *voters = is_left ? w.pl : w.pu, *vld = is_left ? w.pr : w.members;
+    // Deep sides first try CLASSES: reads with the same CIGAR (and, right side, the same right end) are interchangeable for
+    // isPartOf, so containedBy(read) = sum over classes of |class| x [read is part of the class] -- O(reads x classes) on
+    // registers instead of O(reads^2) walks through memory.  One class per lane (<= 64), CIGARs of <= 4 ops; anything else
+    // takes the pairwise loop below.
+    bool classed = false;
+    if (np > 64) {
+        int c_n = 0, c_cnt = 0, c_rr = 0; uint32_t c_w0 = 0, c_w1 = 0, c_w2 = 0, c_w3 = 0;      // lane c = class c
+        int nclass = 0; bool fail = false;
+        auto load_read = [&](uint32_t k, bool &has, int &n_, int &rr_, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
+            has = false; n_ = 0; rr_ = 0; w0 = w1 = w2 = w3 = 0;
+            uint32_t rd = k < np ? side[begin + k] : NONE32;
+            if (rd == NONE32) return;
+            has = true;
+            const ReadDesc d = load_desc(w.rdesc, rd);
+            n_ = d.nc; rr_ = is_left ? 0 : d.pos + d.rlen;
+            if (n_ == 1) w0 = d.c0;
+            else if (n_ >= 2 && n_ <= 4) {                                     // oriented: i-th op from the compared end (bamutil.cpp:213-218)
+                const uint32_t *cg = b.cigar + b.cigar_off[rd];
+                w0 = left_mode ? cg[0] : cg[n_ - 1]; w1 = left_mode ? cg[1] : cg[n_ - 2];
+                if (n_ >= 3) w2 = left_mode ? cg[2] : cg[n_ - 3];
+                if (n_ >= 4) w3 = left_mode ? cg[3] : cg[0];
+            }
+        };
+        for (uint32_t base = 0; base < np && !fail; base += 64) {
+            bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
+            load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
+            if (__any(has && n_ > 4)) { fail = true; break; }
+            const unsigned long long hm = __ballot(has);
+            for (unsigned long long m = hm; m; m &= m - 1) {
+                const int t = __ffsll((long long)m) - 1;
+                const int r_n = rl32(n_, t), r_rr = rl32(rr_, t);
+                const uint32_t r0 = (uint32_t)rl32((int)w0, t), r1 = (uint32_t)rl32((int)w1, t), r2 = (uint32_t)rl32((int)w2, t), r3 = (uint32_t)rl32((int)w3, t);
+                const unsigned long long hit = __ballot(lane < nclass && c_n == r_n && c_rr == r_rr && c_w0 == r0 && c_w1 == r1 && c_w2 == r2 && c_w3 == r3);
+                if (hit) { if (lane == __ffsll((long long)hit) - 1) c_cnt++; }
+                else {
+                    if (nclass == 64) { fail = true; break; }
+                    if (lane == nclass) { c_n = r_n; c_rr = r_rr; c_w0 = r0; c_w1 = r1; c_w2 = r2; c_w3 = r3; c_cnt = 1; }
+                    nclass++;
+                }
+            }
+        }
+        if (!fail) {
+            auto part_of4 = [&](int pn, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int wn, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+                if (wn < pn) return false;                                      // BamUtil::isPartOf (bamutil.cpp:204-255) on oriented words
+                const uint32_t pw[4] = {p0, p1, p2, p3}, ww[4] = {q0, q1, q2, q3};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i < pn) {
+                        if (cig_op(pw[i]) != cig_op(ww[i])) return false;
+                        const int la = cig_len(pw[i]), lb = cig_len(ww[i]);
+                        if (la > lb) return false;
+                        if (la < lb && i != pn - 1) {
+                            if (i != pn - 2) return false;
+                            if (cig_op(pw[i + 1 < 4 ? i + 1 : 3]) != 5 /*H*/) return false;
+                        }
+                    }
+                }
+                return true;
+            };
+            for (uint32_t base = 0; base < np; base += 64) {
+                bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
+                load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
+                uint32_t cb = 0;
+                for (int cc = 0; cc < nclass; cc++) {
+                    const int q_n = rl32(c_n, cc), q_rr = rl32(c_rr, cc), q_cnt = rl32(c_cnt, cc);
+                    const uint32_t q0 = (uint32_t)rl32((int)c_w0, cc), q1 = (uint32_t)rl32((int)c_w1, cc), q2 = (uint32_t)rl32((int)c_w2, cc), q3 = (uint32_t)rl32((int)c_w3, cc);
+                    if (has && (is_left || rr_ == q_rr) && part_of4(n_, w0, w1, w2, w3, q_n, q0, q1, q2, q3)) cb += (uint32_t)q_cnt;
+                }
+                if (base + lane < np) contained[begin + base + lane] = has ? cb : 0;
+            }
+            classed = true;
+        }
+    }
+    if (!classed)
     for (uint32_t base = 0; base < np; base += 64) {
         uint32_t k = base + lane;
         if (k < np) {
@@ -1130,8 +1216,8 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
             if (it * 64 < nbytes) {           // wave-uniform
                 uint8_t ob = act0[it] ? oseq[bi] : 0;
                 int hi = ob >> 4, lo = ob & 0xF;
-                if (act0[it]) { ColResult r = vote_column(v, c0, hi, lane); hi = r.base; nq0[it] = (uint8_t)r.qual; minc += r.minc; }
-                if (act1[it]) { ColResult r = vote_column(v, c1, lo, lane); lo = r.base; nq1[it] = (uint8_t)r.qual; minc += r.minc; }
+                { ColResult r = vote_column(v, c0, hi, lane, act0[it]); if (act0[it]) { hi = r.base; nq0[it] = (uint8_t)r.qual; minc += r.minc; } }
+                { ColResult r = vote_column(v, c1, lo, lane, act1[it]); if (act1[it]) { lo = r.base; nq1[it] = (uint8_t)r.qual; minc += r.minc; } }
                 nb[it] = (uint8_t)((hi << 4) | lo);
             }
         }
@@ -1152,11 +1238,12 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         }
     } else {
         // long templates: pass 1 counts mismatchInc without writing, pass 2 recomputes and writes
-        for (int bi = lane; bi < nbytes; bi += 64) {
-            uint8_t ob = oseq[bi];
+        for (int bb = 0; bb < nbytes; bb += 64) {                             // (wave-uniform trip count: vote_column broadcasts)
+            const int bi = bb + lane; const bool in = bi < nbytes;
+            uint8_t ob = in ? oseq[bi] : 0;
             int c0 = bi * 2, c1 = c0 + 1;
-            if (c0 < len) minc += vote_column(v, c0, ob >> 4, lane).minc;
-            if (c1 < len) minc += vote_column(v, c1, ob & 0xF, lane).minc;
+            { ColResult r = vote_column(v, c0, ob >> 4, lane, in && c0 < len); if (in && c0 < len) minc += r.minc; }
+            { ColResult r = vote_column(v, c1, ob & 0xF, lane, in && c1 < len); if (in && c1 < len) minc += r.minc; }
         }
         minc = wave_sum(minc);
         bool restore = false;
@@ -1166,12 +1253,13 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
             else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
         }
         if (!restore) {
-            for (int bi = lane; bi < nbytes; bi += 64) {
-                uint8_t ob = oseq[bi];
+            for (int bb = 0; bb < nbytes; bb += 64) {
+                const int bi = bb + lane; const bool in = bi < nbytes;
+                uint8_t ob = in ? oseq[bi] : 0;
                 int c0 = bi * 2, c1 = c0 + 1, hi = ob >> 4, lo = ob & 0xF;
-                if (c0 < len) { ColResult r = vote_column(v, c0, hi, lane); hi = r.base; oqual[c0] = (uint8_t)r.qual; }
-                if (c1 < len) { ColResult r = vote_column(v, c1, lo, lane); lo = r.base; oqual[c1] = (uint8_t)r.qual; }
-                oseq[bi] = (uint8_t)((hi << 4) | lo);
+                { ColResult r = vote_column(v, c0, hi, lane, in && c0 < len); if (in && c0 < len) { hi = r.base; oqual[c0] = (uint8_t)r.qual; } }
+                { ColResult r = vote_column(v, c1, lo, lane, in && c1 < len); if (in && c1 < len) { lo = r.base; oqual[c1] = (uint8_t)r.qual; } }
+                if (in) oseq[bi] = (uint8_t)((hi << 4) | lo);
             }
         }
     }

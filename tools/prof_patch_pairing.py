@@ -10,7 +10,7 @@ def ins(before, text):
     s = s[:i] + text + s[i:]
 ins("    const uint32_t start = w.cl_start[c], n = w.cl_n[c];\n    uint64_t entry = w.table[w.cl_slot[c]];\n    uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);\n    if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }\n    const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;\n    bool defer = n > 64;", "    long long t_[10]; t_[0] = clock64();\n")
 ins("    const bool act = lane < (int)n;\n    uint64_t nw[8];", "    t_[1] = clock64();\n")
-ins("    unsigned long long EQ = 0, LOW = 0;", "    t_[2] = clock64();\n")
+ins("    const unsigned long long ACT = __ballot(act);", "    t_[2] = clock64();\n")
 ins("    {   // exact verification of every hash match", "    t_[3] = clock64();\n")
 ins("    // ---- pairs (cluster.cpp:260-273, pair.cpp:188-216): first read of a name = mLeft", "    t_[4] = clock64();\n")
 ins("    const uint32_t pidx = __popcll(LT);", "    t_[5] = clock64();\n")
