@@ -372,7 +372,9 @@ int gce_process(gce_engine *e) {
     if (C > 0 && e->h_si.error == 0) {
         HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score recognises pair slots by gpl != NONE
         hipLaunchKernelGGL(k_pairing_fast, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
-        hipLaunchKernelGGL(k_pairing_slow, dim3(2048), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
+        hipLaunchKernelGGL(k_pairing_slow<2>, dim3(1024), dim3(256), 0, s, b, p, w);
         const unsigned nblk_C = cdiv(C, SCAN_TILE);
         hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, (uint64_t)C, w.scan_part);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_C, &w.si->n_pairs /*scratch*/, &w.si->n_groups);

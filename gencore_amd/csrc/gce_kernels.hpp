@@ -450,12 +450,16 @@ __device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (
     }
 }
 // generic path: any cluster size / name length, cluster-local global scratch
-__device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
+// Three launches (PHASE 0: name windows, 1: ranks, 2: pairs + UMI grouping + layout): the rank scan is O(n^2 / 64) per cluster and
+// a cluster of thousands of reads would otherwise keep one wave busy for milliseconds; phase 1 spreads a cluster's 64-read blocks
+// over `ibstep` waves.
+template <int PHASE>
+__device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane, uint32_t ib0 = 0, uint32_t ibstep = 1) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
     uint64_t entry = w.table[w.cl_slot[c]];
     uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
     if (mode == THR_NEVER) {                      // pending after an early finishConsensus: never processed (gencore.cpp:23)
-        if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
+        if (PHASE == 2 && lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
         return;
     }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
@@ -464,7 +468,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
     //      16 bytes after the cluster's common prefix, as two big-endian words per read in scratch, decide almost every
     //      comparison in registers; equal windows (mates, near-identical names) fall back to strcmp.
     uint64_t *kw = w.k64 + (size_t)start * 3;
-    {
+    if (PHASE == 0) {
         const char *n0 = d_qname(b, w.members[start]);
         int cp = 0x7FFFFFFF;
         for (uint32_t i = lane; i < n; i += 64) {
@@ -481,9 +485,10 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
             load_be_words<2>(d_qname(b, my) + cp, max(nl - cp, 0), k2);
             kw[2 * i] = k2[0]; kw[2 * i + 1] = k2[1];
         }
+        return;
     }
-    WAVE_SYNC();
-    for (uint32_t base = 0; base < n; base += 64) {
+    if (PHASE == 1) {
+    for (uint32_t base = 64 * ib0; base < n; base += 64 * ibstep) {
         const uint32_t i = base + lane;
         const bool mine = i < n;
         const uint32_t my = mine ? w.members[start + i] : NONE32;
@@ -508,7 +513,8 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
             w.sorted[start + rk] = my;
         }
     }
-    WAVE_SYNC();
+    return;
+    }
     // ---- (b) pairs: first read of a qname run = mLeft, last of the run (if any other) = mRight (pair.cpp:188-216)
     uint32_t npairs = 0;
     int any_umi = 0;
@@ -630,11 +636,12 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
 }
 
 
+template <int PHASE>
 __global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, Work w) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n_slow = w.si->n_slow_pair;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
-        pairing_generic(b, p, w, w.slow_list[idx], lane);
+        pairing_generic<PHASE>(b, p, w, w.slow_list[idx], lane, blockIdx.y, gridDim.y);
         WAVE_SYNC();
     }
 }
