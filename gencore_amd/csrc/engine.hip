@@ -408,7 +408,9 @@ int gce_process(gce_engine *e) {
         }
         if (e->h_si.n_fb > 0 && e->h_si.error == 0) {              // global-memory path
             const uint32_t nfb = e->h_si.n_fb;
-            hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
+            static const bool score_units = !(getenv("GCE_SCORE2") && atoi(getenv("GCE_SCORE2")) == 0);        // 0: the 8-lanes-per-pair kernel
+            if (score_units) hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
+            else hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
             HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
             static const bool lean_pairs = !(getenv("GCE_LEAN2") && atoi(getenv("GCE_LEAN2")) == 0);    // 0: one wave per side instead of per group
             if (lean_pairs) hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, nfb, e->fused_groups ? 0 : 1);

@@ -891,6 +891,83 @@ __global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, 
     }
 }
 
+// Pair::computeScore, second formulation: ONE LANE PER PAIR for the dependent part (slot -> reads -> descriptors -> overlap
+// window and patch descriptors: 64 pairs share each round trip instead of 8), then the wave's overlap work is cut into units of
+// 8 bases and dealt evenly to the lanes (half of the pairs have no overlap, a few have a long one): unit -> pair through a small
+// LDS map, the pair's fields through ds_bpermute.  A unit costs one 8-byte load per array and side and one 8-byte score store
+// per side; only complete units are stored as words (the bytes behind the last overlap base belong to other patches).
+#define SC2_MAXU 1280        // >= 64 pairs x ceil(150 / 8); longer overlaps take more rounds of the unit map
+__global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
+    __shared__ uint8_t s_map[WAVES_PER_BLOCK][SC2_MAXU];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t slot = (blockIdx.x * WAVES_PER_BLOCK + wv) * 64 + lane;
+    uint32_t L = NONE32, R = NONE32;
+    if (slot < n_slots && !(use_flags && !w.slot_flag[slot])) { L = w.gpl[slot]; if (L != NONE32) R = w.gpr[slot]; }
+    int lstart = 0, rstart = 0, cmp = 0;
+    uint64_t lso = 0, rso = 0, lqo = 0, rqo = 0;
+    if (L != NONE32) {
+        if (R == NONE32) w.spatch[L] = GCE_PATCH_CONST;                                          // pair.cpp:89-105
+        else {
+            const ReadDesc lk = load_desc(w.rdesc, L), rk = load_desc(w.rdesc, R);
+            if (!(lk.ml > 0 && rk.ml > 0)) { w.spatch[L] = GCE_PATCH_CONST; w.spatch[R] = GCE_PATCH_CONST; }
+            else {
+                const int dis = rk.pos - lk.pos;                                                 // pair.cpp:108-120
+                if (dis >= 0) { lstart = lk.mo + dis; rstart = rk.mo; cmp = min(lk.ml - dis, rk.ml); }
+                else { lstart = lk.mo; rstart = rk.mo - dis; cmp = min(lk.ml, rk.ml + dis); }
+                if (cmp > 0 && (lk.lq > 65535 || rk.lq > 65535)) { raise_error(w.si, GCE_ERR_INVALID, L); cmp = 0; }
+                if (cmp > 0) {
+                    w.spatch[L] = (uint32_t)lstart | ((uint32_t)cmp << 16); w.spatch[R] = (uint32_t)rstart | ((uint32_t)cmp << 16);
+                    lso = lk.so; rso = rk.so; lqo = lk.qo; rqo = rk.qo;
+                } else cmp = 0;                                                                  // no overlap: both reads are pure qual2score
+            }
+        }
+    }
+    // ---- units of 8 overlap bases, exclusive prefix over the wave's pairs
+    const int nu = (cmp + 7) >> 3;
+    int pre = nu;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+    const int total = __shfl(pre, 63);
+    pre -= nu;
+    for (int ubase = 0; ubase < total; ubase += SC2_MAXU) {                                      // (one pass unless the overlaps are huge)
+        for (int k = 0; k < nu; k++) { const int u = pre + k - ubase; if (u >= 0 && u < SC2_MAXU) s_map[wv][u] = (uint8_t)lane; }
+        WAVE_SYNC();
+        const int lim = min(SC2_MAXU, total - ubase);
+        for (int r0 = 0; r0 < lim; r0 += 64) {
+            const int u = r0 + lane;
+            const bool live = u < lim;
+            const int pl = live ? s_map[wv][u] : 0;                                              // (all lanes run the shuffles)
+            const int ppre = __shfl(pre, pl), pcmp = __shfl(cmp, pl), pls = __shfl(lstart, pl), prs = __shfl(rstart, pl);
+            const uint64_t plso = (uint64_t)__shfl((long long)lso, pl), prso = (uint64_t)__shfl((long long)rso, pl);
+            const uint64_t plqo = (uint64_t)__shfl((long long)lqo, pl), prqo = (uint64_t)__shfl((long long)rqo, pl);
+            if (live) {
+                const int i0 = 8 * (ubase + u - ppre), nv = min(8, pcmp - i0), l = pls + i0, r = prs + i0;
+                uint8_t *lq = b.qual + plqo, *rq = b.qual + prqo;
+                const uint64_t ql8 = *(const u64_unaligned *)(lq + l), qr8 = *(const u64_unaligned *)(rq + r);
+                const uint64_t sl8 = *(const u64_unaligned *)(b.seq + plso + (l >> 1)), sr8 = *(const u64_unaligned *)(b.seq + prso + (r >> 1));
+                uint64_t outl = 0, outr = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int ql = (int)(ql8 >> (8 * k)) & 0xFF, qr = (int)(qr8 >> (8 * k)) & 0xFF;
+                    const int jl = (l & 1) + k, jr = (r & 1) + k;                             // nibble index in the loaded bytes: byte j/2, high nibble first
+                    const int nl = (int)(sl8 >> (8 * (jl >> 1) + ((jl & 1) ? 0 : 4))) & 0xF, nr = (int)(sr8 >> (8 * (jr >> 1) + ((jr & 1) ? 0 : 4))) & 0xF;
+                    int scl, scr;
+                    if (nl == nr) scl = scr = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4 + p.score_bias;        // pair.cpp:148-154
+                    else {                                                                     // pair.cpp:155-168: quals rewritten in place
+                        if (k < nv) { lq[l + k] = (uint8_t)max(0, ql - qr); rq[r + k] = (uint8_t)max(0, qr - ql); }
+                        if (ql >= qr) { scl = d_qual2score(p, ql - qr) - 3 + p.score_bias; scr = p.score_bias; }
+                        else { scl = p.score_bias; scr = d_qual2score(p, qr - ql) - 3 + p.score_bias; }
+                    }
+                    outl |= (uint64_t)(scl & 0xFF) << (8 * k); outr |= (uint64_t)(scr & 0xFF) << (8 * k);
+                }
+                int8_t *ls = w.score + plqo, *rs = w.score + prqo;
+                if (nv == 8) { *(u64_unaligned *)(ls + l) = outl; *(u64_unaligned *)(rs + r) = outr; }
+                else for (int k = 0; k < nv; k++) { ls[l + k] = (int8_t)(outl >> (8 * k)); rs[r + k] = (int8_t)(outr >> (8 * k)); }
+            }
+        }
+        WAVE_SYNC();
+    }
+}
+
 // ===================================================================================================== consensus
 struct VoteCtx {
     const DevBatch *b; const DevParams *p; const Work *w;
