@@ -44,6 +44,7 @@ struct Work {
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
+    uint8_t *pf_flag; uint32_t *pf_list;      // clusters the half-wave pairing kernel hands to the full-wave one (same scheme)
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
                                           // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
     uint32_t *fb_list; uint8_t *slot_flag;   // groups the fused LDS kernel handed to the global-memory path; their pair slots
@@ -652,10 +653,7 @@ __device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
 }
 
 // One wave per cluster, <= 64 reads, names <= 64 bytes, UMIs <= 24 bytes: everything in registers.
-__global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
-    const int lane = lane_id();
-    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (c >= n_clusters) return;
+__device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
     uint64_t entry = w.table[w.cl_slot[c]];
     uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
@@ -812,6 +810,15 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
         gbase += run;
     }
     if (lane == 0) { const bool cross = d_key(b.core[w.members[start]], p).right < 0; w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0)); }
+}
+// one wave per cluster: every cluster (list == nullptr) or the clusters k_pairing_half (gce_pair2.hpp) flagged, compacted into pf_list
+__global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, Work w, uint32_t n_clusters, const uint32_t *list) {
+    const int lane = lane_id();
+    const uint32_t total = list ? (uint32_t)w.si->n_pf_items : n_clusters, stride = gridDim.x * WAVES_PER_BLOCK;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); idx < total; idx += stride) {
+        pairing_fast_cluster(b, p, w, list ? list[idx] : idx, lane);
+        WAVE_SYNC();
+    }
 }
 
 // exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word

@@ -1,0 +1,209 @@
+// gce_pair2.hpp — mate pairing + UMI grouping with TWO clusters per wave: lanes 0-31 work one cluster, lanes 32-63 the next.
+//
+// k_pairing_fast is VALU-bound with 13 of 64 lanes carrying a read at the benchmark's depth; running two clusters as the two
+// halves of a wave executes the same instruction stream once for both.  Same algorithm as k_pairing_fast (gce_kernels.hpp):
+// names as big-endian words, hash-filtered name classes verified exactly, first / last read of a name = mLeft / mRight
+// (pair.cpp:188-216), lexicographic rank against the first read of every other name (std::map order, cluster.cpp:260-273),
+// the setRight UMI check, read -> pair transposition by ds_permute, greedy UMI grouping (cluster.cpp:57-100), group-contiguous
+// layout.  What was wave-uniform is half-uniform here: masks are 32-bit per half, broadcasts are ds_bpermute from (half base
+// + index), loops run to the larger half's trip count under per-lane predicates.
+//
+// Scope: <= 32 reads per cluster, names <= 64 bytes, UMIs <= 24 bytes.  Anything else is flagged (pf_flag) and taken by
+// k_pairing_fast / the generic kernel in a second launch over the compacted list.
+#pragma once
+
+__device__ __forceinline__ int half_max(int v) {
+    for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64_t)__shfl((long long)v, src); }
+
+__global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+    const int lane = lane_id(), h = lane >> 5, hl = lane & 31, hb = lane & 32;
+    const uint32_t c = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 2 + (uint32_t)h;
+    bool live = c < n_clusters;
+    uint32_t start = 0, n = 0; int thr = 0;
+    if (live) {
+        start = w.cl_start[c]; n = w.cl_n[c];
+        const uint64_t entry = w.table[w.cl_slot[c]];
+        const uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
+        if (mode == THR_NEVER) { if (hl == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } live = false; }   // gencore.cpp:23
+        thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
+    }
+    uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0;
+    if (live && n <= 32 && hl < (int)n) {
+        my = w.members[start + hl];
+        nl = (int)b.core[my].l_qname - 1;
+        nm = d_qname(b, my);
+        ul = w.umi_len[my];
+    }
+    const uint32_t toolong = half_ballot(nl > 64 || ul > 24, h);
+    if (live && (n > 32 || toolong)) { if (hl == 0) w.pf_flag[c] = 1; live = false; }           // the full-wave kernel takes it
+    if (!__any(live)) return;
+    const bool act = live && hl < (int)n;
+    const int nwords = (wave_max(act ? nl : 0) + 7) >> 3;
+    uint64_t nw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = 0;
+        if (k < nwords) {
+            const int rem = (act ? nl : 0) - 8 * k;
+            if (rem > 0) { v = *(const u64_unaligned *)(nm + 8 * k); if (rem < 8) v &= (1ull << (8 * rem)) - 1ull; v = d_bswap64(v); }
+        }
+        nw[k] = v;
+    }
+    // ---- name classes: 32-bit hash as a filter (verified word by word below)
+    uint32_t h32 = 0x9E3779B9u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < nwords) {
+        const uint32_t lo = (uint32_t)nw[k], hi = (uint32_t)(nw[k] >> 32);
+        h32 = (__builtin_rotateleft32(h32, 5) ^ lo) + hi;
+        h32 = __builtin_rotateleft32(h32, 11) ^ (hi + 0x7F4A7C15u);
+    }
+    h32 ^= h32 >> 15;
+    const int nmax = wave_max(live ? (int)n : 0);
+    uint32_t EQ = 0, LOW = 0;
+    for (int j = 0; j < nmax; j++) {
+        const uint32_t oh = (uint32_t)__shfl((int)h32, hb + j);
+        const bool same = act && j < (int)n && h32 == oh;
+        const uint32_t cls = half_ballot(same, h);
+        if (same) EQ = cls;
+    }
+    EQ &= ~(1u << hl);
+    {   // exact verification of every hash match, arrival order inside the class (all lanes run the shuffles)
+        bool bad = false;
+        const int rounds = wave_max(act ? __popc(EQ) : 0);
+        uint32_t rest = act ? EQ : 0u;
+        for (int r = 0; r < rounds; r++) {
+            const bool has = rest != 0;
+            const int sl = has ? __ffs((int)rest) - 1 : hl;
+            rest &= rest - 1;
+            const uint32_t oj = (uint32_t)__shfl((int)my, hb + sl);
+            if (has && oj < my) LOW |= 1u << sl;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (k < nwords) { const uint64_t o = shfl64(nw[k], hb + sl); if (has && o != nw[k]) bad = true; }
+        }
+        const uint32_t badm = half_ballot(bad, h);
+        if (live && badm) { if (hl == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; live = false; }     // false hash match: generic kernel
+    }
+    if (!__any(live)) return;
+    const bool act2 = act && live;
+    // ---- pairs: first read of a name = mLeft, last one = mRight
+    const bool first = act2 && !(EQ & LOW), last = act2 && !(EQ & ~LOW);
+    const uint32_t FIRST = half_ballot(first, h);
+    const uint32_t npairs = __popc(FIRST);
+    // ---- std::map order: lexicographic compares only against the first read of every OTHER name
+    uint32_t LT = 0;
+    {
+        const int itmax = wave_max((int)npairs);
+        uint32_t fm = FIRST;
+        for (int it = 0; it < itmax; it++) {
+            const bool has = fm != 0;
+            const int j = has ? __ffs((int)fm) - 1 : hl;
+            fm &= fm - 1;
+            int cmp = 0;                                    // sign of name_j - name_mine
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < nwords) {
+                    const uint64_t o = shfl64(nw[k], hb + j);
+                    if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
+                }
+            }
+            if (has && cmp < 0) LT |= 1u << j;
+        }
+    }
+    const uint32_t pidx = __popc(LT);                       // distinct names before mine
+    uint64_t ruw[3];
+    load_be_words<3>(act2 ? w.umi_ptr[my] : nullptr, act2 ? ul : 0, ruw);
+    {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty; the pair's current read is
+        // the predecessor in arrival order = the largest read index among the same-name reads before mine
+        uint32_t prev = act2 ? (EQ & LOW) : 0u;
+        const int rounds = wave_max(__popc(prev));
+        int plane = -1; uint32_t pv = 0;
+        for (int r = 0; r < rounds; r++) {
+            const bool has = prev != 0;
+            const int sl = has ? __ffs((int)prev) - 1 : hl;
+            prev &= prev - 1;
+            const uint32_t o = (uint32_t)__shfl((int)my, hb + sl);
+            if (has && (plane < 0 || o > pv)) { pv = o; plane = sl; }
+        }
+        if (rounds > 0) {
+            const int src = hb + (plane < 0 ? hl : plane);
+            const uint64_t q0 = shfl64(ruw[0], src), q1 = shfl64(ruw[1], src), q2 = shfl64(ruw[2], src);
+            const int qul = __shfl(ul, src);
+            if (plane >= 0 && qul != 0 && !(qul == ul && q0 == ruw[0] && q1 == ruw[1] && q2 == ruw[2])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
+        }
+    }
+    const bool any_umi = half_ballot(act2 && last && ul > 0, h) != 0;
+    // ---- lanes now stand for pairs (qname order): every read pushes its fields to its pair's lane.  Lanes with nothing to send aim
+    //      at lane 31 of the half, a pair lane only when all 32 reads are mate-less singletons -- and then every lane sends.
+    const bool pact = live && hl < (int)npairs;
+    uint32_t L, R, g_of = 0, ngroups = live ? 1u : 0u;
+    {
+        const int to_first = (hb + (first ? (int)pidx : 31)) << 2, to_right = (hb + ((last && !first) ? (int)pidx : 31)) << 2;
+        L = (uint32_t)__builtin_amdgcn_ds_permute(to_first, first ? (int)(my + 1u) : 0) - 1u;
+        R = (uint32_t)__builtin_amdgcn_ds_permute(to_right, (last && !first) ? (int)(my + 1u) : 0) - 1u;
+        if (!pact) { L = NONE32; R = NONE32; }
+    }
+    if (__any(any_umi)) {                                    // greedy UMI grouping (cluster.cpp:57-100), for the halves that carry UMIs
+        uint64_t uw[3]; int ulen;
+        {
+            const int to_last = (hb + (last ? (int)pidx : 31)) << 2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(to_last, last ? (int)(uint32_t)ruw[k] : 0);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(to_last, last ? (int)(uint32_t)(ruw[k] >> 32) : 0);
+                uw[k] = pact ? (((uint64_t)hi << 32) | lo) : 0ull;
+            }
+            ulen = __builtin_amdgcn_ds_permute(to_last, last ? ul : 0);
+            if (!pact) ulen = 0;
+        }
+        const bool grp = any_umi;                           // (a half without UMIs keeps its single group)
+        int cnt = 0, urank = 0;                             // umiCount[umi], and the rank of my UMI in std::string order
+        const int pmax = wave_max(grp ? (int)npairs : 0);
+        const bool one_word = wave_max(ulen) <= 8;
+        for (int q = 0; q < pmax; q++) {
+            const bool in = q < (int)npairs;
+            const uint64_t a0 = shfl64(uw[0], hb + q); const int al = __shfl(ulen, hb + q);
+            if (one_word) { cnt += (in && a0 == uw[0] && al == ulen); urank += (in && (a0 != uw[0] ? a0 < uw[0] : al < ulen)); }
+            else {
+                const uint64_t a1 = shfl64(uw[1], hb + q), a2 = shfl64(uw[2], hb + q);
+                const bool eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
+                const bool lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
+                cnt += (in && eq); urank += (in && lt);
+            }
+        }
+        if (grp) { g_of = NONE32; ngroups = 0; }
+        uint32_t remaining = grp ? half_ballot(pact, h) : 0u;
+        while (__any(remaining != 0)) {
+            const bool open = remaining != 0;
+            const int key = (open && pact && g_of == NONE32) ? (cnt * 64 + (63 - urank)) : -1;     // highest count, then smallest UMI
+            const int best = half_max(key);
+            const uint32_t bm = half_ballot(key == best && key >= 0, h);
+            const int tl = hb + (bm ? __ffs((int)bm) - 1 : hl);
+            const uint64_t t0 = shfl64(uw[0], tl), t1 = shfl64(uw[1], tl), t2 = shfl64(uw[2], tl);
+            const int diff = popc_nonzero_bytes(t0 ^ uw[0]) + popc_nonzero_bytes(t1 ^ uw[1]) + popc_nonzero_bytes(t2 ^ uw[2]);   // Cluster::umiDiff
+            const bool take = open && pact && g_of == NONE32 && diff <= thr;
+            if (take) g_of = ngroups;
+            remaining &= ~half_ballot(take, h);
+            if (open) ngroups++;
+        }
+    }
+    // ---- lay the pairs out group by group (qname order inside a group)
+    {
+        uint32_t gbase = 0;
+        const int gmax = wave_max((int)ngroups);
+        for (int g = 0; g < gmax; g++) {
+            const bool in = pact && g_of == (uint32_t)g;
+            const uint32_t m = half_ballot(in, h);
+            if (in) { const uint32_t d = start + gbase + __popc(m & ((1u << hl) - 1u)); w.gpl[d] = L; w.gpr[d] = R; }
+            const uint32_t run = __popc(m);
+            if (live && hl == 0 && g < (int)ngroups) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
+            gbase += run;
+        }
+    }
+    if (live && hl == 0) {
+        const bool cross = d_key(b.core[w.members[start]], p).right < 0;
+        w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0));
+    }
+}
