@@ -56,7 +56,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf k64, slow_list, pf_flag, pf_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -130,7 +130,7 @@ void gce_destroy(gce_engine *e) {
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -374,14 +374,21 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score recognises pair slots by gpl != NONE
         static const bool pair_halves = !(getenv("GCE_PAIR2") && atoi(getenv("GCE_PAIR2")) == 0);   // 0: one wave per cluster throughout
         if (pair_halves) {
-            ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4);
-            w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>();
-            HIPCHK(hipMemsetAsync(e->pf_flag.p, 0, c1, s));
-            hipLaunchKernelGGL(k_pairing_half, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
-            const unsigned nbc = cdiv(C, SCAN_TILE);                  // compact the clusters it flagged (> 32 reads, long names / UMIs)
-            hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)w.pf_flag, (uint64_t)C, w.scan_part);
-            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, &w.si->n_pf_items, (unsigned long long *)nullptr);
-            hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)w.pf_flag, (uint64_t)C, (const uint64_t *)w.scan_part, w.pf_list);
+            // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
+            // compacted by the scan kernels (never one shared append counter)
+            ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4);
+            w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>();
+            HIPCHK(hipMemsetAsync(e->pf_flag.p, 0, c1, s)); HIPCHK(hipMemsetAsync(e->pq_flag.p, 0, c1, s));
+            const unsigned nbc = cdiv(C, SCAN_TILE);
+            auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
+                hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
+                hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, count, (unsigned long long *)nullptr);
+                hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, (const uint64_t *)w.scan_part, list);
+            };
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
+            compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
+            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
+            compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
             hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
         } else hipLaunchKernelGGL(k_pairing_fast, dim3(cdiv(C, WAVES_PER_BLOCK) < 65535u * 16u ? cdiv(C, WAVES_PER_BLOCK) : 65535u * 16u), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);

@@ -81,6 +81,7 @@ struct StreamInfo {
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one
+    unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
 };

@@ -1,4 +1,5 @@
-// gce_pair2.hpp — mate pairing + UMI grouping with TWO clusters per wave: lanes 0-31 work one cluster, lanes 32-63 the next.
+// gce_pair2.hpp — mate pairing + UMI grouping with SEVERAL clusters per wave: 16 lanes per cluster (four clusters per wave) for
+// clusters of <= 16 reads, then 32 lanes per cluster (two per wave) for the ones that pass flagged on, then k_pairing_fast.
 //
 // k_pairing_fast is VALU-bound with 13 of 64 lanes carrying a read at the benchmark's depth; running two clusters as the two
 // halves of a wave executes the same instruction stream once for both.  Same algorithm as k_pairing_fast (gce_kernels.hpp):
@@ -8,20 +9,32 @@
 // layout.  What was wave-uniform is half-uniform here: masks are 32-bit per half, broadcasts are ds_bpermute from (half base
 // + index), loops run to the larger half's trip count under per-lane predicates.
 //
-// Scope: <= 32 reads per cluster, names <= 64 bytes, UMIs <= 24 bytes.  Anything else is flagged (pf_flag) and taken by
-// k_pairing_fast / the generic kernel in a second launch over the compacted list.
+// Scope: <= SUB reads per cluster, names <= 64 bytes, UMIs <= 24 bytes.  Anything else is flagged and taken by the next wider
+// instantiation / k_pairing_fast / the generic kernel in a later launch over the compacted list ("half" in the comments below
+// = the SUB-lane group of a cluster).
 #pragma once
 
-__device__ __forceinline__ int half_max(int v) {
-    for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
+template <int SUB> __device__ __forceinline__ int sub_max(int v) {
+    for (int o = SUB / 2; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
     return v;
+}
+// my sub-group's bits of a wave ballot
+template <int SUB> __device__ __forceinline__ uint32_t sub_ballot(bool pr, int hb) {
+    const unsigned long long m = __ballot(pr);
+    return (uint32_t)(m >> hb) & (SUB == 32 ? 0xFFFFFFFFu : ((1u << (SUB & 31)) - 1u));
 }
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64_t)__shfl((long long)v, src); }
 
-__global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
-    const int lane = lane_id(), h = lane >> 5, hl = lane & 31, hb = lane & 32;
-    const uint32_t c = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 2 + (uint32_t)h;
-    bool live = c < n_clusters;
+// SUB = lanes per cluster (32: two clusters per wave, 16: four).  `list` != nullptr: the clusters a narrower instantiation flagged.
+template <int SUB>
+__global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Work w, uint32_t n_clusters, const uint32_t *list, const unsigned long long *list_n, uint8_t *flag_out) {
+    constexpr int PER = 64 / SUB;
+    const int lane = lane_id(), hl = lane & (SUB - 1), hb = lane & ~(SUB - 1);
+    const uint32_t idx = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * PER + (uint32_t)(lane / SUB);
+    const uint32_t total = list ? (uint32_t)*list_n : n_clusters;
+    if ((blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * PER >= total) return;
+    bool live = idx < total;
+    const uint32_t c = live ? (list ? list[idx] : idx) : 0u;
     uint32_t start = 0, n = 0; int thr = 0;
     if (live) {
         start = w.cl_start[c]; n = w.cl_n[c];
@@ -31,14 +44,14 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
         thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     }
     uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0;
-    if (live && n <= 32 && hl < (int)n) {
+    if (live && n <= (uint32_t)SUB && hl < (int)n) {
         my = w.members[start + hl];
         nl = (int)b.core[my].l_qname - 1;
         nm = d_qname(b, my);
         ul = w.umi_len[my];
     }
-    const uint32_t toolong = half_ballot(nl > 64 || ul > 24, h);
-    if (live && (n > 32 || toolong)) { if (hl == 0) w.pf_flag[c] = 1; live = false; }           // the full-wave kernel takes it
+    const uint32_t toolong = sub_ballot<SUB>(nl > 64 || ul > 24, hb);
+    if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
     if (!__any(live)) return;
     const bool act = live && hl < (int)n;
     const int nwords = (wave_max(act ? nl : 0) + 7) >> 3;
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
     for (int j = 0; j < nmax; j++) {
         const uint32_t oh = (uint32_t)__shfl((int)h32, hb + j);
         const bool same = act && j < (int)n && h32 == oh;
-        const uint32_t cls = half_ballot(same, h);
+        const uint32_t cls = sub_ballot<SUB>(same, hb);
         if (same) EQ = cls;
     }
     EQ &= ~(1u << hl);
@@ -83,14 +96,14 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
 #pragma unroll
             for (int k = 0; k < 8; k++) if (k < nwords) { const uint64_t o = shfl64(nw[k], hb + sl); if (has && o != nw[k]) bad = true; }
         }
-        const uint32_t badm = half_ballot(bad, h);
+        const uint32_t badm = sub_ballot<SUB>(bad, hb);
         if (live && badm) { if (hl == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; live = false; }     // false hash match: generic kernel
     }
     if (!__any(live)) return;
     const bool act2 = act && live;
     // ---- pairs: first read of a name = mLeft, last one = mRight
     const bool first = act2 && !(EQ & LOW), last = act2 && !(EQ & ~LOW);
-    const uint32_t FIRST = half_ballot(first, h);
+    const uint32_t FIRST = sub_ballot<SUB>(first, hb);
     const uint32_t npairs = __popc(FIRST);
     // ---- std::map order: lexicographic compares only against the first read of every OTHER name
     uint32_t LT = 0;
@@ -134,13 +147,13 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
             if (plane >= 0 && qul != 0 && !(qul == ul && q0 == ruw[0] && q1 == ruw[1] && q2 == ruw[2])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
         }
     }
-    const bool any_umi = half_ballot(act2 && last && ul > 0, h) != 0;
+    const bool any_umi = sub_ballot<SUB>(act2 && last && ul > 0, hb) != 0;
     // ---- lanes now stand for pairs (qname order): every read pushes its fields to its pair's lane.  Lanes with nothing to send aim
     //      at lane 31 of the half, a pair lane only when all 32 reads are mate-less singletons -- and then every lane sends.
     const bool pact = live && hl < (int)npairs;
     uint32_t L, R, g_of = 0, ngroups = live ? 1u : 0u;
     {
-        const int to_first = (hb + (first ? (int)pidx : 31)) << 2, to_right = (hb + ((last && !first) ? (int)pidx : 31)) << 2;
+        const int to_first = (hb + (first ? (int)pidx : SUB - 1)) << 2, to_right = (hb + ((last && !first) ? (int)pidx : SUB - 1)) << 2;
         L = (uint32_t)__builtin_amdgcn_ds_permute(to_first, first ? (int)(my + 1u) : 0) - 1u;
         R = (uint32_t)__builtin_amdgcn_ds_permute(to_right, (last && !first) ? (int)(my + 1u) : 0) - 1u;
         if (!pact) { L = NONE32; R = NONE32; }
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
     if (__any(any_umi)) {                                    // greedy UMI grouping (cluster.cpp:57-100), for the halves that carry UMIs
         uint64_t uw[3]; int ulen;
         {
-            const int to_last = (hb + (last ? (int)pidx : 31)) << 2;
+            const int to_last = (hb + (last ? (int)pidx : SUB - 1)) << 2;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(to_last, last ? (int)(uint32_t)ruw[k] : 0);
@@ -174,18 +187,18 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
             }
         }
         if (grp) { g_of = NONE32; ngroups = 0; }
-        uint32_t remaining = grp ? half_ballot(pact, h) : 0u;
+        uint32_t remaining = grp ? sub_ballot<SUB>(pact, hb) : 0u;
         while (__any(remaining != 0)) {
             const bool open = remaining != 0;
             const int key = (open && pact && g_of == NONE32) ? (cnt * 64 + (63 - urank)) : -1;     // highest count, then smallest UMI
-            const int best = half_max(key);
-            const uint32_t bm = half_ballot(key == best && key >= 0, h);
+            const int best = sub_max<SUB>(key);
+            const uint32_t bm = sub_ballot<SUB>(key == best && key >= 0, hb);
             const int tl = hb + (bm ? __ffs((int)bm) - 1 : hl);
             const uint64_t t0 = shfl64(uw[0], tl), t1 = shfl64(uw[1], tl), t2 = shfl64(uw[2], tl);
             const int diff = popc_nonzero_bytes(t0 ^ uw[0]) + popc_nonzero_bytes(t1 ^ uw[1]) + popc_nonzero_bytes(t2 ^ uw[2]);   // Cluster::umiDiff
             const bool take = open && pact && g_of == NONE32 && diff <= thr;
             if (take) g_of = ngroups;
-            remaining &= ~half_ballot(take, h);
+            remaining &= ~sub_ballot<SUB>(take, hb);
             if (open) ngroups++;
         }
     }
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256) void k_pairing_half(DevBatch b, DevParams p, W
         const int gmax = wave_max((int)ngroups);
         for (int g = 0; g < gmax; g++) {
             const bool in = pact && g_of == (uint32_t)g;
-            const uint32_t m = half_ballot(in, h);
+            const uint32_t m = sub_ballot<SUB>(in, hb);
             if (in) { const uint32_t d = start + gbase + __popc(m & ((1u << hl) - 1u)); w.gpl[d] = L; w.gpr[d] = R; }
             const uint32_t run = __popc(m);
             if (live && hl == 0 && g < (int)ngroups) { w.grp_begin[start + g] = start + gbase; w.grp_n[start + g] = run; }
