@@ -167,7 +167,11 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             else {
                 sc_lo = lower_bound_ok ? smin4 : d_q2s4_biased(p, q_lo); sc_hi = lower_bound_ok ? smin4 : d_q2s4_biased(p, q_hi);
                 const int ps = (int)(vpatch & 0xFFFF) - c8, pe = ps + (int)(vpatch >> 16);       // patch = unit bytes [ps, pe)
-                const uint32_t pm_lo = byte_range4(ps, pe), pm_hi = byte_range4(ps - 4, pe - 4);
+                // bytes [ps, pe) of the 8-byte unit as one 64-bit mask (two shifts) instead of two clamped 32-bit ranges
+                const int a8 = min(max(ps, 0), 8), z8 = min(max(pe, 0), 8);
+                const uint64_t upto_z = z8 >= 8 ? ~0ull : ((1ull << (8 * z8)) - 1ull), upto_a = a8 >= 8 ? ~0ull : ((1ull << (8 * a8)) - 1ull);
+                const uint64_t pm8 = z8 > a8 ? (upto_z & ~upto_a) : 0ull;
+                const uint32_t pm_lo = (uint32_t)pm8, pm_hi = (uint32_t)(pm8 >> 32);
                 if (pm_lo | pm_hi) {
                     const uint32_t st_lo = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + c8), st_hi = *(const u32_unaligned *)((const uint8_t *)w.score + vqo + c8 + 4);
                     sc_lo = (sc_lo & ~pm_lo) | (st_lo & pm_lo); sc_hi = (sc_hi & ~pm_hi) | (st_hi & pm_hi);
