@@ -24,6 +24,7 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     note = sys.argv[3] if len(sys.argv) > 3 else ""
     rows = rows_from_db(src) if src.endswith(".db") else rows_from_csv(src)
+    rows = [((r[0][5:] if r[0].startswith("void ") else r[0]),) + tuple(r[1:]) for r in rows]      # templated kernels are reported as "void k_x<..>(...)"
     ours = [r for r in rows if r[0].startswith("k_")]
     tot = sum(r[2] for r in ours)
     with open(dst, "w") as f:
