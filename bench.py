@@ -167,11 +167,11 @@ def main():
     tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tj) and args.workload == "cfg3" and args.pairs is None:
         kk = json.load(open(tj))["kernels"]
-        names = {"consensus": ("k_score", "k_consensus_lean2", "k_consensus_lean", "k_consensus_fast", "k_consensus_slow"), "cluster": ("k_cluster",)}
+        names = {"consensus": ("k_score", "k_score2", "k_consensus_lean2", "k_consensus_lean", "k_consensus_fast", "k_consensus_slow"), "cluster": ("k_cluster",)}
         def tr(ns):
             return sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in ns if n in kk)
         traffic = {k: tr(v) for k, v in names.items()}
-    roofline = dict(bound="hbm", kernel={"consensus": "k_score+k_consensus (Pair::computeScore + Group::makeConsensus)",
+    roofline = dict(bound="hbm", kernel={"consensus": "k_score2+k_consensus_* (Pair::computeScore + Group::makeConsensus)",
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
