@@ -440,7 +440,7 @@ int gce_process(gce_engine *e) {
                 hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
                 hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
             }
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w);
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
             hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         } else HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));

@@ -1878,12 +1878,14 @@ __global__ __launch_bounds__(256, 6) void k_consensus_lean(DevBatch b, DevParams
 __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // one list entry per wave; the launch covers the largest possible list (the count only exists on the device) and the
-    // surplus waves leave at once
-    const uint32_t n = (uint32_t)w.si->n_gen_items, idx = blockIdx.x * WAVES_PER_BLOCK + wv;
-    if (idx >= n) return;
-    const uint32_t e = w.gen_list[idx];
-    consensus_fast_side<false>(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
+    // the count only exists on the device: a capped grid strides over the list (a wave takes one or two entries when the list is
+    // long, and leaves at once when it is short -- launching one block per POSSIBLE entry cost more than the work itself)
+    const uint32_t n = (uint32_t)w.si->n_gen_items;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
+        const uint32_t e = w.gen_list[idx];
+        consensus_fast_side<false>(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
+        WAVE_SYNC();
+    }
 }
 
 // ===================================================================================================== finish
