@@ -445,7 +445,7 @@ int gce_process(gce_engine *e) {
         } else HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
-        hipLaunchKernelGGL(k_finish, dim3(cdiv(C, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+        hipLaunchKernelGGL(k_finish, dim3(cdiv(C, 64 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
     } else { HIPCHK(hipEventRecord(e->ev[EV_SCORE], s)); HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s)); }
     if (N > 0 && e->h_si.error == 0) {
         hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);

@@ -2000,12 +2000,8 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
 }
 
 // Duplex matching (cluster.cpp:119-168), one wave per cluster that has UMIs and at least two groups.
-__global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
-    const int lane = lane_id();
-    uint32_t c = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (c >= n_clusters) return;
+__device__ void finish_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t G = w.cl_ngroups[c];
-    if (G < 2 || !(w.cl_hasumi[c] & 1) || p.disable_duplex) return;
     const uint32_t g0 = w.cl_gbase[c];
     for (int idx = (int)G - 1; idx >= 0; idx--) {
         uint32_t gi = g0 + idx;
@@ -2037,6 +2033,18 @@ __global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w,
             bool outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
             if (lane == 0) { w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED; if (outp) d_emit_pair(w, gi, false); }
         }
+        WAVE_SYNC();
+    }
+}
+// Few clusters need the duplex stage (UMIs and >= 2 groups): a wave screens 64 clusters with one coalesced load each and works
+// through the ones that qualify, instead of one (mostly idle) wave per cluster.
+__global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+    const int lane = lane_id();
+    const uint32_t c0 = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64, c = c0 + (uint32_t)lane;
+    if (c0 >= n_clusters || p.disable_duplex) return;
+    const bool need = c < n_clusters && w.cl_ngroups[c] >= 2 && (w.cl_hasumi[c] & 1);
+    for (unsigned long long m = __ballot(need); m; m &= m - 1) {
+        finish_cluster(b, p, w, c0 + (uint32_t)(__ffsll((long long)m) - 1), lane);
         WAVE_SYNC();
     }
 }
