@@ -144,16 +144,22 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(Work w, DevParams p) {
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    for (int64_t base = 0; base < w.n_chunks; base += 1024) {
-        int64_t i = base + threadIdx.x;
-        unsigned int v = i < w.n_chunks ? w.chunk_cnt[i] : 0, x = v;
+    // eight consecutive counts per thread and step: 8192 chunks between two barriers instead of 1024
+    for (int64_t base = 0; base < w.n_chunks; base += 8192) {
+        const int64_t i0 = base + 8 * (int64_t)threadIdx.x;
+        unsigned int c[8], v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c[k] = i0 + k < w.n_chunks ? w.chunk_cnt[i0 + k] : 0; v += c[k]; }
+        unsigned int x = v;
         for (int o = 1; o < 64; o <<= 1) { unsigned int t = __shfl_up(x, o); if (lane >= o) x += t; }
         if (lane == 63) s_w[wv] = x;
         __syncthreads();
         unsigned int woff = 0;
         for (int k = 0; k < wv; k++) woff += s_w[k];
-        unsigned int carry = s_carry;
-        if (i < w.n_chunks) w.chunk_base[i] = carry + woff + x - v;
+        const unsigned int carry = s_carry;
+        unsigned int run = carry + woff + x - v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (i0 + k < w.n_chunks) w.chunk_base[i0 + k] = run; run += c[k]; }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = carry + woff + x;
         __syncthreads();
