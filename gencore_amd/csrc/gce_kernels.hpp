@@ -211,7 +211,7 @@ __device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *
 // CL_U consecutive 256-read chunks per block, one read of each per thread, written stage by stage so that the CL_U
 // dependent chains (key record -> flush events -> bucket probe -> CAS -> owner check -> rank atomic) overlap their
 // memory round trips: the scan is bound by latency x occupancy, not by issue.
-#define CL_U 4
+#define CL_U 2
 __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
     __shared__ unsigned int s_cnt[CL_U][WAVES_PER_BLOCK];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
