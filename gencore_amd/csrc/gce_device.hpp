@@ -231,17 +231,19 @@ __device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start
 #pragma unroll
     for (int k = 0; k < 4; k++) w[k] = 8 * k < nwin ? *(const u64_unaligned_t *)(s + base + 8 * k) : 0ull;
     start = 0; len = 0;
-    uint64_t anchor[4];                                                    // prefix characters, or ':'
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint64_t h = 0;
-        if (p.prefix_len > 0) { for (int c = 0; c < p.prefix_len; c++) h |= d_eq_bytes(w[k], p.prefix[c]); }
-        else h = d_eq_bytes(w[k], ':');
-        anchor[k] = h & d_range_bytes(0, nwin, k);
-    }
+    // last prefix character / ':' : words are examined from the end and only while nothing was found (the anchor of a real
+    // name sits in the last word or two, so the earlier words usually cost nothing)
     int wpos = -1;                                                         // window index of the last anchor byte
 #pragma unroll
-    for (int k = 3; k >= 0; k--) if (wpos < 0 && anchor[k]) wpos = 8 * k + ((63 - __clzll((long long)anchor[k])) >> 3);
+    for (int k = 3; k >= 0; k--) {
+        if (wpos < 0 && 8 * k < nwin) {
+            uint64_t h = 0;
+            if (p.prefix_len > 0) { for (int c = 0; c < p.prefix_len; c++) h |= d_eq_bytes(w[k], p.prefix[c]); }
+            else h = d_eq_bytes(w[k], ':');
+            h &= d_range_bytes(0, nwin, k);
+            if (h) wpos = 8 * k + ((63 - __clzll((long long)h)) >> 3);
+        }
+    }
     if (wpos < 0) {
         if (base == 0) return true;                                        // no anchor anywhere: no UMI
         return d_umi_slice_bytes(s, p, start, len, n);                     // anchor (if any) in front of the window
@@ -250,10 +252,13 @@ __device__ inline bool d_umi_slice(const char *s, const DevParams &p, int &start
         const int wst = wpos + 2;                                          // find_last_of + 2 (bamutil.cpp:47-50)
         if (base + wst > n) return false;                                  // substr(start) with start > size() throws
         int l = nwin - wst;                                                // run of [ATCG_] from wst, ended by the first other byte
+        bool open = true;                                                  // (forward from the word that holds wst; stop at the first hit)
 #pragma unroll
-        for (int k = 3; k >= 0; k--) {
-            const uint64_t stop = ~d_umi_bytes(w[k]) & 0x8080808080808080ull & d_range_bytes(wst, nwin, k);
-            if (stop) l = 8 * k + ((__ffsll((long long)stop) - 1) >> 3) - wst;
+        for (int k = 0; k < 4; k++) {
+            if (open && 8 * k + 8 > wst && 8 * k < nwin) {
+                const uint64_t stop = ~d_umi_bytes(w[k]) & 0x8080808080808080ull & d_range_bytes(wst, nwin, k);
+                if (stop) { l = 8 * k + ((__ffsll((long long)stop) - 1) >> 3) - wst; open = false; }
+            }
         }
         start = base + wst; len = l;
         return true;
