@@ -240,3 +240,19 @@ def test_full_size_shard_property(built):
         pre += r.pre.as_array(); post_sum += r.post.as_array()
     assert np.array_equal(flags, whole.out_flag) and np.array_equal(fr, whole.fr) and np.array_equal(nm, whole.nm_new)
     assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post_sum, whole.post.as_array())
+
+
+@pytest.mark.parametrize("switch", ["GCE_PAIR2", "GCE_SCORE2", "GCE_LEAN2"])
+def test_alternate_kernel_paths(built, switch):
+    """The one-wave-per-cluster pairing, the 8-lanes-per-pair scoring and the one-wave-per-side vote stay selectable
+    (README "Diagnostic switches").  They are read once per process, so each runs a slice of this suite in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env[switch] = "0"
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_quirks.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "fuzz_stream or fuzz_umi_modes or quirk_cases or synthetic_configs"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
