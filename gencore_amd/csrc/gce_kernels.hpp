@@ -1994,7 +1994,12 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
         if (right != NONE32) {
             const char *u2; int ul2;
             d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
-            if (left != NONE32 && ul != 0 && !d_bytes_equal(u, ul, u2, ul2)) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
+            if (left != NONE32 && ul != 0) {                               // (two word loads per side instead of a byte loop with a data-dependent exit)
+                bool same = ul == ul2;
+                if (same && ul <= 24) { uint64_t a[3], c3[3]; load_be_words<3>(u, ul, a); load_be_words<3>(u2, ul2, c3); same = a[0] == c3[0] && a[1] == c3[1] && a[2] == c3[2]; }
+                else if (same) same = d_bytes_equal(u, ul, u2, ul2);
+                if (!same) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
+            }
             u = u2; ul = ul2;
         }
     }
