@@ -861,11 +861,11 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 }
 
 // ===================================================================================================== scoring
-// Pair::computeScore (pair.cpp:88-172).  16 lanes per pair slot, 4 slots per wave (gpl/gpr are pre-filled with NONE32,
-// so a slot is a pair iff gpl != NONE32): the kernel is bound by the dependent metadata chain slot -> reads -> core ->
-// CIGAR -> bases, so four independent chains share one wave and every level of the chain is issued as one batch.
+// Pair::computeScore (pair.cpp:88-172).  gpl/gpr are pre-filled with NONE32, so a slot is a pair iff gpl != NONE32.
 // Pairs of groups that never reach a vote get scores too; nothing reads them and no qual is touched for a mate-less
 // pair, so the result is identical to the reference's lazy evaluation.
+// k_score (below) is the first formulation, kept selectable (GCE_SCORE2=0): 8 lanes per pair, 8 pairs per wave.  The default
+// is k_score2 further down: one lane per pair for the dependent chain, overlap work dealt to the lanes in 8-base units.
 #define SC_LPP 8             // lanes per pair
 #define SC_PPW (64 / SC_LPP) // pairs per wave
 // Only the mate-overlap region needs work: outside it a score is qual2score(qual) of an untouched qual, which the vote kernels
