@@ -1,15 +1,19 @@
 #!/usr/bin/env python
 """bench.py — consensus read-pairs/s of the HIP engine on BASELINE.json's workload, with the dominant kernel's
-HBM roofline and the CPU baseline (oracle port, 1 thread) in the same JSON line.
+HBM roofline, the CPU baseline (oracle port, 1 thread and all host cores) and a parity check of the timed entry
+points in the same JSON line.
 
     python bench.py --gpus 1 --steps 5 --warmup 2                       # default workload: cfg3 (10 M pairs, UMI, depth 8, -s 2)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one gce_process() pass of the whole hot path (clustering scan -> pairing/UMI grouping -> scoring ->
-template pick + column vote -> duplex/filter/tags -> Stats) over one synthetic coordinate-sorted stream that is
-already resident in HBM (gce_submit_device).  Every step (warm-up included) gets its own pristine copy of the
-mutable seq/qual blobs, so no work is skipped or cached.  Multi-GPU: one rank per GPU, each rank owns its own
-coordinate shard (weak scaling, no data-path collective); the per-step Stats merge is one RCCL all-reduce.
+template pick + column vote -> duplex/filter/tags -> Stats -> output order + compaction) over one synthetic
+coordinate-sorted stream that is already resident in HBM (gce_submit_device).  Every step (warm-up included) gets its
+own pristine copy of the mutable seq/qual blobs, so no work is skipped or cached.
+Multi-GPU (N > 1): ONE stream of N x pairs-per-GPU pairs (default workload cfg4s = BASELINE configs[3]) is planned by
+every rank, cut into N key ranges of equal read count (gencore_amd/synth.py plan/materialise, cuts fall inside contigs);
+each rank materialises and processes only its own range, with the global ticks and the stream's flush events handed
+to the engine — no data-path collective, one RCCL all-reduce for the Stats merge.  Weak scaling (per-GPU work fixed).
 """
 import argparse
 import ctypes as C
@@ -26,13 +30,76 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy rate
 
 
+def _hip():
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return C.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime loaded")
+
+
+def device_batch(capi, t, n_reads, seq, qual, tick=None):
+    b = capi.GceBatch()
+    b.n_reads = n_reads
+    b.core, b.qname_off, b.qname = t["core"].data_ptr(), t["qname_off"].data_ptr(), t["qname"].data_ptr()
+    b.cigar_off, b.cigar = t["cigar_off"].data_ptr(), t["cigar"].data_ptr()
+    b.seq_off, b.seq, b.qual_off, b.qual = t["seq_off"].data_ptr(), seq.data_ptr(), t["qual_off"].data_ptr(), qual.data_ptr()
+    b.nm, b.nm_type = t["nm"].data_ptr(), t["nm_type"].data_ptr()
+    b.mi_off, b.mi = None, None
+    b.tick = tick.data_ptr() if tick is not None else None
+    b.qname_bytes, b.cigar_words = t["qname"].numel(), t["cigar"].numel()
+    b.seq_bytes, b.qual_bytes, b.mi_bytes = t["seq"].numel(), t["qual"].numel(), 0
+    return b
+
+
+def padded_clone(x):                                        # device blobs must be readable 16 bytes past their end
+    y = torch.zeros(x.numel() + 64, dtype=x.dtype, device=x.device)
+    y[:x.numel()].copy_(x)
+    return y
+
+
+def fetch_rows(capi, lib, eng):
+    """gce_result_device -> numpy rows (the table of emitted records) + Stats blocks."""
+    import numpy as np
+    r = capi.GceResult()
+    assert lib.gce_result_device(eng, C.byref(r)) == 0
+    hip = _hip()
+    n = int(r.n_out)
+
+    def dev(ptr, count, dt):
+        out = np.empty(count, dt)
+        if count:
+            assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+    rows = {k: dev(getattr(r, k), n, dt) for k, dt in (("src", np.uint32), ("kind", np.uint8), ("qname_src", np.uint32), ("nm_new", np.int32),
+                                                       ("fr", np.int16), ("rr", np.int16), ("mate", np.uint32), ("seq_off", np.uint64), ("qual_off", np.uint64))}
+    rows["seq"], rows["qual"] = dev(r.seq, int(r.seq_bytes), np.uint8), dev(r.qual, int(r.qual_bytes), np.uint8)
+    pre, post = capi.GceStats(), capi.GceStats()
+    C.memmove(C.byref(pre), C.byref(r.pre), C.sizeof(capi.GceStats))
+    C.memmove(C.byref(post), C.byref(r.post), C.sizeof(capi.GceStats))
+    return rows, pre, post
+
+
+def _cpu_shard_worker(args):
+    """One process of the all-cores CPU baseline: the oracle over one contig-range shard of the sample."""
+    import numpy as np
+    from gencore_amd import capi
+    from oracle import oracle_py
+    sub, ctx, tl, umi_prefix, s_req, ref_host = args
+    tl = np.asarray(tl, np.uint32)
+    prm = capi.default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=umi_prefix, cluster_size_req=s_req, **ctx)
+    t0 = time.perf_counter()
+    res = oracle_py.run(sub, prm, ref_host)
+    return res.status, time.perf_counter() - t0, res.pre.as_array(), res.post.as_array(), int((res.out_flag != 0).sum())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", help="cfg2 | cfg3 | cfg4s | cfg5 (see gencore_amd/synth.py)")
+    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4s | cfg5 (gencore_amd/synth.py); default cfg3 on 1 GPU, cfg4s on N > 1")
     ap.add_argument("--pairs", type=int, default=None, help="override the workload's pair count (per GPU)")
+    ap.add_argument("--scale", type=float, default=None, help="genome scale of cfg3 (1.0 = hg19 lengths, the default here)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
@@ -49,6 +116,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    workload = args.workload or ("cfg3" if world == 1 else "cfg4s")
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -57,12 +125,22 @@ def main():
         dist.barrier()
     import numpy as np
     from gencore_amd import capi, synth
-    from gencore_amd.capi import GceBatch, GceResult, GceStats, GceTiming
+    from gencore_amd.batch import check_output_order, diff_results, table_from_rows
+    from gencore_amd.capi import GceTiming
     lib = capi.load_library()
     dev = torch.device("cuda", local_rank)
+    over = {}
+    if workload == "cfg3":
+        over["scale"] = args.scale if args.scale is not None else 1.0     # hg19-length contigs (3.04 Gb); tests use the 0.1 default
 
     # ------------------------------------------------------------------ workload (synthetic, generated on the GPU)
-    data = synth.generate(args.workload, n_pairs=args.pairs, seed=rank, device=dev, align=args.align)
+    stream_ctx = None
+    if world == 1:
+        data = synth.generate(workload, n_pairs=args.pairs, seed=0, device=dev, align=args.align, **over)
+    else:
+        per_gpu = args.pairs if args.pairs is not None else synth.CONFIGS[workload]["n_pairs"]
+        data = synth.generate(workload, n_pairs=per_gpu * world, seed=0, device=dev, align=args.align, shard=(rank, world), **over)
+        stream_ctx = data.stream_context
     t = data.t
     n_reads, n_pairs = data.n_reads, data.info["n_pairs"]
     tl = np.asarray(data.target_len, np.uint32)
@@ -74,39 +152,27 @@ def main():
         raise SystemExit("gce_create failed: %s" % lib.gce_status_message(rc).decode())
     for tid, (nib, ln) in enumerate(data.reference):
         assert lib.gce_set_reference(eng, tid, nib.data_ptr(), ln) == 0
+    tick_dev = None
+    if stream_ctx is not None:
+        tick_dev = stream_ctx["tick"]
+        et, ep = stream_ctx["ev_tid"], stream_ctx["ev_pos"]
+        assert lib.gce_set_flush_events(eng, len(et), et.ctypes.data, ep.ctypes.data) == 0
 
     n_copies = args.steps + args.warmup
-
-    def padded_clone(x):                                    # device blobs must be readable 16 bytes past their end
-        y = torch.zeros(x.numel() + 64, dtype=x.dtype, device=x.device)
-        y[:x.numel()].copy_(x)
-        return y
     seqs = [padded_clone(t["seq"]) for _ in range(n_copies)]
     quals = [padded_clone(t["qual"]) for _ in range(n_copies)]
     t["qname"] = padded_clone(t["qname"])
-
-    def make_batch(k):
-        b = GceBatch()
-        b.n_reads = n_reads
-        b.core, b.qname_off, b.qname = t["core"].data_ptr(), t["qname_off"].data_ptr(), t["qname"].data_ptr()
-        b.cigar_off, b.cigar = t["cigar_off"].data_ptr(), t["cigar"].data_ptr()
-        b.seq_off, b.seq, b.qual_off, b.qual = t["seq_off"].data_ptr(), seqs[k].data_ptr(), t["qual_off"].data_ptr(), quals[k].data_ptr()
-        b.nm, b.nm_type = t["nm"].data_ptr(), t["nm_type"].data_ptr()
-        b.mi_off, b.mi = None, None
-        b.qname_bytes, b.cigar_words = t["qname"].numel(), t["cigar"].numel()
-        b.seq_bytes, b.qual_bytes, b.mi_bytes = t["seq"].numel(), t["qual"].numel(), 0
-        return b
 
     stats_dev = torch.zeros(2 * capi.GCE_STATS_WORDS, dtype=torch.int64, device=dev)
     timings, last_res = [], {}
 
     def step(k):
-        b = make_batch(k)
+        b = device_batch(capi, t, n_reads, seqs[k], quals[k], tick_dev)
         rc = lib.gce_submit_device(eng, C.byref(b))
         rc = rc or lib.gce_process(eng)
         if rc:
             raise SystemExit("engine failed: %s" % lib.gce_last_error(eng).decode())
-        r = GceResult()
+        r = capi.GceResult()
         lib.gce_result_device(eng, C.byref(r))
         if dist:                                            # the final Stats merge: one RCCL all-reduce over xGMI
             host = np.concatenate([r.pre.as_array(), r.post.as_array()])
@@ -146,7 +212,7 @@ def main():
     timed = timings[args.warmup:]
     avg = {k: sum(x[k] for x in timed) / len(timed) for k in timed[0]}
     n_groups = max(1.0, avg["n_groups"])
-    d = n_pairs / n_groups                                  # mean group depth
+    d = max(1.0, avg["n_pairs"]) / n_groups                 # mean group depth (pairs per UMI group)
     L = data.info["read_len"]
     per_read = (L + 1) // 2 + L + 4                         # seq + qual + one CIGAR word (229 B at 150 bp)
     consensus_bytes = n_pairs * (2 * per_read + (2 * ((L + 1) // 2 + L) + L) / d)    # 458 + 600/d per pair at 150 bp
@@ -154,41 +220,45 @@ def main():
     kernels = {
         "cluster": dict(ms=avg["cluster_ms"], algorithmic_bytes=cluster_bytes),
         "consensus": dict(ms=avg["score_ms"] + avg["consensus_ms"], algorithmic_bytes=consensus_bytes),
+        "cluster_formation": dict(ms=avg["prescan_ms"] + avg["cluster_ms"] + avg["csr_ms"], algorithmic_bytes=cluster_bytes),
     }
     for v in kernels.values():
         v["achieved_gbs"] = v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
         v["frac"] = v["achieved_gbs"] / HBM_PEAK_GBS
-    phase_ms = {k: avg[k] for k in ("prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "total_ms")}
+    phase_ms = {k: avg[k] for k in ("prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms", "total_ms")}
     dom = "consensus" if kernels["consensus"]["ms"] >= kernels["cluster"]["ms"] else "cluster"
     # HBM traffic of the dominant phase from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # same command: profiles/hbm_traffic.json, tools/hbm_summary.py): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
     # prescribes for gfx950.  Quoted only for the workload it was measured on; PMC counters cannot be read inside this process.
     traffic = None
     tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tj) and args.workload == "cfg3" and args.pairs is None:
-        kk = json.load(open(tj))["kernels"]
-        names = {"consensus": ("k_score", "k_score2", "k_consensus_lean2", "k_consensus_lean", "k_consensus_fast", "k_consensus_slow"), "cluster": ("k_cluster",)}
-        def tr(ns):
-            return sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in ns if n in kk)
-        traffic = {k: tr(v) for k, v in names.items()}
+    if os.path.exists(tj) and args.pairs is None and world == 1:
+        hj = json.load(open(tj))
+        if hj.get("workload") == workload:
+            kk = hj["kernels"]
+            names = {"consensus": hj.get("consensus_kernels", []), "cluster": ["k_cluster"]}
+            traffic = {k: sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in v if n in kk) for k, v in names.items()}
     roofline = dict(bound="hbm", kernel={"consensus": "k_score2+k_consensus_* (Pair::computeScore + Group::makeConsensus)",
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
+                    frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic and traffic[dom] else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
                     clustering_scan=dict(achieved=round(kernels["cluster"]["achieved_gbs"], 2), frac=round(kernels["cluster"]["frac"], 5),
                                          ms=round(kernels["cluster"]["ms"], 4), algorithmic_bytes=round(cluster_bytes),
-                                         traffic=(round(traffic["cluster"]) if traffic else None)),
+                                         traffic=(round(traffic["cluster"]) if traffic and traffic["cluster"] else None)),
+                    cluster_formation=dict(what="k_prescan + table clear + k_cluster + cluster/member lists against the same 40 B/read",
+                                           ms=round(kernels["cluster_formation"]["ms"], 4), frac=round(kernels["cluster_formation"]["frac"], 5)),
                     phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3))
 
-    # ------------------------------------------------------------------ CPU baseline: the oracle port, 1 thread, bounded sample
-    cpu = None
+    # ------------------------------------------------------------------ CPU baseline (oracle port) + parity of the timed entry points
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from gencore_amd.shard import clustered_mask, slice_contiguous
         from oracle import oracle_py
         sample_pairs = min(args.cpu_sample_pairs, n_pairs)
-        sd = synth.generate(args.workload, n_pairs=sample_pairs, seed=12345, device=dev)
+        sd = synth.generate(workload, n_pairs=sample_pairs, seed=12345, device=dev, **over)
         sb = sd.to_batch()
         stl = np.asarray(sd.target_len, np.uint32)
-        sprm = capi.default_params(n_targets=len(stl), target_len=stl.ctypes.data, umi_prefix=sd.info["umi_prefix"],
+        sprm = capi.default_params(device=local_rank, n_targets=len(stl), target_len=stl.ctypes.data, umi_prefix=sd.info["umi_prefix"],
                                    cluster_size_req=sd.info["supporting_reads"])
         ref_host = sd.reference_host()
         oracle_py.lib()
@@ -196,20 +266,71 @@ def main():
         res = oracle_py.run(sb, sprm, ref_host)
         cs = time.perf_counter() - c0
         assert res.status == 0
+        # the same sample through the entry points timed above (gce_submit_device -> gce_process -> gce_result_device)
+        seng = C.c_void_p()
+        assert lib.gce_create(C.byref(sprm), C.byref(seng)) == 0
+        for tid, (nib, ln) in enumerate(sd.reference):
+            assert lib.gce_set_reference(seng, tid, nib.data_ptr(), ln) == 0
+        st = sd.t
+        s_seq, s_qual = padded_clone(st["seq"]), padded_clone(st["qual"])
+        st["qname"] = padded_clone(st["qname"])
+        sbd = device_batch(capi, st, sd.n_reads, s_seq, s_qual)
+        assert lib.gce_submit_device(seng, C.byref(sbd)) == 0 and lib.gce_process(seng) == 0, lib.gce_last_error(seng)
+        rows, pre, post = fetch_rows(capi, lib, seng)
+        lib.gce_destroy(seng)
+        got = table_from_rows(sb, rows, pre, post)
+        diffs = diff_results(sb, got, res) + check_output_order(sb, rows)
+        parity = dict(pairs=sd.info["n_pairs"], records=int(len(rows["src"])), ok=not diffs,
+                      what="engine via gce_submit_device/gce_result_device vs oracle on the CPU-baseline sample: every emitted record "
+                           "(bases, quals, NM, qname source, FR/RR, mate), both Stats blocks, bamComp order")
+        if diffs:
+            parity["first_diffs"] = diffs[:3]
+        # all host cores: N independent processes on contig-range shards of the same sample (the only way the single-threaded
+        # reference scales), Stats merged; wall time of the slowest
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        multi = None
+        if cores > 1:
+            import multiprocessing as mp
+            tid = sb.core["tid"].astype(np.int64)
+            cm = clustered_mask(sb.core)
+            counts = np.bincount(tid[tid >= 0], minlength=len(stl))
+            cum = np.cumsum(counts)
+            nshard = min(cores, len(stl))
+            bounds = sorted(set([0] + [int(np.searchsorted(cum, cum[-1] * r / nshard, side="left")) + 1 for r in range(1, nshard)] + [len(stl)]))
+            total_ticks = int(cm.sum())
+            jobs = []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                idx = np.nonzero((tid >= lo) & (tid < hi))[0]
+                if not len(idx):
+                    continue
+                before, mine = int(cm[tid < lo].sum()), int(cm[idx].sum())
+                ctx = dict(tick_offset=before, trailing_flush=int(total_ticks // 10000 > (before + mine) // 10000))
+                jobs.append((slice_contiguous(sb, int(idx[0]), int(idx[-1]) + 1), ctx, sd.target_len, sd.info["umi_prefix"], sd.info["supporting_reads"], ref_host))
+            m0 = time.perf_counter()
+            with mp.get_context("fork").Pool(len(jobs)) as pool:
+                outs = pool.map(_cpu_shard_worker, jobs)
+            ms_ = time.perf_counter() - m0
+            ok = all(o[0] == 0 for o in outs) and np.array_equal(sum(o[2] for o in outs), res.pre.as_array()) and np.array_equal(sum(o[3] for o in outs), res.post.as_array())
+            multi = dict(value=round(sd.info["n_pairs"] / ms_, 1), processes=len(jobs), host_cores=cores, seconds=round(ms_, 2), stats_equal_single=bool(ok))
         cpu = dict(value=round(sd.info["n_pairs"] / cs, 1), unit="read-pairs/s", cores=1, kind="port",
-                   sample="%s generator, %d pairs, oracle/gencore_oracle.c single thread, %.1f s" % (args.workload, sd.info["n_pairs"], cs))
+                   sample="%s generator, %d pairs, oracle/gencore_oracle.c single thread, %.1f s" % (workload, sd.info["n_pairs"], cs),
+                   all_cores=multi)
 
     if rank == 0:
+        pre = last_res.get("pre", {})
         out = {
             "metric": "consensus read-pairs/sec (whole node) + clustering HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d paired %d bp reads per GPU, %s, mean group depth %.1f, -s %d, coordinate-sharded x%d" % (
-                args.workload, n_pairs, L, ("%d bp UMI" % data.info["umi_len"]) if data.info["umi_len"] else "no UMI", d,
-                data.info["supporting_reads"], world), "pairs_per_gpu": n_pairs, "reads_per_gpu": n_reads,
-                "records_out_per_gpu": last_res.get("n_out"), "parallelism": "coordinate shards x%d, Stats all-reduce" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": "%s: %d paired %d bp reads per GPU, %s, mean group depth %.1f, -s %d, %s, genome %.2f Gb%s" % (
+                workload, n_pairs, L, ("%d bp UMI" % data.info["umi_len"]) if data.info["umi_len"] else "no UMI", d,
+                data.info["supporting_reads"], ("one stream cut into %d key ranges" % world) if world > 1 else "one stream",
+                data.info["genome_bases"] / 1e9, (", %d BED targets x 200 bp" % data.info["bed_targets"]) if data.info.get("bed_targets") else ""),
+                "pairs_per_gpu": n_pairs, "reads_per_gpu": n_reads, "records_out_per_gpu": last_res.get("n_out"),
+                "clusters": pre.get("clusters"), "multi_molecule_clusters": pre.get("multi_molecule_clusters"),
+                "parallelism": ("key-range shards x%d (cluster key (tid,left), global ticks + flush events), Stats all-reduce" % world) if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity,
         }
         if cpu:
             out["speedup_vs_cpu_port"] = round(value / cpu["value"], 2)

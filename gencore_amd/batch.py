@@ -45,6 +45,7 @@ class ReadBatch:
 
     FIELDS = ("core", "qname_off", "qname", "cigar_off", "cigar", "seq_off", "seq", "qual_off", "qual", "nm",
               "nm_type", "mi_off", "mi")
+    tick = None          # optional uint64 [n]: global tick of every clustered read (key-range shards, gencore_amd/shard.py)
 
     def __init__(self, **kw):
         for f in self.FIELDS:
@@ -72,6 +73,7 @@ class ReadBatch:
             setattr(b, f, None if a is None or a.size == 0 and f in ("mi", "mi_off") else a.ctypes.data)
         b.qname_bytes, b.cigar_words, b.seq_bytes, b.qual_bytes = self.qname.size, self.cigar.size, self.seq.size, self.qual.size
         b.mi_bytes = 0 if self.mi is None else self.mi.size
+        b.tick = None if self.tick is None else np.ascontiguousarray(self.tick, np.uint64).ctypes.data
         return b
 
     # ------------------------------------------------------------------ construction from python records
@@ -143,8 +145,61 @@ class ReadBatch:
         return q[o:o + n].copy()
 
 
+def table_from_rows(batch, rows, pre, post):
+    """Per-read ResultTable (the form the oracle produces and diff_results compares) from the engine's table of emitted records
+    (gce_result, one row per record): rows = dict of numpy arrays src, kind, qname_src, nm_new, fr, rr, mate, seq_off, qual_off,
+    seq, qual.  The blobs of the per-read form are the batch's own with the emitted records' bytes put in place."""
+    n = batch.n
+    src = rows["src"].astype(np.int64)
+    out_flag = np.zeros(n, np.uint8); out_flag[src] = rows["kind"]
+    qname_src = np.arange(n, dtype=np.uint32); qname_src[src] = rows["qname_src"]
+    nm_new = np.full(n, -1, np.int32); nm_new[src] = rows["nm_new"]
+    fr = np.full(n, -1, np.int16); fr[src] = rows["fr"]
+    rr = np.full(n, -1, np.int16); rr[src] = rows["rr"]
+    mate = np.full(n, GCE_NONE, np.uint32)
+    has = rows["mate"] != GCE_NONE
+    mate[src[has]] = rows["src"][rows["mate"][has].astype(np.int64)]
+    seq, qual = batch.seq.copy(), batch.qual.copy()
+    lq = batch.core["l_qseq"].astype(np.int64)[src]
+    so, qo = batch.seq_off.astype(np.int64)[src], batch.qual_off.astype(np.int64)[src]
+    ro, rq = rows["seq_off"].astype(np.int64), rows["qual_off"].astype(np.int64)
+
+    def scatter(dst, dst_off, blob, blob_off, lens):           # dst[dst_off[k] + j] = blob[blob_off[k] + j], j < lens[k]; chunked
+        for a in range(0, len(lens), 100000):
+            ln = lens[a:a + 100000]
+            tot = int(ln.sum())
+            if tot == 0:
+                continue
+            within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+            dst[np.repeat(dst_off[a:a + 100000], ln) + within] = blob[np.repeat(blob_off[a:a + 100000], ln) + within]
+    scatter(qual, qo, rows["qual"], rq, lq)
+    scatter(seq, so, rows["seq"], ro, lq // 2)                  # whole bytes; the high nibble of an odd read's last byte below
+    odd = np.nonzero(lq % 2 == 1)[0]
+    if len(odd):                                               # (the pad nibble of an odd-length read is not part of the record)
+        d, a = so[odd] + lq[odd] // 2, ro[odd] + lq[odd] // 2
+        seq[d] = (rows["seq"][a] & 0xF0) | (seq[d] & 0x0F)
+    t = ResultTable(out_flag, qname_src, nm_new, fr, rr, mate, seq, qual, pre, post)
+    t.rows = rows
+    return t
+
+
+def check_output_order(batch, rows):
+    """The table must come in the order of the reference's output set: bamComp (gencore.h:19-47) with the input index as the
+    final tie-break; mates must point at each other.  Returns a list of complaints."""
+    bad = []
+    c = batch.core[rows["src"].astype(np.int64)]
+    key = list(zip(c["tid"].tolist(), c["pos"].tolist(), c["mtid"].tolist(), c["mpos"].tolist(), c["isize"].tolist(), rows["src"].tolist()))
+    if key != sorted(key):
+        bad.append("rows are not in bamComp order")
+    m = rows["mate"]
+    has = np.nonzero(m != GCE_NONE)[0]
+    if len(has) and not np.array_equal(m[m[has].astype(np.int64)], has.astype(np.uint32)):
+        bad.append("mate rows do not point back")
+    return bad
+
+
 class ResultTable:
-    """Per-read result arrays (gce_result / orc_result) as numpy, plus the mutated seq/qual blobs."""
+    """Per-read result arrays (orc_result, or table_from_rows of a gce_result) as numpy, plus the mutated seq/qual blobs."""
 
     def __init__(self, out_flag, qname_src, nm_new, fr, rr, mate, seq, qual, pre, post, status=0, message=""):
         self.out_flag, self.qname_src, self.nm_new, self.fr, self.rr, self.mate = out_flag, qname_src, nm_new, fr, rr, mate
@@ -170,6 +225,27 @@ class ResultTable:
         return out
 
 
+def _differing_reads(batch, a, b, reads):
+    """Subset of `reads` whose record bytes (packed bases incl. the pad nibble of odd reads masked, qualities) differ."""
+    lq = batch.core["l_qseq"].astype(np.int64)[reads]
+    so, qo = batch.seq_off.astype(np.int64)[reads], batch.qual_off.astype(np.int64)[reads]
+    bad = np.zeros(len(reads), bool)
+    for lo in range(0, len(reads), 100000):
+        ln = lq[lo:lo + 100000]
+        tot = int(ln.sum())
+        if tot == 0:
+            continue
+        rid = np.repeat(np.arange(len(ln)), ln)
+        within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+        qi = np.repeat(qo[lo:lo + 100000], ln) + within
+        dq = a.qual[qi] != b.qual[qi]
+        si = np.repeat(so[lo:lo + 100000], ln) + within // 2
+        sh = np.where(within % 2 == 0, 4, 0)
+        ds = ((a.seq[si] >> sh) & 0xF) != ((b.seq[si] >> sh) & 0xF)
+        np.logical_or.at(bad, lo + rid[dq | ds], True)
+    return reads[bad]
+
+
 def diff_results(batch, a, b, max_report=5):
     """Bit-exact comparison of two ResultTables over the same batch.  Returns a list of difference strings."""
     diffs = []
@@ -182,6 +258,9 @@ def diff_results(batch, a, b, max_report=5):
                                                                        x[bad[:max_report]].tolist(), y[bad[:max_report]].tolist()))
     both = np.nonzero((a.out_flag != 0) & (b.out_flag != 0))[0]
     nbad = 0
+    if len(both) > 20000:      # large streams: vectorised screen first (equal-length records), the loop below only reports
+        bad_reads = _differing_reads(batch, a, b, both)
+        both = bad_reads
     for i in both:
         i = int(i)
         so, n = int(batch.seq_off[i]), int(batch.core["l_qseq"][i])

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-GCE_ABI_VERSION = 1
+GCE_ABI_VERSION = 2
 GCE_NONE = 0xFFFFFFFF
 GCE_MAX_SUPPORTING_READS = 100
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
@@ -50,6 +50,7 @@ class GceBatch(C.Structure):
         ("mi_off", C.c_void_p), ("mi", C.c_void_p),
         ("qname_bytes", C.c_size_t), ("cigar_words", C.c_size_t), ("seq_bytes", C.c_size_t),
         ("qual_bytes", C.c_size_t), ("mi_bytes", C.c_size_t),
+        ("tick", C.c_void_p),
     ]
 
 
@@ -73,16 +74,18 @@ assert C.sizeof(GceStats) == 8 * GCE_STATS_WORDS
 
 
 class GceResult(C.Structure):
+    """One row per emitted record, in the order of the reference's output set (include/gencore_amd.h)."""
     _fields_ = [
-        ("n_reads", C.c_int64), ("out_flag", C.c_void_p), ("qname_src", C.c_void_p), ("nm_new", C.c_void_p),
-        ("fr", C.c_void_p), ("rr", C.c_void_p), ("mate", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p),
-        ("n_out", C.c_int64), ("out_index", C.c_void_p), ("pre", GceStats), ("post", GceStats),
+        ("n_reads", C.c_int64), ("n_out", C.c_int64), ("src", C.c_void_p), ("kind", C.c_void_p), ("qname_src", C.c_void_p),
+        ("nm_new", C.c_void_p), ("fr", C.c_void_p), ("rr", C.c_void_p), ("mate", C.c_void_p), ("seq_off", C.c_void_p),
+        ("qual_off", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p), ("seq_bytes", C.c_size_t), ("qual_bytes", C.c_size_t),
+        ("pre", GceStats), ("post", GceStats),
     ]
 
 
 class GceTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
-        "total_ms", "prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms")] + [
+        "total_ms", "prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms")] + [
         ("n_clusters", C.c_int64), ("n_groups", C.c_int64), ("n_pairs", C.c_int64)]
 
     def as_dict(self):
@@ -95,8 +98,8 @@ STATUS_NAMES = {
     -14: "GCE_ERR_QNAME_SHORT"}
 
 EXPORTED_SYMBOLS = [
-    "gce_params_default", "gce_detect_umi_prefix", "gce_create", "gce_destroy", "gce_set_reference",
-    "gce_pack_reference", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
+    "gce_params_default", "gce_detect_umi_prefix", "gce_create", "gce_destroy", "gce_set_reference", "gce_set_reference_ascii",
+    "gce_pack_reference", "gce_set_flush_events", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version"]
 
 
@@ -126,8 +129,10 @@ def load_library(path=None):
     lib.gce_destroy.argtypes = [C.c_void_p]
     lib.gce_destroy.restype = None
     lib.gce_set_reference.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    lib.gce_set_reference_ascii.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     lib.gce_pack_reference.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
     lib.gce_pack_reference.restype = None
+    lib.gce_set_flush_events.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.gce_submit.argtypes = [C.c_void_p, C.POINTER(GceBatch)]
     lib.gce_submit_device.argtypes = [C.c_void_p, C.POINTER(GceBatch)]
     lib.gce_process.argtypes = [C.c_void_p]

@@ -10,9 +10,9 @@
 #include <vector>
 
 #include "gce_kernels.hpp"
-#include "gce_fused.hpp"
 #include "gce_lean2.hpp"
 #include "gce_pair2.hpp"
+#include "gce_output.hpp"
 
 namespace {
 
@@ -31,7 +31,7 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
-enum { EV_START = 0, EV_PRESCAN, EV_CLUSTER, EV_CSR, EV_PAIRING, EV_SCORE, EV_CONSENSUS, EV_FINISH, EV_COUNT };
+enum { EV_START = 0, EV_PRESCAN, EV_CLUSTER, EV_CSR, EV_PAIRING, EV_SCORE, EV_CONSENSUS, EV_FINISH, EV_OUTPUT, EV_COUNT };
 
 }  // namespace
 
@@ -46,22 +46,26 @@ struct gce_engine {
     DevBuf d_ref_ptr, d_ref_len, d_target_len, d_target_cum;
     // host staging (gce_submit)
     std::vector<gce_core> h_core; std::vector<uint64_t> h_qoff, h_coff, h_soff, h_loff, h_mioff;
-    std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm;
-    bool have_mi = false, host_mode = false, device_mode = false, processed = false;
-    bool fused_groups = false;          // GCE_FUSED_GROUPS=1: LDS-resident group kernel (gce_fused.hpp) instead of k_score + k_consensus_fast
+    std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm; std::vector<uint64_t> h_tick;
+    std::vector<int32_t> h_ev_tid, h_ev_pos;   // gce_set_flush_events
+    bool have_mi = false, have_tick = false, have_events = false, host_mode = false, device_mode = false, processed = false;
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
-    DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi;
+    DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
-    DevBuf cls, umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, qname_src, nm_new, fr, rr, mate, out_index;
+    DevBuf cls, umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, orec, out_index;
+    // output table (gce_result): device arrays + host copies
+    DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_rowof, o_units, o_soff, o_qoff, o_seq, o_qual, ref_ascii;
+    int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, fb_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, scan_part, si;
+    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
     // host result copies
-    std::vector<uint8_t> r_flag, r_seq, r_qual; std::vector<uint32_t> r_qsrc, r_mate, r_oidx; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
+    std::vector<uint8_t> r_kind, r_seq, r_qual; std::vector<uint32_t> r_src, r_qsrc, r_mate; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
+    std::vector<uint64_t> r_soff, r_qoff;
 };
 
 static int fail(gce_engine *e, int code, const std::string &msg) { if (e) e->err = msg; return code; }
@@ -116,7 +120,6 @@ int gce_create(const gce_params *params, gce_engine **out) {
     e->prm.target_len = nullptr;
     if (hipSetDevice(params->device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess) { delete e; return GCE_ERR_HIP; }
     for (auto &v : e->ev) (void)hipEventCreate(&v);
-    { const char *f = getenv("GCE_FUSED_GROUPS"); e->fused_groups = f && f[0] == '1'; }
     *out = e;
     return GCE_OK;
 }
@@ -126,12 +129,13 @@ void gce_destroy(gce_engine *e) {
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
-                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
-                     &e->slot, &e->rank, &e->score, &e->out_flag, &e->qname_src, &e->nm_new, &e->fr, &e->rr, &e->mate, &e->out_index, &e->chunk_cnt,
+                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
+                     &e->slot, &e->rank, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
+                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->fb_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
-                     &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->scan_part, &e->si};
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
@@ -163,26 +167,56 @@ int gce_set_reference(gce_engine *e, int32_t tid, const uint8_t *nibbles, int64_
     return GCE_OK;
 }
 
+// One contig of FastaReader::mAllContigs as upper-cased ASCII: packed to the 4-bit code on the GPU (fastareader.cpp:139-152).
+int gce_set_reference_ascii(gce_engine *e, int32_t tid, const char *bases, int64_t n_bases) {
+    if (!e || tid < 0 || n_bases < 0 || (!bases && n_bases > 0)) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if ((size_t)tid >= e->ref_buf.size()) { e->ref_buf.resize(tid + 1); e->ref_ptr.resize(tid + 1, nullptr); e->ref_len.resize(tid + 1, 0); }
+    const size_t bytes = (size_t)((n_bases + 1) / 2);
+    HIPCHK(e->ref_buf[tid].ensure(bytes + 16));
+    HIPCHK(e->ref_ascii.ensure((size_t)n_bases + 16));
+    hipPointerAttribute_t attr; const bool is_dev = hipPointerGetAttributes(&attr, bases) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (n_bases) {
+        HIPCHK(hipMemcpyAsync(e->ref_ascii.p, bases, (size_t)n_bases, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+        const unsigned grid = (unsigned)std::min<uint64_t>((bytes + 255) / 256, 65535u * 4u);
+        hipLaunchKernelGGL(k_pack_reference, dim3(grid), dim3(256), 0, e->stream, (const char *)e->ref_ascii.p, n_bases, e->ref_buf[tid].as<uint8_t>());
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    e->ref_ptr[tid] = e->ref_buf[tid].as<uint8_t>(); e->ref_len[tid] = n_bases;
+    return GCE_OK;
+}
+
 int gce_reset(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
-    e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear();
+    e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear(); e->h_tick.clear();
     e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
-    e->have_mi = e->host_mode = e->device_mode = e->processed = false; e->n = 0;
+    e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = false; e->n = 0; e->n_out = 0;
+    return GCE_OK;
+}
+
+// The flush events of the whole stream (gencore.cpp:319-322), for shards cut inside a contig: see include/gencore_amd.h.
+int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid, const int32_t *ev_pos) {
+    if (!e || n_events < 0 || (n_events > 0 && (!ev_tid || !ev_pos))) return GCE_ERR_INVALID;
+    e->h_ev_tid.assign(ev_tid, ev_tid + n_events); e->h_ev_pos.assign(ev_pos, ev_pos + n_events);
+    e->have_events = true;
     return GCE_OK;
 }
 
 // Gencore::addToCluster for a whole batch (src/gencore.cpp:272,469): host buffers are staged, then uploaded by gce_process.
 int gce_submit(gce_engine *e, const gce_batch *b) {
     if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
-    if (e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
+    if (e->device_mode && !e->processed) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
     if (e->processed) gce_reset(e);
     e->host_mode = true;
     const int64_t n = b->n_reads;
     if (n == 0) return GCE_OK;
     if (!b->core || !b->qname_off || !b->qname || !b->cigar_off || !b->seq_off || !b->seq || !b->qual_off || !b->qual || !b->nm || !b->nm_type)
         return fail(e, GCE_ERR_INVALID, "null array in gce_batch");
-    const uint64_t q0 = e->h_qname.size(), c0 = e->h_cigar.size(), s0 = e->h_seq.size(), l0 = e->h_qual.size(), m0 = e->h_mi.size();
     const size_t old = e->h_core.size();
+    if (old > 0 && (b->tick != nullptr) != e->have_tick) return fail(e, GCE_ERR_INVALID, "gce_batch.tick must be given for every batch of a stream or for none");
+    const uint64_t q0 = e->h_qname.size(), c0 = e->h_cigar.size(), s0 = e->h_seq.size(), l0 = e->h_qual.size(), m0 = e->h_mi.size();
     e->h_core.insert(e->h_core.end(), b->core, b->core + n);
     e->h_nm.insert(e->h_nm.end(), b->nm, b->nm + n);
     e->h_nmt.insert(e->h_nmt.end(), b->nm_type, b->nm_type + n);
@@ -190,9 +224,11 @@ int gce_submit(gce_engine *e, const gce_batch *b) {
     if (b->cigar_words) e->h_cigar.insert(e->h_cigar.end(), b->cigar, b->cigar + b->cigar_words);
     e->h_seq.insert(e->h_seq.end(), b->seq, b->seq + b->seq_bytes);
     e->h_qual.insert(e->h_qual.end(), b->qual, b->qual + b->qual_bytes);
+    if (b->tick) { e->h_tick.insert(e->h_tick.end(), b->tick, b->tick + n); e->have_tick = true; }
     bool mi = b->mi && b->mi_off;
     if (mi && !e->have_mi) { e->h_mioff.assign(old, UINT64_MAX); e->have_mi = true; }
     if (mi) e->h_mi.insert(e->h_mi.end(), b->mi, b->mi + b->mi_bytes);
+    e->h_qoff.reserve(old + n); e->h_coff.reserve(old + n); e->h_soff.reserve(old + n); e->h_loff.reserve(old + n);
     for (int64_t i = 0; i < n; i++) {
         e->h_qoff.push_back(b->qname_off[i] + q0); e->h_coff.push_back(b->cigar_off[i] + c0);
         e->h_soff.push_back(b->seq_off[i] + s0); e->h_loff.push_back(b->qual_off[i] + l0);
@@ -207,6 +243,7 @@ int gce_submit_device(gce_engine *e, const gce_batch *b) {
     if (e->host_mode || e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_submit_device takes exactly one batch per gce_process");
     e->device_mode = true;
     e->dev_batch = *b;
+    e->have_tick = b->tick != nullptr;
     return GCE_OK;
 }
 
@@ -225,6 +262,7 @@ static int upload(gce_engine *e) {
         {&e->b_nmt, e->h_nmt.data(), e->h_nmt.size(), (const void **)&e->dev_batch.nm_type},
         {&e->b_mioff, e->h_mioff.data(), e->h_mioff.size() * 8, (const void **)&e->dev_batch.mi_off},
         {&e->b_mi, e->h_mi.data(), e->h_mi.size(), (const void **)&e->dev_batch.mi},
+        {&e->b_tick, e->h_tick.data(), e->h_tick.size() * 8, (const void **)&e->dev_batch.tick},
     };
     for (auto &it : items) {
         HIPCHK(it.d->ensure(it.bytes + 64));      // +64: string kernels may look one byte past a name
@@ -232,6 +270,7 @@ static int upload(gce_engine *e) {
         *it.dst = it.bytes ? it.d->p : nullptr;
     }
     if (!e->have_mi) { e->dev_batch.mi = nullptr; e->dev_batch.mi_off = nullptr; }
+    if (!e->have_tick) e->dev_batch.tick = nullptr;
     e->dev_batch.n_reads = (int64_t)e->h_core.size();
     e->dev_batch.qname_bytes = e->h_qname.size(); e->dev_batch.cigar_words = e->h_cigar.size();
     e->dev_batch.seq_bytes = e->h_seq.size(); e->dev_batch.qual_bytes = e->h_qual.size(); e->dev_batch.mi_bytes = e->h_mi.size();
@@ -242,21 +281,24 @@ static int upload(gce_engine *e) {
 static int read_si(gce_engine *e) {
     HIPCHK(hipMemcpyAsync(&e->h_si, e->si.p, sizeof(StreamInfo), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_si.err_key != ~0ull) { e->dev_error = -(int)(e->h_si.err_key & 0xFF); e->dev_error_read = (uint32_t)(e->h_si.err_key >> 8); }
     return GCE_OK;
 }
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// Every clusterByUMI of the stream (src/gencore.cpp:355 periodic, :409 end of file) + outputPair bookkeeping.
+// Every clusterByUMI of the stream (src/gencore.cpp:355 periodic, :409 end of file) + outputPair bookkeeping + the output order.
 int gce_process(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
     if (!e->host_mode && !e->device_mode) return fail(e, GCE_ERR_INVALID, "nothing submitted");
+    if (e->processed) return fail(e, GCE_ERR_INVALID, "gce_process called twice without a new submit (the stream was mutated in place)");
+    if (e->have_tick && !e->have_events) return fail(e, GCE_ERR_INVALID, "gce_batch.tick needs gce_set_flush_events");
     (void)hipSetDevice(e->prm.device);
     int rc;
     if (e->host_mode && (rc = upload(e)) != GCE_OK) return rc;
     const gce_batch &hb = e->dev_batch;
     const int64_t N = hb.n_reads;
-    e->n = N;
+    e->n = N; e->n_out = 0; e->out_seq_bytes = e->out_qual_bytes = 0; e->dev_error = 0; e->dev_error_read = 0;
     e->processed = true;
     memset(&e->timing, 0, sizeof e->timing);
     memset(&e->h_si, 0, sizeof e->h_si);
@@ -265,7 +307,7 @@ int gce_process(gce_engine *e) {
 
     DevBatch b{}; b.n = N; b.core = hb.core; b.qname_off = hb.qname_off; b.qname = hb.qname; b.cigar_off = hb.cigar_off; b.cigar = hb.cigar;
     b.seq_off = hb.seq_off; b.seq = hb.seq; b.qual_off = hb.qual_off; b.qual = hb.qual; b.nm = hb.nm; b.nm_type = hb.nm_type;
-    b.mi_off = hb.mi_off; b.mi = hb.mi;
+    b.mi_off = hb.mi_off; b.mi = hb.mi; b.tick = e->have_tick ? hb.tick : nullptr;
 
     // reference + params to the device
     const int nref = (int)e->ref_ptr.size();
@@ -301,14 +343,14 @@ int gce_process(gce_engine *e) {
     }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
-    p.tick_offset = e->prm.tick_offset; p.trailing_flush = e->prm.trailing_flush;
+    p.tick_offset = e->have_tick ? 0 : e->prm.tick_offset; p.trailing_flush = e->have_tick ? 0 : e->prm.trailing_flush;
     p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
 
     // ---- allocations that only depend on N
     Work w{};
     const int64_t n_chunks = (N + CHUNK - 1) / CHUNK;
     w.n_chunks = n_chunks;
-    const int64_t max_events = (p.tick_offset % p.period + N) / p.period + 2;
+    const int64_t max_events = e->have_tick ? (int64_t)e->h_ev_tid.size() + 2 : (p.tick_offset % p.period + N) / p.period + 2;
     w.max_events = (int)max_events;
     // buckets: 1.25 x reads (worst case, every read its own cluster, still probes at load 0.8; typical load is a few percent).
     // Every per-step pass over the table (clear, count scan, offsets) is proportional to T, so T is not rounded to a power of two.
@@ -317,7 +359,7 @@ int gce_process(gce_engine *e) {
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
     ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDesc)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
-    ENS(out_flag, n1); ENS(qname_src, n1 * 4); ENS(nm_new, n1 * 4); ENS(fr, n1 * 2); ENS(rr, n1 * 2); ENS(mate, n1 * 4); ENS(out_index, n1 * 4);
+    ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
     ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
     ENS(table, T * 8); ENS(tcount, T * 4); ENS(toff, T * 4);
@@ -328,8 +370,7 @@ int gce_process(gce_engine *e) {
     ENS(scan_part, (size_t)(nblk_T > 2 * nblk_N ? nblk_T : 2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
     w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
-    w.out_flag = e->out_flag.as<uint8_t>(); w.qname_src = e->qname_src.as<uint32_t>(); w.nm_new = e->nm_new.as<int32_t>();
-    w.fr = e->fr.as<int16_t>(); w.rr = e->rr.as<int16_t>(); w.mate = e->mate.as<uint32_t>(); w.out_index = e->out_index.as<uint32_t>();
+    w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
     w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
     w.table = e->table.as<uint64_t>(); w.tcount = e->tcount.as<uint32_t>(); w.toff = e->toff.as<uint32_t>();
@@ -338,18 +379,26 @@ int gce_process(gce_engine *e) {
     w.grp_begin = e->grp_begin.as<uint32_t>(); w.grp_n = e->grp_n.as<uint32_t>();
     w.scan_part = e->scan_part.as<uint64_t>(); w.si = e->si.as<StreamInfo>();
 
-    StreamInfo init{}; init.first_unmapped = NONE32;
+    StreamInfo init{}; init.first_unmapped = NONE32; init.err_key = ~0ull;
+    if (e->have_tick) { init.n_events = init.n_events_a = (int)e->h_ev_tid.size(); }
     HIPCHK(hipMemcpyAsync(e->si.p, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(e->table.p, 0xFF, T * 8, e->stream));
-    HIPCHK(hipMemsetAsync(e->tcount.p, 0, T * 4, e->stream));
+    if (e->have_tick && !e->h_ev_tid.empty()) {
+        HIPCHK(hipMemcpyAsync(e->ev_tid.p, e->h_ev_tid.data(), e->h_ev_tid.size() * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->ev_pos.p, e->h_ev_pos.data(), e->h_ev_pos.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
     hipStream_t s = e->stream;
     HIPCHK(hipEventRecord(e->ev[EV_START], s));
+    HIPCHK(hipMemsetAsync(e->table.p, 0xFF, T * 8, s));
+    HIPCHK(hipMemsetAsync(e->tcount.p, 0, T * 4, s));
+    HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
     if (N > 0) {
-        // ---- prescan + tick scan + flush events
+        // ---- prescan + tick scan + flush events (the latter two come with the batch for key-range shards)
         int cpb = (int)((n_chunks + 32767) / 32768); if (cpb < 1) cpb = 1;
         hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
-        hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
-        hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
+        if (!e->have_tick) {
+            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
+            hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
+        }
     }
     HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
     if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)cdiv(n_chunks, CL_U)), dim3(CHUNK), 0, s, b, p, w);
@@ -370,27 +419,24 @@ int gce_process(gce_engine *e) {
     w.cl_npairs = e->cl_npairs.as<uint32_t>(); w.cl_ngroups = e->cl_ngroups.as<uint32_t>(); w.cl_gbase = e->cl_gbase.as<uint32_t>();
     w.cl_nresult = e->cl_nresult.as<uint32_t>(); w.cl_hasumi = e->cl_hasumi.as<uint8_t>();
     uint32_t NG = 0;
-    if (C > 0 && e->h_si.error == 0) {
-        HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score recognises pair slots by gpl != NONE
-        static const bool pair_halves = !(getenv("GCE_PAIR2") && atoi(getenv("GCE_PAIR2")) == 0);   // 0: one wave per cluster throughout
-        if (pair_halves) {
-            // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
-            // compacted by the scan kernels (never one shared append counter)
-            ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4);
-            w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>();
-            HIPCHK(hipMemsetAsync(e->pf_flag.p, 0, c1, s)); HIPCHK(hipMemsetAsync(e->pq_flag.p, 0, c1, s));
-            const unsigned nbc = cdiv(C, SCAN_TILE);
-            auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
-                hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
-                hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, count, (unsigned long long *)nullptr);
-                hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, (const uint64_t *)w.scan_part, list);
-            };
-            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
-            compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
-            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
-            compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
-            hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
-        } else hipLaunchKernelGGL(k_pairing_fast, dim3(cdiv(C, WAVES_PER_BLOCK) < 65535u * 16u ? cdiv(C, WAVES_PER_BLOCK) : 65535u * 16u), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr);
+    if (C > 0 && e->dev_error == 0) {
+        HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score2 recognises pair slots by gpl != NONE
+        // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
+        // compacted by the scan kernels (never one shared append counter)
+        ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4);
+        w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(e->pf_flag.p, 0, c1, s)); HIPCHK(hipMemsetAsync(e->pq_flag.p, 0, c1, s));
+        const unsigned nbc = cdiv(C, SCAN_TILE);
+        auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
+            hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
+            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, count, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, (const uint64_t *)w.scan_part, list);
+        };
+        hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
+        compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
+        hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
+        compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
+        hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
         hipLaunchKernelGGL(k_pairing_slow<2>, dim3(1024), dim3(256), 0, s, b, p, w);
@@ -404,110 +450,119 @@ int gce_process(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(fb_list, g1 * 4); ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
-    ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4);
-    w.fb_list = e->fb_list.as<uint32_t>(); w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
+    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4); ENS(rp_nm, g1 * 8); ENS(rp_qsl, g1 * 4); ENS(rp_qsr, g1 * 4);
+    w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
     w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
-    if (NG > 0 && e->h_si.error == 0) {
-        if (e->fused_groups) HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
+    w.rp_nm = e->rp_nm.as<int32_t>(); w.rp_qsl = e->rp_qsl.as<uint32_t>(); w.rp_qsr = e->rp_qsr.as<uint32_t>();
+    if (NG > 0 && e->dev_error == 0) {
         HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
         HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
+        HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
         hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
-        if (e->fused_groups) {
-            // fused LDS group kernels, three LDS tiers by pairs per group: (0,8], (8,16], (16,32]; larger groups go to fb_list
-            hipLaunchKernelGGL((k_group_fused<8, 4>), dim3(cdiv(NG, 4)), dim3(256), 0, s, b, p, w, NG, 0u, 0);
-            hipLaunchKernelGGL((k_group_fused<16, 2>), dim3(cdiv(NG, 2)), dim3(128), 0, s, b, p, w, NG, 8u, 0);
-            hipLaunchKernelGGL((k_group_fused<32, 1>), dim3(NG), dim3(64), 0, s, b, p, w, NG, 16u, 1);
-            if ((rc = read_si(e)) != GCE_OK) return rc;
-            HIPCHK(hipGetLastError());
-        } else {
-            e->h_si.n_fb = NG;                                       // every group, in order: the list itself is not materialised
+        hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 0);
+        HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        {   // compact the flagged sides into gen_list
+            const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
+            hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
+            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
         }
-        if (e->h_si.n_fb > 0 && e->h_si.error == 0) {              // global-memory path
-            const uint32_t nfb = e->h_si.n_fb;
-            static const bool score_units = !(getenv("GCE_SCORE2") && atoi(getenv("GCE_SCORE2")) == 0);        // 0: the 8-lanes-per-pair kernel
-            if (score_units) hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
-            else hipLaunchKernelGGL(k_score, dim3(cdiv(N, WAVES_PER_BLOCK * SC_PPW)), dim3(256), 0, s, b, p, w, (uint32_t)N, e->fused_groups ? 1 : 0);
-            HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-            static const bool lean_pairs = !(getenv("GCE_LEAN2") && atoi(getenv("GCE_LEAN2")) == 0);    // 0: one wave per side instead of per group
-            if (lean_pairs) hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, nfb, e->fused_groups ? 0 : 1);
-            else hipLaunchKernelGGL(k_consensus_lean, dim3(cdiv(2ull * nfb, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, 2u * nfb, e->fused_groups ? 0 : 1);
-            {   // compact the flagged sides into gen_list
-                const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
-                hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
-                hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
-                hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
-            }
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
-            hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
-        } else HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
         hipLaunchKernelGGL(k_finish, dim3(cdiv(C, 64 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
     } else { HIPCHK(hipEventRecord(e->ev[EV_SCORE], s)); HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s)); }
-    if (N > 0 && e->h_si.error == 0) {
-        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);
+    if (N > 0 && e->dev_error == 0) hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);
+    HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
+    // ---- the output set: emitted reads in bamComp order (gencore.h:19-47) as one compact table.  Capacities are worst case
+    //      (every read emitted): nothing here needs a host round trip.
+    OutTable o{};
+    if (N > 0 && e->dev_error == 0) {
+        const size_t seq_cap = hb.seq_bytes + 16 * n1 + 64, qual_cap = hb.qual_bytes + 16 * n1 + 64;
+        ENS(o_src, n1 * 4); ENS(o_kind, n1); ENS(o_qsrc, n1 * 4); ENS(o_nm, n1 * 4); ENS(o_fr, n1 * 2); ENS(o_rr, n1 * 2); ENS(o_mate, n1 * 4); ENS(o_rowof, n1 * 4);
+        ENS(o_units, n1 * 8); ENS(o_soff, n1 * 8); ENS(o_qoff, n1 * 8); ENS(o_seq, seq_cap); ENS(o_qual, qual_cap);
+        o.src = e->o_src.as<uint32_t>(); o.kind = e->o_kind.as<uint8_t>(); o.qname_src = e->o_qsrc.as<uint32_t>(); o.nm_new = e->o_nm.as<int32_t>();
+        o.fr = e->o_fr.as<int16_t>(); o.rr = e->o_rr.as<int16_t>(); o.mate = e->o_mate.as<uint32_t>(); o.row_of = e->o_rowof.as<uint32_t>();
+        o.units = e->o_units.as<uint64_t>(); o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
         hipLaunchKernelGGL(k_flag_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, w.scan_part);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_out, (unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_flag_apply, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, (const uint64_t *)w.scan_part, w.out_index);
+        const unsigned og = std::min<unsigned>(cdiv(n1, 256), 8192u);
+        hipLaunchKernelGGL(k_out_order, dim3(og), dim3(256), 0, s, b, w, o);
+        hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, b, w, o);
+        hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)o.units, (const unsigned long long *)&w.si->n_out, w.scan_part);
+        hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_out, &w.si->out_units);
+        hipLaunchKernelGGL(k_out_offsets, dim3(nblk_N), dim3(256), 0, s, o, (const unsigned long long *)&w.si->n_out, (const uint64_t *)w.scan_part);
+        hipLaunchKernelGGL(k_out_gather, dim3(std::min<unsigned>(cdiv(n1, 16), 16384u)), dim3(256), 0, s, b, w, o);
     }
-    HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
+    HIPCHK(hipEventRecord(e->ev[EV_OUTPUT], s));
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
     e->h_si.n_groups = NG;
     float ms = 0;
     auto el = [&](int a, int c) { ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[c]); return (double)ms; };
-    e->timing.total_ms = el(EV_START, EV_FINISH);
+    e->timing.total_ms = el(EV_START, EV_OUTPUT);
     e->timing.prescan_ms = el(EV_START, EV_PRESCAN); e->timing.cluster_ms = el(EV_PRESCAN, EV_CLUSTER); e->timing.csr_ms = el(EV_CLUSTER, EV_CSR);
     e->timing.pairing_ms = el(EV_CSR, EV_PAIRING); e->timing.score_ms = el(EV_PAIRING, EV_SCORE); e->timing.consensus_ms = el(EV_SCORE, EV_CONSENSUS);
-    e->timing.finish_ms = el(EV_CONSENSUS, EV_FINISH);
-    e->timing.n_clusters = C; e->timing.n_groups = NG; e->timing.n_pairs = 0;
-    if (e->h_si.error != 0) {
-        char buf[160]; snprintf(buf, sizeof buf, "%s (read %u)", gce_status_message(e->h_si.error), e->h_si.error_read);
-        return fail(e, e->h_si.error, buf);
+    e->timing.finish_ms = el(EV_CONSENSUS, EV_FINISH); e->timing.output_ms = el(EV_FINISH, EV_OUTPUT);
+    e->timing.n_clusters = C; e->timing.n_groups = NG;
+    if (e->dev_error != 0) {
+        char buf[160]; snprintf(buf, sizeof buf, "%s (read %u)", gce_status_message(e->dev_error), e->dev_error_read);
+        return fail(e, e->dev_error, buf);
     }
+    e->n_out = (int64_t)e->h_si.n_out;
+    e->out_seq_bytes = (size_t)(e->h_si.out_units >> 32) * 16; e->out_qual_bytes = (size_t)(e->h_si.out_units & 0xFFFFFFFFull) * 16;
+    e->timing.n_pairs = (int64_t)e->h_si.n_pairs_total;
     return GCE_OK;
 }
 
 static void fill_stats(gce_stats *dst, const long long *src) { memcpy(dst, src, sizeof(gce_stats)); }
 
 int gce_result_device(gce_engine *e, gce_result *out) {
-    if (!e || !out || !e->processed) return GCE_ERR_INVALID;
+    if (!e || !out || !e->processed || e->dev_error) return GCE_ERR_INVALID;
     memset(out, 0, sizeof *out);
-    out->n_reads = e->n; out->out_flag = e->out_flag.as<uint8_t>(); out->qname_src = e->qname_src.as<uint32_t>(); out->nm_new = e->nm_new.as<int32_t>();
-    out->fr = e->fr.as<int16_t>(); out->rr = e->rr.as<int16_t>(); out->mate = e->mate.as<uint32_t>();
-    out->seq = e->dev_batch.seq; out->qual = e->dev_batch.qual; out->n_out = (int64_t)e->h_si.n_out; out->out_index = e->out_index.as<uint32_t>();
+    out->n_reads = e->n; out->n_out = e->n_out;
+    out->src = e->o_src.as<uint32_t>(); out->kind = e->o_kind.as<uint8_t>(); out->qname_src = e->o_qsrc.as<uint32_t>(); out->nm_new = e->o_nm.as<int32_t>();
+    out->fr = e->o_fr.as<int16_t>(); out->rr = e->o_rr.as<int16_t>(); out->mate = e->o_mate.as<uint32_t>();
+    out->seq_off = e->o_soff.as<uint64_t>(); out->qual_off = e->o_qoff.as<uint64_t>(); out->seq = e->o_seq.as<uint8_t>(); out->qual = e->o_qual.as<uint8_t>();
+    out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
     return GCE_OK;
 }
 
-// Draining csPairs into Gencore::outputPair (src/gencore.cpp:356-360,410-414): result table copied to host memory.
+// Draining csPairs into Gencore::outputPair (src/gencore.cpp:356-360,410-414): the table of emitted records copied to host memory.
 int gce_drain(gce_engine *e, gce_result *out) {
-    if (!e || !out || !e->processed) return GCE_ERR_INVALID;
+    if (!e || !out || !e->processed || e->dev_error) return GCE_ERR_INVALID;
     (void)hipSetDevice(e->prm.device);
-    const size_t n = (size_t)e->n;
-    e->r_flag.resize(n); e->r_qsrc.resize(n); e->r_nm.resize(n); e->r_fr.resize(n); e->r_rr.resize(n); e->r_mate.resize(n);
-    e->r_oidx.resize((size_t)e->h_si.n_out);
-    e->r_seq.resize(e->dev_batch.seq_bytes); e->r_qual.resize(e->dev_batch.qual_bytes);
+    const size_t n = (size_t)e->n_out;
+    e->r_src.resize(n); e->r_kind.resize(n); e->r_qsrc.resize(n); e->r_nm.resize(n); e->r_fr.resize(n); e->r_rr.resize(n); e->r_mate.resize(n);
+    e->r_soff.resize(n); e->r_qoff.resize(n); e->r_seq.resize(e->out_seq_bytes); e->r_qual.resize(e->out_qual_bytes);
     hipStream_t s = e->stream;
     if (n) {
-        HIPCHK(hipMemcpyAsync(e->r_flag.data(), e->out_flag.p, n, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(e->r_qsrc.data(), e->qname_src.p, n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(e->r_nm.data(), e->nm_new.p, n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(e->r_fr.data(), e->fr.p, n * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(e->r_rr.data(), e->rr.p, n * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(e->r_mate.data(), e->mate.p, n * 4, hipMemcpyDeviceToHost, s));
-        if (!e->r_oidx.empty()) HIPCHK(hipMemcpyAsync(e->r_oidx.data(), e->out_index.p, e->r_oidx.size() * 4, hipMemcpyDeviceToHost, s));
-        if (!e->r_seq.empty()) HIPCHK(hipMemcpyAsync(e->r_seq.data(), e->dev_batch.seq, e->r_seq.size(), hipMemcpyDeviceToHost, s));
-        if (!e->r_qual.empty()) HIPCHK(hipMemcpyAsync(e->r_qual.data(), e->dev_batch.qual, e->r_qual.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_src.data(), e->o_src.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_kind.data(), e->o_kind.p, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_qsrc.data(), e->o_qsrc.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_nm.data(), e->o_nm.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_fr.data(), e->o_fr.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_rr.data(), e->o_rr.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_mate.data(), e->o_mate.p, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_soff.data(), e->o_soff.p, n * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(e->r_qoff.data(), e->o_qoff.p, n * 8, hipMemcpyDeviceToHost, s));
+        if (!e->r_seq.empty()) HIPCHK(hipMemcpyAsync(e->r_seq.data(), e->o_seq.p, e->r_seq.size(), hipMemcpyDeviceToHost, s));
+        if (!e->r_qual.empty()) HIPCHK(hipMemcpyAsync(e->r_qual.data(), e->o_qual.p, e->r_qual.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     memset(out, 0, sizeof *out);
-    out->n_reads = e->n; out->out_flag = e->r_flag.data(); out->qname_src = e->r_qsrc.data(); out->nm_new = e->r_nm.data();
-    out->fr = e->r_fr.data(); out->rr = e->r_rr.data(); out->mate = e->r_mate.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
-    out->n_out = (int64_t)e->h_si.n_out; out->out_index = e->r_oidx.data();
+    out->n_reads = e->n; out->n_out = e->n_out;
+    out->src = e->r_src.data(); out->kind = e->r_kind.data(); out->qname_src = e->r_qsrc.data(); out->nm_new = e->r_nm.data();
+    out->fr = e->r_fr.data(); out->rr = e->r_rr.data(); out->mate = e->r_mate.data();
+    out->seq_off = e->r_soff.data(); out->qual_off = e->r_qoff.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
+    out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
     return GCE_OK;
 }

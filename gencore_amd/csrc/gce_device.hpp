@@ -23,6 +23,7 @@ struct DevBatch {
     const uint64_t *qual_off;  uint8_t *qual;
     const int32_t *nm; const uint8_t *nm_type;
     const uint64_t *mi_off; const char *mi;
+    const uint64_t *tick;             // optional: global tick of every clustered read (key-range shards), else nullptr
 };
 
 struct DevParams {
@@ -70,15 +71,15 @@ static_assert(sizeof(ReadDesc) == 48, "ReadDesc must stay 48 bytes");
 struct StreamInfo {
     unsigned long long n_clustered;      // number of clustered reads (ticks)
     unsigned int first_unmapped;         // index of the first unmapped read (U) or NONE32
-    int error;                           // first gce_status error raised on device (0 = none)
-    unsigned int error_read;
+    unsigned long long err_key;          // min over raised errors of (read index << 8 | -gce_status); ~0 = none
     int n_events;                        // E: flush events inside this slice
     int n_events_a;                      // E_A: events whose read index < U
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
-    unsigned int n_fb;                   // groups handed from the fused LDS kernel to the global-memory path
-    unsigned int pad1;
+    unsigned int pad0, pad1;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
+    unsigned long long n_pairs_total;    // pairs over all processed clusters
+    unsigned long long out_units;        // size of the compact output blobs in 16-byte units: bases << 32 | qualities
     unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one
     unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
@@ -86,8 +87,10 @@ struct StreamInfo {
     long long post[GCE_STATS_WORDS];
 };
 
+// Fatal conditions of the path: the reference exits on the first one it meets; the engine reports the one on the EARLIEST read
+// (deterministic whatever the scheduling: one 64-bit atomicMin on read index << 8 | code).
 __device__ __forceinline__ void raise_error(StreamInfo *si, int code, uint32_t read) {
-    if (atomicCAS(&si->error, 0, code) == 0) si->error_read = read;
+    atomicMin(&si->err_key, ((unsigned long long)read << 8) | (unsigned long long)((-code) & 0xFF));
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -19,6 +19,10 @@
 #define CHUNK 256            // reads per prescan/cluster block
 #define WAVES_PER_BLOCK 4
 
+// what Gencore::outputPair hands on for one emitted record (written once, where the record is emitted)
+struct __attribute__((aligned(16))) OutRec { uint32_t qname_src, mate; int16_t nm_new, fr, rr; uint16_t pad; };
+static_assert(sizeof(OutRec) == 16, "OutRec must stay 16 bytes");
+
 struct Work {
     // per read
     uint8_t *cls;
@@ -27,9 +31,9 @@ struct Work {
     uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
     uint32_t *slot, *rank;
     int8_t *score;                       // parallel to qual
-    // outputs per read
-    uint8_t *out_flag; uint32_t *qname_src; int32_t *nm_new; int16_t *fr, *rr; uint32_t *mate;
-    uint32_t *out_index;
+    // outputs per read: out_flag for every read (0 = not emitted, 1 = outputPair, 2 = pass-through); orec only where out_flag == 1
+    uint8_t *out_flag; OutRec *orec;
+    uint32_t *out_index;                 // emitted reads, ascending
     // tick scan
     uint32_t *chunk_cnt, *chunk_base; int64_t n_chunks;
     // events
@@ -48,8 +52,10 @@ struct Work {
     uint8_t *pq_flag; uint32_t *pq_list;      // ... and the quarter-wave kernel to the half-wave one
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
                                           // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
-    uint32_t *fb_list; uint8_t *slot_flag;   // groups the fused LDS kernel handed to the global-memory path; their pair slots
+    uint8_t *slot_flag;                   // pair slots of the groups whose sides were handed on (k_score2 scores only those)
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
+    int32_t *rp_nm;                       // [2 x groups] NM byte patched into the side's template (group.cpp:570), -1 = untouched
+    uint32_t *rp_qsl, *rp_qsr;            // per group: copyQName source of the left / right result record
     // generic scan scratch
     uint64_t *scan_part;
     StreamInfo *si;
@@ -97,8 +103,7 @@ __global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work
             if (mism > 0) st[5] += 1;
             if (k.tid < 0 || k.pos < 0) { if ((unsigned)i < first_unm) first_unm = (unsigned)i; }
             w.cls[i] = c;
-            w.out_flag[i] = (c == CLS_BYPASS) ? 2 : 0;
-            w.qname_src[i] = (uint32_t)i; w.nm_new[i] = -1; w.fr[i] = -1; w.rr[i] = -1; w.mate[i] = NONE32;
+            if (c == CLS_BYPASS) w.out_flag[i] = 2;                            // (out_flag is cleared by a memset; nothing else is initialised per read)
             if (c == CLS_CLUSTERED) {
                 ReadDesc d;
                 d.so = b.seq_off[i]; d.qo = b.qual_off[i]; d.pos = k.pos; d.lq = k.l_qseq; d.isize = k.isize; d.nc = k.n_cigar; d.tid16 = (uint16_t)((uint32_t)k.tid < 0xFFFFu ? k.tid : 0xFFFF);
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         if (cl[u]) {
             unsigned int inblock = lanes_below(m[u]) + 1;
             for (int q = 0; q < wv; q++) inblock += s_cnt[u][q];
-            const long long tick = p.tick_offset + (long long)w.chunk_base[blockIdx.x * CL_U + u] + inblock;   // the reference's `tick` after ++
+            // the reference's `tick` after ++ (gencore.cpp:319-320): counted here, or handed in with the batch (key-range shards)
+            const long long tick = b.tick ? (long long)b.tick[idx[u]] : p.tick_offset + (long long)w.chunk_base[blockIdx.x * CL_U + u] + inblock;
             e_[u] = (int)((tick - 1) / per - p.tick_offset / per);                          // flush events before this read
             const bool seg_b = (first_unm != NONE32) && ((unsigned)idx[u] > first_unm);
             key[u] = d_key(k[u], p);
@@ -864,48 +870,11 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 // Pair::computeScore (pair.cpp:88-172).  gpl/gpr are pre-filled with NONE32, so a slot is a pair iff gpl != NONE32.
 // Pairs of groups that never reach a vote get scores too; nothing reads them and no qual is touched for a mate-less
 // pair, so the result is identical to the reference's lazy evaluation.
-// k_score (below) is the first formulation, kept selectable (GCE_SCORE2=0): 8 lanes per pair, 8 pairs per wave.  The default
-// is k_score2 further down: one lane per pair for the dependent chain, overlap work dealt to the lanes in 8-base units.
-#define SC_LPP 8             // lanes per pair
-#define SC_PPW (64 / SC_LPP) // pairs per wave
 // Only the mate-overlap region needs work: outside it a score is qual2score(qual) of an untouched qual, which the vote kernels
-// derive on the fly (d_q2s4_biased / d_score_at).  Per pair this kernel writes the two reads' patch descriptors and, for
+// derive on the fly (d_q2s4_biased / d_score_at).  Per pair the kernel writes the two reads' patch descriptors and, for
 // overlapping pairs, the overlap scores (match: qual2score((lq+rq)/2)+4; mismatch: quals rewritten to max(0, own - mate),
-// the stronger side gets qual2score(|diff|)-3, the other 0).  8 lanes per pair, one overlap base per lane and step.
-__global__ __launch_bounds__(256) void k_score(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
-    const int lane = lane_id(), sl = lane & (SC_LPP - 1), qd = lane / SC_LPP, wv = threadIdx.x >> 6;
-    const uint32_t slot = (blockIdx.x * WAVES_PER_BLOCK + wv) * SC_PPW + qd;
-    if (slot >= n_slots) return;
-    const uint32_t L = w.gpl[slot], R = w.gpr[slot];
-    if (L == NONE32) return;
-    if (use_flags && !w.slot_flag[slot]) return;                               // only pairs of groups on the global-memory path
-    if (R == NONE32) { if (sl == 0) w.spatch[L] = GCE_PATCH_CONST; return; }   // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
-    const ReadDesc lk = load_desc(w.rdesc, L), rk = load_desc(w.rdesc, R);
-    if (!(lk.ml > 0 && rk.ml > 0)) { if (sl == 0) { w.spatch[L] = GCE_PATCH_CONST; w.spatch[R] = GCE_PATCH_CONST; } return; }
-    int dis = rk.pos - lk.pos, lstart, rstart, cmp;                            // pair.cpp:108-120
-    if (dis >= 0) { lstart = lk.mo + dis; rstart = rk.mo; cmp = min(lk.ml - dis, rk.ml); }
-    else { lstart = lk.mo; rstart = rk.mo - dis; cmp = min(lk.ml, rk.ml + dis); }
-    if (cmp <= 0) return;                                                      // no overlap: both reads are pure qual2score
-    if (lk.lq > 65535 || rk.lq > 65535) { raise_error(w.si, GCE_ERR_INVALID, L); return; }
-    if (sl == 0) { w.spatch[L] = (uint32_t)lstart | ((uint32_t)cmp << 16); w.spatch[R] = (uint32_t)rstart | ((uint32_t)cmp << 16); }
-    const uint8_t *lseq = b.seq + lk.so, *rseq = b.seq + rk.so;
-    uint8_t *lq = b.qual + lk.qo, *rq = b.qual + rk.qo;
-    int8_t *ls = w.score + lk.qo, *rs = w.score + rk.qo;
-    for (int i = sl; i < cmp; i += SC_LPP) {
-        const int l = lstart + i, r = rstart + i;
-        const int ql = lq[l], qr = rq[r];
-        if (d_nib(lseq, l) == d_nib(rseq, r)) {                               // pair.cpp:148-154
-            const int sc = d_qual2score(p, ((ql + qr) / 2) & 0xFF) + 4 + p.score_bias;
-            ls[l] = (int8_t)sc; rs[r] = (int8_t)sc;
-        } else {                                                              // pair.cpp:155-168: quals rewritten in place
-            lq[l] = (uint8_t)max(0, ql - qr); rq[r] = (uint8_t)max(0, qr - ql);
-            if (ql >= qr) { ls[l] = (int8_t)(d_qual2score(p, ql - qr) - 3 + p.score_bias); rs[r] = (int8_t)p.score_bias; }
-            else { ls[l] = (int8_t)p.score_bias; rs[r] = (int8_t)(d_qual2score(p, qr - ql) - 3 + p.score_bias); }
-        }
-    }
-}
-
-// Pair::computeScore, second formulation: ONE LANE PER PAIR for the dependent part (slot -> reads -> descriptors -> overlap
+// the stronger side gets qual2score(|diff|)-3, the other 0).
+// ONE LANE PER PAIR for the dependent part (slot -> reads -> descriptors -> overlap
 // window and patch descriptors: 64 pairs share each round trip instead of 8), then the wave's overlap work is cut into units of
 // 8 bases and dealt evenly to the lanes (half of the pairs have no overlap, a few have a long one): unit -> pair through a small
 // LDS map, the pair's fields through ds_bpermute.  A unit costs one 8-byte load per array and side and one 8-byte score store
@@ -1095,7 +1064,7 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
 // Scratch (cluster-local arrays that are dead after k_pairing): left side uses sorted/pl/pr, right side pg/pu/members
 // for containedBy / voters / lenDiff (the two sides of a group may run concurrently on different waves).
 __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left,
-                                   uint32_t *tally, int lane) {
+                                   uint32_t *tally, int lane, int32_t *nm_slot) {
     const uint32_t *side = is_left ? w.gpl : w.gpr;
     // ---- low-complexity skip for very deep groups (group.cpp:142-175)
     if ((int)np > p.skip_low_complexity_thr) {
@@ -1324,7 +1293,7 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         if (minc != 0) {                                                      // group.cpp:528-573
             if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
             else if (minc > 5) restore = true;
-            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) *nm_slot = nn; }
         }
         if (!restore) {
 #pragma unroll
@@ -1348,7 +1317,7 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         if (minc != 0) {
             if (b.nm_type[out] == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
             else if (minc > 5) restore = true;
-            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+            else if (lane == 0) { int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) *nm_slot = nn; }
         }
         if (!restore) {
             for (int bb = 0; bb < nbytes; bb += 64) {
@@ -1385,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p,
         uint32_t e = w.slow_list[idx], gi = e >> 1; bool is_left = !(e & 1);
         uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
         uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
-        uint32_t out = side_consensus(b, p, w, begin, np, is_left, s_tally[wv], lane);
+        uint32_t out = side_consensus(b, p, w, begin, np, is_left, s_tally[wv], lane, w.rp_nm + e);
         if (lane == 0) { if (is_left) w.rp_left[gi] = out; else w.rp_right[gi] = out; }
         WAVE_SYNC();
     }
@@ -1543,10 +1512,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
-// LEAN = the instantiation for the usual group side: every read carries the same single-op CIGAR and length ("150M" x depth)
-// and the packed-byte vote applies.  All CIGAR walking, per-voter range checks and the generic column loop are compiled out;
-// a side that does not qualify is flagged (gen_flag -> gen_list) and taken by the full instantiation in a second launch.
-template <bool LEAN>
+// This is the kernel behind the group kernel (gce_vote.hpp): it takes the group sides that one flags (gen_flag -> gen_list).
 __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
@@ -1568,7 +1534,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         patch = w.spatch[rd];
         const ReadDesc k = load_desc(w.rdesc, rd);
         pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen; tid16 = k.tid16;
-        if (!LEAN && (nc > 1 || (nc == 1 && cig_op(c0) != 0))) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
+        if ((nc > 1 || (nc == 1 && cig_op(c0) != 0))) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
     }
     const unsigned long long hmask = __ballot(has);
     if (!hmask) { if (lane == 0) rp_out[gi] = NONE32; return; }              // no read on this side: "no majority" / out == NULL
@@ -1585,9 +1551,8 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const int first_has = __ffsll((long long)hmask) - 1;
     const uint32_t c0f = (uint32_t)rl32((int)c0, first_has); const int lqf = rl32(lq, first_has);
     const bool uniform = !__any(has && (nc != 1 || c0 != c0f || lq != lqf)) && (is_left || left_mode);
-    if (LEAN && !uniform) { if (lane == 0) w.gen_flag[gi * 2 + (is_left ? 0 : 1)] = 1; return; }
     int best, bc;
-    if (LEAN || uniform) { best = first_has; bc = __popcll(hmask); }
+    if (uniform) { best = first_has; bc = __popcll(hmask); }
     else {
         int cb = has ? 1 : 0;
         for (unsigned long long m = hmask; m; m &= m - 1) {
@@ -1611,14 +1576,14 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     const uint32_t *ocig = b.cigar + o_cigo;
     // ---- voters and lenDiff (group.cpp:287-313,339-348)
     bool take = false; int ld = 0;
-    if (LEAN || uniform) take = has;                                          // identical CIGARs: every read votes, lenDiff 0
+    if (uniform) take = has;                                          // identical CIGARs: every read votes, lenDiff 0
     else if (has) {
         take = lane == best || part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, left_mode);
         if (take) { ld = lq - o_lq; if (ld != 0 && pos == o_pos && part_of_fast(o_c0, o_nc, ocig, c0, nc, b.cigar + cigo, true)) ld = 0; }
     }
     const unsigned long long vmask = __ballot(take);
     int len = o_lq;
-    if (!LEAN && o_nc == 0) len = wave_min(take ? lq : 0x7FFFFFFF);           // group.cpp:354-360
+    if (o_nc == 0) len = wave_min(take ? lq : 0x7FFFFFFF);           // group.cpp:354-360
     const int nbytes = (len + 1) >> 1;
     if (nbytes > 256) {                                                       // very long template: generic kernel
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
@@ -1641,11 +1606,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     //      base unchanged, qual = max qual.  Everything else is queued for the full 16-bin rule cascade (pass B).
     const int accept_score = max(p.base_score_req, 1);
     int n_cplx = 0; bool odd = false;
-    const bool even_ld = LEAN || left_mode || !__any(take && (ld & 1));      // every voter's columns stay byte aligned
+    const bool even_ld = left_mode || !__any(take && (ld & 1));      // every voter's columns stay byte aligned
     const int nvot = __popcll(vmask);
     const bool swar_ok = even_ld && len <= 256 && nvot * (p.score_max + p.score_bias) <= 255 && p.q2s_swar_ok && accept_score + nvot * p.score_bias <= 255;
-    if (LEAN && !swar_ok) { if (lane == 0) w.gen_flag[gi * 2 + (is_left ? 0 : 1)] = 1; return; }
-    if (LEAN || swar_ok) {
+    if (swar_ok) {
         // SWAR form: one lane = 4 consecutive columns = 2 packed-base bytes + 4 quals + 4 scores, i.e. three loads per voter.
         //   unanimity  : XOR of the voter's two base bytes with the template's, OR-accumulated (a zero nibble = all agree)
         //   score sum  : packed byte add (scores are stored biased >= 0 and nv * max < 256, so bytes never carry)
@@ -1671,11 +1635,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 s16[u] = t16; q4[u] = 0; sc4[u] = 0; vm[u] = 0;
                 if (vv[u] >= 0) {                                              // wave-uniform
                     const int v = vv[u];
-                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = (LEAN || left_mode) ? 0 : rl32(ld, v), vlq = LEAN ? len : rl32(lq, v);
+                    const uint64_t vso = rl64(so, v), vqo = rl64(qo, v); const int vld = left_mode ? 0 : rl32(ld, v), vlq = rl32(lq, v);
                     const uint32_t vpatch = (uint32_t)rl32((int)patch, v);
                     const int r0 = c4 + vld;
                     if (act) {
-                        if (LEAN || (r0 >= 0 && r0 + nval <= vlq)) {                     // the whole unit lies inside the voter
+                        if (r0 >= 0 && r0 + nval <= vlq) {                     // the whole unit lies inside the voter
                             s16[u] = *(const u16_unaligned *)(b.seq + vso + (r0 >> 1));
                             q4[u] = *(const u32_unaligned *)(b.qual + vqo + r0);
                             // scores (vpatch is wave-uniform): qual2score of the four quals; a constant for a read scored without a
@@ -1820,10 +1784,10 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
                 const int c = (int)(((uint32_t)it_ * magic) >> 20), kx = it_ - c * nvot;
                 const int vl = vlist[kx], col = cplx[cbase + c];
                 const uint64_t vso = (uint64_t)__shfl((long long)so, vl), vqo = (uint64_t)__shfl((long long)qo, vl);
-                const int vld = (LEAN || left_mode) ? 0 : __shfl(ld, vl), vlq = LEAN ? len : __shfl(lq, vl);
+                const int vld = left_mode ? 0 : __shfl(ld, vl), vlq = __shfl(lq, vl);
                 const uint32_t vpatch = (uint32_t)__shfl((int)patch, vl);
                 const int rp = col + vld;
-                if (live && (LEAN || (rp >= 0 && rp < vlq))) {
+                if (live && rp >= 0 && rp < vlq) {
                     const int nb = d_nib(b.seq + vso, rp), q = b.qual[vqo + rp], sc = d_score_at(p, w.score + vqo, vpatch, rp, q);
                     const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
                     if (bin < 0 || (q & 0x80)) odd = true;
@@ -1858,7 +1822,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     if (minc != 0) {                                                          // group.cpp:528-573
         if (o_nm_type == 0) { if (lane == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
         else if (minc > 5) restore = true;
-        else if (lane == 0) { int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+        else if (lane == 0) { int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.rp_nm[gi * 2 + (is_left ? 0 : 1)] = nn; }
     }
     if (!restore) {
         for (int bi = lane; bi < nbytes; bi += 64) {
@@ -1870,17 +1834,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     if (lane == 0) rp_out[gi] = out;
 }
 
-// global-memory consensus, one wave per (group, side).
-//   k_consensus_lean: every side of every group on the list (`identity`: all groups in order, the default pipeline; otherwise
-//                     fb_list, the groups the fused LDS kernel handed over); non-qualifying sides go to gen_list
-//   k_consensus_fast: the full instantiation over gen_list (grid-stride, count read on the device)
-__global__ __launch_bounds__(256, 6) void k_consensus_lean(DevBatch b, DevParams p, Work w, uint32_t n_items, int identity) {
-    // per wave: new base [512], new qual [512], contested column list u16[512], pass-B tallies [32][5][4] u32, voter list [64]
-    __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv;
-    if (idx < n_items) consensus_fast_side<true>(b, p, w, identity ? (idx >> 1) : w.fb_list[idx >> 1], !(idx & 1), s_res[wv], lane);
-}
+// global-memory consensus, one wave per (group, side): the sides on gen_list (grid-stride, count read on the device)
 __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -1889,7 +1843,7 @@ __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams
     const uint32_t n = (uint32_t)w.si->n_gen_items;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t e = w.gen_list[idx];
-        consensus_fast_side<false>(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
+        consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
         WAVE_SYNC();
     }
 }
@@ -1953,8 +1907,9 @@ __device__ inline void d_emit_pair(const Work &w, uint32_t gi, bool duplex) {   
     uint32_t l = w.rp_left[gi], r = w.rp_right[gi];
     int fr = (int)min(w.rp_merge[gi], 65535u) & 0xFF;                               // low byte of an unsigned short (quirk Q8)
     int rr = (int)min(w.rp_rmerge[gi], 65535u) & 0xFF;
-    if (l != NONE32) { w.out_flag[l] = 1; w.fr[l] = (int16_t)fr; if (duplex) w.rr[l] = (int16_t)rr; w.mate[l] = r; }
-    if (r != NONE32) { w.out_flag[r] = 1; w.fr[r] = (int16_t)fr; if (duplex) w.rr[r] = (int16_t)rr; w.mate[r] = l; }
+    OutRec o; o.fr = (int16_t)fr; o.rr = duplex ? (int16_t)rr : (int16_t)-1; o.pad = 0;
+    if (l != NONE32) { w.out_flag[l] = 1; o.qname_src = w.rp_qsl[gi]; o.mate = r; o.nm_new = (int16_t)w.rp_nm[gi * 2]; w.orec[l] = o; }
+    if (r != NONE32) { w.out_flag[r] = 1; o.qname_src = w.rp_qsr[gi]; o.mate = l; o.nm_new = (int16_t)w.rp_nm[gi * 2 + 1]; w.orec[r] = o; }
 }
 
 // The tail of Group::consensusMerge (group.cpp:104-132) — mMergeReads, qname reconciliation, the new Pair's UMI — one
@@ -1969,6 +1924,7 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
     const uint8_t cflags = w.cl_hasumi[c];
     const uint32_t G = w.cl_ngroups[c];
     const bool single = np == 1 && w.gpr[begin] == NONE32;
+    uint32_t qsl = left, qsr = right;                                     // BamUtil::copyQName sources (== the record itself if unchanged)
     if (!single) {
         if (cflags & 2) {                                                 // cross-contig cluster: group.cpp:79-99,109-112
             uint32_t ntc = NONE32; int bl = 0;
@@ -1979,21 +1935,22 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
             }
             if (left != NONE32 && ntc != NONE32 && ntc != left) {
                 if (d_lqname_pad(b.core[left]) < d_lqname_pad(b.core[ntc])) raise_error(w.si, GCE_ERR_QNAME_SHORT, left);
-                w.qname_src[left] = ntc;
+                qsl = ntc;
             }
         } else if (left != NONE32 && right != NONE32) {                   // group.cpp:114-123
-            if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) w.qname_src[right] = left;
-            else w.qname_src[left] = right;
+            if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) qsr = left;
+            else qsl = right;
         }
     }
+    w.rp_qsl[gi] = qsl; w.rp_qsr[gi] = qsr;
     const uint32_t merge = single ? 1 : np;
     const bool duplex_cluster = (cflags & 1) && !p.disable_duplex && G >= 2;
     const char *u = nullptr; int ul = 0;                                  // Pair::setLeft / setRight (pair.cpp:188-216)
     if ((cflags & 1) || b.mi) {
-        if (left != NONE32) d_record_umi(b, p, w, left, w.qname_src[left], u, ul);
+        if (left != NONE32) d_record_umi(b, p, w, left, qsl, u, ul);
         if (right != NONE32) {
             const char *u2; int ul2;
-            d_record_umi(b, p, w, right, w.qname_src[right], u2, ul2);
+            d_record_umi(b, p, w, right, qsr, u2, ul2);
             if (left != NONE32 && ul != 0) {                               // (two word loads per side instead of a byte loop with a data-dependent exit)
                 bool same = ul == ul2;
                 if (same && ul <= 24) { uint64_t a[3], c3[3]; load_be_words<3>(u, ul, a); load_be_words<3>(u2, ul2, c3); same = a[0] == c3[0] && a[1] == c3[1] && a[2] == c3[2]; }
@@ -2063,8 +2020,9 @@ __global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w,
 // ===================================================================================================== Stats
 // All counters are additive (stats.h:47-65).  Block-local accumulation in LDS, one global atomic per non-zero counter.
 __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_clusters, uint32_t n_groups) {
-    __shared__ unsigned long long s_pre[GCE_STATS_WORDS], s_post[GCE_STATS_WORDS];
+    __shared__ unsigned long long s_pre[GCE_STATS_WORDS], s_post[GCE_STATS_WORDS], s_np;
     for (int k = threadIdx.x; k < GCE_STATS_WORDS; k += blockDim.x) { s_pre[k] = 0; s_post[k] = 0; }
+    if (threadIdx.x == 0) s_np = 0;
     __syncthreads();
     const uint64_t tid0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
     // indices into gce_stats: 6 clusters, 7 multi, 8 molecules, 9 se, 10 pe, 11 sscs, 12 dcs, 13 uncounted, 14.. hist
@@ -2072,6 +2030,7 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
         uint32_t G = w.cl_ngroups[c];
         if (G == 0) continue;
         atomicAdd(&s_pre[6], 1ull); if (G > 1) atomicAdd(&s_pre[7], 1ull);              // cluster.cpp:102
+        atomicAdd(&s_np, (unsigned long long)w.cl_npairs[c]);
         uint32_t nr = 0; { const uint32_t g0 = w.cl_gbase[c]; for (uint32_t g = 0; g < G; g++) { uint8_t st = w.rp_state[g0 + g]; nr += (st == RP_OUT_SSCS || st == RP_OUT_DCS); } }
         if (nr > 0) { atomicAdd(&s_post[6], 1ull); if (nr > 1) atomicAdd(&s_post[7], 1ull); }   // cluster.cpp:185-187
     }
@@ -2092,7 +2051,8 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
         if (!w.out_flag[i]) continue;
         gce_core k = b.core[i];
         bool mapped = k.tid >= 0;
-        int nm = w.nm_new[i] >= 0 ? w.nm_new[i] : b.nm[i];
+        const int nmn = w.out_flag[i] == 1 ? (int)w.orec[i].nm_new : -1;
+        int nm = nmn >= 0 ? nmn : b.nm[i];
         int mism = (mapped && b.nm_type[i]) ? nm : 0;
         atomicAdd(&s_post[0], 1ull); atomicAdd(&s_post[1], (unsigned long long)k.l_qseq);
         if (mism) { atomicAdd(&s_post[4], (unsigned long long)(long long)mism); }
@@ -2104,6 +2064,7 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
         if (s_pre[k]) atomicAdd((unsigned long long *)&w.si->pre[k], s_pre[k]);
         if (s_post[k]) atomicAdd((unsigned long long *)&w.si->post[k], s_post[k]);
     }
+    if (threadIdx.x == 0 && s_np) atomicAdd(&w.si->n_pairs_total, s_np);
 }
 
 // out_index: ascending list of emitted reads (3-phase scan over out_flag != 0)

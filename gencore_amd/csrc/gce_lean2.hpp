@@ -273,7 +273,7 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
             const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
             if (o_nm_type == 0) { if (hl == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
             else if (minc > 5) restore = true;
-            else if (hl == 0) { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.nm_new[out] = nn; }
+            else if (hl == 0) { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.rp_nm[gi * 2 + h] = nn; }
         }
         if (!restore) {
             for (int bi = hl; bi < nbytes; bi += 32) {
@@ -287,10 +287,10 @@ __device__ void consensus_lean_pair(const DevBatch &b, const DevParams &p, const
     if (hl == 0 && write_result) rp_out[gi] = result;
 }
 
-// one wave per group (both sides); list semantics as k_consensus_lean
-__global__ __launch_bounds__(256, 6) void k_consensus_lean2(DevBatch b, DevParams p, Work w, uint32_t n_groups, int identity) {
+// one wave per group (both sides), every group in order
+__global__ __launch_bounds__(256, 6) void k_consensus_lean2(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2 * L2_HALF_BYTES];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv;
-    if (idx < n_groups) consensus_lean_pair(b, p, w, identity ? idx : w.fb_list[idx], s_res[wv], lane);
+    if (idx < n_groups) consensus_lean_pair(b, p, w, idx, s_res[wv], lane);
 }

@@ -2,15 +2,18 @@
 
 Names follow the reference seam: Engine.add_reads ~ Gencore::addToCluster (src/gencore.cpp:469),
 Engine.finish ~ Gencore::finishConsensus + the periodic clusterByUMI calls (src/gencore.cpp:355,409),
-Engine.output ~ draining csPairs into Gencore::outputPair (src/gencore.cpp:145).
+Engine.rows ~ draining csPairs into Gencore::outputPair and the output set (src/gencore.cpp:145, src/gencore.h:19-47).
 """
 import ctypes as C
 
 import numpy as np
 
 from . import capi
-from .batch import ResultTable
-from .capi import GceBatch, GceError, GceResult, GceStats, GceTiming
+from .batch import table_from_rows
+from .capi import GceError, GceResult, GceStats, GceTiming
+
+_ROW_FIELDS = (("src", np.uint32), ("kind", np.uint8), ("qname_src", np.uint32), ("nm_new", np.int32), ("fr", np.int16),
+               ("rr", np.int16), ("mate", np.uint32), ("seq_off", np.uint64), ("qual_off", np.uint64))
 
 
 class Engine:
@@ -43,12 +46,20 @@ class Engine:
         ptr = nibbles if isinstance(nibbles, int) else np.ascontiguousarray(nibbles, np.uint8).ctypes.data
         self._check(self.lib.gce_set_reference(self._h, tid, ptr, n_bases))
 
+    def set_reference_ascii(self, tid, bases):
+        """bases: bytes / numpy uint8 of upper-cased ASCII; packed to the 4-bit code on the GPU."""
+        a = np.frombuffer(bases, np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, np.uint8)
+        self._check(self.lib.gce_set_reference_ascii(self._h, tid, a.ctypes.data, int(a.size)))
+
+    def set_flush_events(self, ev_tid, ev_pos):
+        """Flush events of the whole stream (key-range shards; see gencore_amd/shard.py)."""
+        t, p = np.ascontiguousarray(ev_tid, np.int32), np.ascontiguousarray(ev_pos, np.int32)
+        self._check(self.lib.gce_set_flush_events(self._h, int(t.size), t.ctypes.data, p.ctypes.data))
+
     def add_reads(self, batch):
         """Submit a host ReadBatch (copied to HBM)."""
         st = batch.as_struct()
         self._check(self.lib.gce_submit(self._h, C.byref(st)))
-        sz = getattr(self, "_sizes", None) or {"seq": 0, "qual": 0}
-        self._sizes = {"seq": sz["seq"] + int(batch.seq.size), "qual": sz["qual"] + int(batch.qual.size)}
 
     def add_reads_device(self, st, keepalive=None):
         """Submit a GceBatch whose pointers are device pointers (zero copy; seq/qual mutated in place)."""
@@ -56,11 +67,9 @@ class Engine:
         self._check(self.lib.gce_submit_device(self._h, C.byref(st)))
 
     def finish(self):
-        rc = self.lib.gce_process(self._h)
-        self._check(rc)
+        self._check(self.lib.gce_process(self._h))
 
     def reset(self):
-        self._sizes = None
         self._check(self.lib.gce_reset(self._h))
 
     def timing(self):
@@ -68,47 +77,47 @@ class Engine:
         self._check(self.lib.gce_get_timing(self._h, C.byref(t)))
         return t.as_dict()
 
-    def output(self):
-        """Result table as numpy copies (ResultTable)."""
+    def rows(self):
+        """The table of emitted records (gce_drain) as numpy copies: (dict of arrays, pre GceStats, post GceStats)."""
         r = GceResult()
         self._check(self.lib.gce_drain(self._h, C.byref(r)))
-        n = r.n_reads
+        n = int(r.n_out)
 
         def arr(ptr, dt, cnt):
             if cnt == 0 or not ptr:
                 return np.zeros(0, dt)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
 
+        rows = {name: arr(getattr(r, name), dt, n) for name, dt in _ROW_FIELDS}
+        rows["seq"] = arr(r.seq, np.uint8, int(r.seq_bytes))
+        rows["qual"] = arr(r.qual, np.uint8, int(r.qual_bytes))
         pre, post = GceStats(), GceStats()
         C.memmove(C.byref(pre), C.byref(r.pre), C.sizeof(GceStats))
         C.memmove(C.byref(post), C.byref(r.post), C.sizeof(GceStats))
-        seq_bytes = self._result_bytes(r.seq, "seq")
-        t = ResultTable(arr(r.out_flag, np.uint8, n), arr(r.qname_src, np.uint32, n), arr(r.nm_new, np.int32, n),
-                        arr(r.fr, np.int16, n), arr(r.rr, np.int16, n), arr(r.mate, np.uint32, n),
-                        seq_bytes, self._result_bytes(r.qual, "qual"), pre, post)
-        t.out_index = arr(r.out_index, np.uint32, r.n_out)
-        return t
+        return rows, pre, post
 
-    def _result_bytes(self, ptr, which):
-        n = self._sizes[which]
-        if n == 0 or not ptr:
-            return np.zeros(0, np.uint8)
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    def output(self, batch):
+        """Per-read ResultTable over `batch` (the whole submitted stream, host arrays; not mutated)."""
+        rows, pre, post = self.rows()
+        t = table_from_rows(batch, rows, pre, post)
+        t.out_index = np.sort(rows["src"])
+        return t
 
     def run(self, batch, reference=None):
         """Convenience: one whole stream -> ResultTable (the host batch is NOT mutated)."""
         for tid, (nib, ln) in enumerate(reference or []):
             if nib is not None:
                 self.set_reference(tid, nib, ln)
-        self._sizes = None
         self.add_reads(batch)
         self.finish()
-        return self.output()
+        return self.output(batch)
 
 
-def run_stream(batch, params, reference=None):
+def run_stream(batch, params, reference=None, events=None):
     e = Engine(params)
     try:
+        if events is not None:
+            e.set_flush_events(*events)
         return e.run(batch, reference)
     finally:
         e.close()

@@ -1,8 +1,15 @@
-"""Coordinate sharding of a sorted stream across GPUs.
+"""Sharding of a sorted stream across GPUs.
 
-Clusters never span contigs (gencore.cpp:295-312: the key carries the read's own tid), so a contiguous range of
-contigs is an exact shard.  What a shard must know about the rest of the stream is only the reference's global
-`tick` (gencore.cpp:319): the number of clustered reads before it, and whether a flush fires after it."""
+Two granularities:
+  * shard_by_contig: clusters never span contigs (gencore.cpp:295-312: the key carries the read's own tid), so a contiguous
+    range of contigs is an exact shard.  What such a shard must know about the rest of the stream is only the reference's
+    global `tick` (gencore.cpp:319): the number of clustered reads before it, and whether a flush fires after it.
+  * plan_shards / shard_by_plan: cuts by CLUSTER KEY (tid, left) anywhere inside a contig — a read with isize < 0 belongs to
+    the cluster at its mate's position (gencore.cpp:301-303), so a shard's reads interleave with its neighbours' in stream
+    order.  Every read then carries its global tick (gce_batch.tick) and every shard gets the flush events of the whole
+    stream (gce_set_flush_events): which clusters a flush takes, and hence the UMI threshold a cluster gets (quirk Q1),
+    comes out exactly as in the unsharded stream.  mode="range": contiguous key ranges balanced by read count;
+    mode="lpt": clusters dealt to the least loaded shard, heaviest first, weighted by depth^2 (ultra-deep hotspots)."""
 import numpy as np
 
 from .batch import ReadBatch
@@ -98,3 +105,50 @@ def shard_by_contig(batch, world, rank, flush_period=10000):
     total_ticks = int(cm.sum())
     later_event = (total_ticks // flush_period) > ((before + mine) // flush_period)
     return slice_batch(batch, idx), idx, dict(tick_offset=before, trailing_flush=int(later_event))
+
+
+def cluster_left(core):
+    """`left` of the cluster key (gencore.cpp:296-303): the mate's position for the right-hand read of a nearby pair."""
+    tid, pos, mtid, mpos, isize = (core[k].astype(np.int64) for k in ("tid", "pos", "mtid", "mpos", "isize"))
+    near = (mtid == tid) & (np.abs(mpos - pos) < 100000)
+    return np.where(near & (isize < 0), mpos, pos)
+
+
+def stream_context(core, flush_period=10000):
+    """(tick, ev_tid, ev_pos) of a whole stream: the value of the reference's `tick` right after each clustered read was
+    added (gencore.cpp:319-320) and the reads on which tick % period == 0, i.e. the periodic flushes (gencore.cpp:321-322)
+    before the first unmapped read (the one and only finishConsensus comes there, gencore.cpp:255-262)."""
+    cm = clustered_mask(core)
+    tick = np.cumsum(cm).astype(np.uint64)
+    unm = np.nonzero((core["tid"] < 0) | (core["pos"] < 0))[0]
+    end = int(unm[0]) if len(unm) else len(core)
+    if len(unm) and cm[end:].any():
+        raise ValueError("key-range shards need every mapped read before the first unmapped read")
+    ev = np.nonzero(cm[:end] & (tick[:end] % np.uint64(flush_period) == 0))[0]
+    return tick, core["tid"][ev].astype(np.int32), core["pos"][ev].astype(np.int32)
+
+
+def plan_shards(core, world, mode="range"):
+    """Shard number of every read.  All reads of one cluster key (tid, left) get the same shard; unmapped reads go last."""
+    tid = core["tid"].astype(np.int64)
+    key = (np.where(tid < 0, np.int64(1) << 30, tid) << 32) | cluster_left(core).clip(0).astype(np.int64)
+    if mode == "range":
+        srt = np.sort(key)
+        cuts = np.asarray([srt[min(len(srt) - 1, (len(srt) * r) // world)] for r in range(1, world)], np.int64) if len(srt) else np.zeros(0, np.int64)
+        return np.searchsorted(cuts, key, side="right").astype(np.int32)
+    uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    load = np.zeros(world, np.float64)
+    owner = np.zeros(len(uk), np.int32)
+    for c in np.argsort(-cnt.astype(np.float64) ** 2, kind="stable"):
+        r = int(np.argmin(load))
+        owner[c] = r
+        load[r] += float(cnt[c]) ** 2
+    return owner[inv]
+
+
+def shard_by_plan(batch, plan, rank, tick):
+    """Sub-batch of `rank` (reads in stream order) carrying the global ticks; returns (sub_batch, read_indices)."""
+    idx = np.nonzero(plan == rank)[0]
+    sub = slice_batch(batch, idx)
+    sub.tick = np.ascontiguousarray(tick[idx], np.uint64)
+    return sub, idx

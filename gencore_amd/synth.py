@@ -7,7 +7,9 @@ struct-of-arrays layout plus the reference contigs in FastaReader's 4-bit code.
 Workloads (BASELINE.json `configs`):
   cfg1s : plumbing substitute for configs[0] (2k pairs, depth 2, no UMI, 1 contig)
   cfg2  : 1 M pairs, 150 bp, no UMI, mean depth 4, single 10 Mb contig, -s 1
-  cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean depth 8, 24 contigs / 300 Mb, -s 2
+  cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean depth 8, -s 2; 24 hg19-shaped contigs (`scale` x hg19 lengths:
+          0.1 = 300 Mb by default, bench.py uses 1.0 = 3.04 Gb); molecules concentrated on 5 k x 200 bp BED targets (the target
+          count follows n_pairs so that a down-scaled stream keeps ~250 molecules per target)
   cfg4s : per-GPU shard of configs[3] (12.5 M pairs, UMI, depth 16)
   cfg5  : ultra-deep hotspots, 250 bp, duplex UMIs AAAA_BBBB, depth U[500,2000]
 Every size can be scaled with `n_pairs=`.
@@ -61,14 +63,14 @@ CONFIGS = {
                   supporting_reads=1),
     "cfg2": dict(n_pairs=1_000_000, L=150, umi=0, duplex=False, mean_depth=4, contigs=[10_000_000], ins_mu=300, ins_sd=30,
                  ins_max=600, supporting_reads=1),
-    "cfg3": dict(n_pairs=10_000_000, L=150, umi=8, duplex=False, mean_depth=8,
-                 contigs=[int(300e6 * w / 3036.0) for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
-                                                            90, 81, 78, 59, 63, 48, 51, 155, 59)],
-                 ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),
+    "cfg3": dict(n_pairs=10_000_000, L=150, umi=8, duplex=False, mean_depth=8, scale=0.1,
+                 contigs=[w * 1_000_000 for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
+                                                  90, 81, 78, 59, 63, 48, 51, 155, 59)],      # hg19 chr1..22, X, Y (Mb)
+                 bed_targets=5000, bed_len=200, ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),
     "cfg4s": dict(n_pairs=12_500_000, L=150, umi=8, duplex=False, mean_depth=16, contigs=[125_000_000] * 3, ins_mu=300, ins_sd=30,
                   ins_max=600, supporting_reads=2),
     "cfg5": dict(n_pairs=0, n_molecules=1250, L=250, umi=4, duplex=True, depth_lo=500, depth_hi=2000, contigs=[50_000_000],
-                 ins_mu=450, ins_sd=50, ins_max=900, supporting_reads=1),
+                 ins_mu=450, ins_sd=50, ins_max=900, supporting_reads=1, shard_mode="lpt"),
 }
 
 
@@ -102,9 +104,14 @@ class SynthData:
         return [(r.cpu().numpy(), n) for r, n in self.reference]
 
 
-def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, align=1, **over):
+def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, align=1, shard=None, flush_period=10000, **over):
     """align: start every read's seq / qual slice on a multiple of `align` bytes (the gce_batch offsets are free-form;
-    an aligned layout lets the kernels' dword accesses stay inside cache lines)."""
+    an aligned layout lets the kernels' dword accesses stay inside cache lines).
+    shard=(rank, world): plan the WHOLE stream (molecules, pairs, the sorted order of all reads: cheap), cut it into `world` ranges
+    of the cluster key (tid, left) with equal read counts — the cuts fall inside contigs — and materialise only this rank's reads
+    (bases, qualities, names).  The result carries `stream_context`: every read's global tick (device tensor) and the flush events
+    of the whole stream (gce_batch.tick / gce_set_flush_events), and `global_index`, the reads' positions in the whole stream.
+    The records are byte-identical to those of the unsharded stream."""
     cfg = dict(CONFIGS[name])
     cfg.update(over)
     if n_pairs is not None:
@@ -113,7 +120,7 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
     dev = torch.device(device)
     L = cfg["L"]
     i64 = dict(dtype=torch.int64, device=dev)
-    contigs = list(cfg["contigs"])
+    contigs = [max(2000, int(c * cfg.get("scale", 1.0))) for c in cfg["contigs"]]
     ncont = len(contigs)
 
     # ---------------------------------------------------------------- molecules and their duplicate counts
@@ -133,7 +140,18 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
     # insert size ~ N(mu, sd) via Irwin-Hall(12), clipped to [L, ins_max]
     z = sum(rnd_f(seed, 10 + k, mid) for k in range(12)) - 6.0
     ins = torch.clamp((cfg["ins_mu"] + cfg["ins_sd"] * z).round().to(torch.int64), L, cfg["ins_max"])
-    g = rnd_u(seed, 2, mid, total)                           # global start, then mapped to (contig, offset)
+    bed = None
+    if cfg.get("bed_targets"):
+        # capture-panel shape: T targets of bed_len bases at random places of the genome; a molecule picks a target
+        # and starts where it still overlaps it.  ~250 molecules per target => clusters with several molecules occur naturally.
+        T = max(1, int(round(cfg["bed_targets"] * cfg["n_pairs"] / float(CONFIGS[name]["n_pairs"]))))
+        tix = torch.arange(T, **i64)
+        tg = rnd_u(seed, 40, tix, total - 2000) + 1000           # target start, genome-linear
+        t_of = rnd_u(seed, 41, mid, T)
+        g = tg[t_of] - (L - 1) + rnd_u(seed, 2, mid, cfg["bed_len"] + L - 1)
+        bed = (tg, cfg["bed_len"])
+    else:
+        g = rnd_u(seed, 2, mid, total)                       # global start, then mapped to (contig, offset)
     m_tid = torch.searchsorted(cum, g, right=True)
     m_start = g - (cum[m_tid] - clen[m_tid])
     m_start = torch.minimum(m_start, clen[m_tid] - ins - 16).clamp_(min=8)
@@ -186,6 +204,47 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
     order = torch.argsort(tie, stable=True)
     order = order[torch.argsort(key[order], stable=True)]
     rd_pair, rd_rev = rd_pair[order], rd_rev[order]
+    del order, tie, rd_pos, rd_tid
+    stream_context = global_index = None
+    n_pairs_stream = P
+    if shard is not None:
+        rank, world = shard
+        # every read of this generator reaches the cluster map, so a read's global tick is its place in the stream (gencore.cpp:319);
+        # flush events = the reads on which tick % period == 0 (gencore.cpp:321-322)
+        evi = torch.arange(flush_period - 1, N, flush_period, **i64) if N >= flush_period else torch.zeros(0, **i64)
+        ev_pair, ev_rev = rd_pair[evi], rd_rev[evi]
+        ev_pos = torch.where(ev_rev == 1, r_pos[ev_pair], f_pos[ev_pair])
+        ev_tid = p_tid[ev_pair]
+        # cluster key of a pair: (tid, left) with left = the leftmost of the two mates (the read with isize < 0 follows its mate,
+        # gencore.cpp:301-303); key ranges with equal pair counts
+        kp = (p_tid << 40) | torch.minimum(f_pos, r_pos)
+        if cfg.get("shard_mode", "range") == "lpt":
+            # ultra-deep hotspots: whole clusters dealt to the least loaded rank, heaviest first, weight = depth^2
+            uk, inv, cnt = torch.unique(kp, return_inverse=True, return_counts=True)
+            cn = cnt.cpu().numpy().astype(np.float64)
+            load, owner = np.zeros(world), np.zeros(len(cn), np.int64)
+            for c in np.argsort(-cn ** 2, kind="stable"):
+                r = int(np.argmin(load)); owner[c] = r; load[r] += cn[c] ** 2
+            mine_p = torch.from_numpy(owner).to(dev)[inv] == rank
+            del uk, inv, cnt
+        else:
+            srt = torch.sort(kp).values
+            cuts = srt[torch.tensor([min(P - 1, (P * r) // world) for r in range(1, world)], **i64)] if world > 1 else srt[:0]
+            mine_p = torch.searchsorted(cuts, kp, right=True) == rank
+            del srt
+        del kp
+        sel = torch.nonzero(mine_p[rd_pair]).squeeze(1)              # my reads, in stream order
+        loc = torch.cumsum(mine_p.to(torch.int64), 0) - 1            # global pair id -> local pair id
+        rd_pair, rd_rev = loc[rd_pair[sel]], rd_rev[sel]
+        global_index = sel
+        stream_context = dict(tick=(sel + 1).contiguous(), ev_tid=ev_tid.to(torch.int32).cpu().numpy(), ev_pos=ev_pos.to(torch.int32).cpu().numpy())
+        # pair-level arrays restricted to my pairs; `pid` keeps the GLOBAL ids: they key the per-base / per-name random streams
+        pid, mol, p_tid, p_start, p_ins, strand = pid[mine_p], mol[mine_p], p_tid[mine_p], p_start[mine_p], p_ins[mine_p], strand[mine_p]
+        fk, fklen, fa, rk, rklen, ra = fk[mine_p], fklen[mine_p], fa[mine_p], rk[mine_p], rklen[mine_p], ra[mine_p]
+        f_pos, r_pos, r0, f_isize, r_isize = f_pos[mine_p], r_pos[mine_p], r0[mine_p], f_isize[mine_p], r_isize[mine_p]
+        P = int(pid.numel())
+        N = int(sel.numel())
+        del mine_p, loc, sel
     isrev = rd_rev == 1
     pos = torch.where(isrev, r_pos[rd_pair], f_pos[rd_pair])
     mpos = torch.where(isrev, f_pos[rd_pair], r_pos[rd_pair])
@@ -252,7 +311,7 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
                            torch.where(j < a, j, j + kl)))))
         rid = torch.arange(s, e, **i64)
         # per-base randomness must belong to the MOLECULE's duplicate, not the sorted position: key on (pair, mate)
-        bkey = ((rd_pair[s:e] * 2 + rd_rev[s:e]) * 1024)[:, None] + j
+        bkey = ((pid[rd_pair[s:e]] * 2 + rd_rev[s:e]) * 1024)[:, None] + j
         h = rnd(seed, 6, bkey)
         gpos = (ref_base_off[tid[s:e]] + ref0[s:e])[:, None] + roff.clamp(min=0)
         rb = ref_all[gpos.clamp(max=ref_all.numel() - 1)].long()
@@ -334,6 +393,15 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
     tensors = dict(core=core, qname_off=qname_off, qname=qname, cigar_off=cigar_off, cigar=cigar.to(torch.int32),
                    seq_off=rid * SBs, seq=seq, qual_off=rid * Ls, qual=qual, nm=nm,
                    nm_type=torch.full((N,), ord("C"), dtype=torch.uint8, device=dev))
-    info = dict(name=name, n_pairs=P, n_reads=N, n_molecules=M, read_len=L, umi_len=Utot,
-                umi_prefix="UMI" if U else "", supporting_reads=cfg["supporting_reads"])
-    return SynthData(tensors, reference, contigs, cfg, info)
+    info = dict(name=name, n_pairs=P, n_reads=N, n_pairs_stream=n_pairs_stream, n_molecules=M, read_len=L, umi_len=Utot,
+                umi_prefix="UMI" if U else "", supporting_reads=cfg["supporting_reads"], genome_bases=total,
+                bed_targets=(int(bed[0].numel()) if bed else 0))
+    if bed:                                                  # BED regions as (tid, start, end), sorted
+        b_tid = torch.searchsorted(cum, bed[0], right=True)
+        b_start = bed[0] - (cum[b_tid] - clen[b_tid])
+        b_start = torch.minimum(b_start, clen[b_tid] - bed[1]).clamp_(min=0)
+        order_b = torch.argsort(b_tid * (1 << 40) + b_start)
+        info["bed"] = torch.stack([b_tid[order_b], b_start[order_b], b_start[order_b] + bed[1]], 1).cpu().numpy()
+    out = SynthData(tensors, reference, contigs, cfg, info)
+    out.stream_context, out.global_index = stream_context, global_index
+    return out

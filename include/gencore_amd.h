@@ -2,13 +2,13 @@
  * gencore_amd.h — C-ABI of the MI355X consensus-read engine (libgencore_amd.so).
  *
  * This is the drop-in boundary for ONE path of OpenGene/gencore v0.17.2: everything between
- * Gencore::addToCluster(b) (reference src/gencore.cpp:361,558) and Gencore::outputPair(p)
- * (src/gencore.cpp:234), i.e. Cluster -> Group -> Pair -> consensus.  The reference has no FFI; the seam
- * it offers is the C++ call pair
- *     Cluster::addRead(bam1_t*)                                   src/cluster.h:23,  src/cluster.cpp:308
- *     vector<Pair*> Cluster::clusterByUMI(thr, pre, post, cross)  src/cluster.h:26,  src/cluster.cpp:103
- * driven by Gencore::addToProperCluster (src/gencore.cpp:384-479) and Gencore::finishConsensus
- * (src/gencore.cpp:481-523).  Each entry point below names the reference interface it replaces.
+ * Gencore::addToCluster(b) (call src/gencore.cpp:272, definition :469) and the output set that
+ * Gencore::outputPair(p) (src/gencore.cpp:145) feeds, i.e. Cluster -> Group -> Pair -> consensus -> output order.
+ * The reference has no FFI; the seam it offers is the C++ call pair
+ *     Cluster::addRead(bam1_t*)                                   src/cluster.h:23,  src/cluster.cpp:260
+ *     vector<Pair*> Cluster::clusterByUMI(thr, pre, post, cross)  src/cluster.h:26,  src/cluster.cpp:55
+ * driven by Gencore::addToProperCluster (src/gencore.cpp:295-390) and Gencore::finishConsensus
+ * (src/gencore.cpp:392-434).  Each entry point below names the reference interface it replaces.
  *
  * Conventions
  *   - plain C, POD structs, pointers + sizes; no C++/torch types.
@@ -16,7 +16,7 @@
  *     maps the codes back to the reference's messages + exit(-1)  (src/util.h:250 error_exit).
  *   - one engine per GPU per host thread; no global state inside the library.
  *   - the engine keeps the whole submitted stream resident in HBM (288 GB per MI355X) and processes it in
- *     one pass at gce_process(): the reference's 10,000-read flush cadence (src/gencore.cpp:408-411) is
+ *     one pass at gce_process(): the reference's 10,000-read flush cadence (src/gencore.cpp:319-322) is
  *     reproduced exactly as a per-cluster attribute, not as a host-side loop.
  */
 #ifndef GENCORE_AMD_H
@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-#define GCE_ABI_VERSION 1
-#define GCE_NONE 0xFFFFFFFFu           /* "no read" marker in uint32 index arrays */
+#define GCE_ABI_VERSION 2
+#define GCE_NONE 0xFFFFFFFFu           /* "no record" marker in uint32 index arrays */
 #define GCE_MAX_SUPPORTING_READS 100   /* src/stats.h:15 MAX_SUPPORTING_READS */
 
 typedef struct gce_engine gce_engine;   /* opaque */
@@ -41,12 +41,13 @@ typedef enum gce_status {
     GCE_ERR_NO_DEVICE = -2,        /* no HIP device: the product path has NO CPU fallback */
     GCE_ERR_HIP = -3,              /* HIP runtime failure, see gce_last_error() */
     GCE_ERR_OOM = -4,
-    /* fatal conditions of the reference path, reported instead of exit(-1): */
-    GCE_ERR_UNSORTED = -10,        /* src/gencore.cpp:322-329 "the input is unsorted" */
-    GCE_ERR_UMI_MISMATCH = -11,    /* src/pair.cpp:605-616 "The UMI of a read pair should be identical" */
-    GCE_ERR_NM_MISSING = -12,      /* src/group.cpp:581-584: NM dereferenced although absent (segfault in the reference) */
-    GCE_ERR_UMI_PARSE = -13,       /* src/bamutil.cpp:86-102: substr(start) with start > length throws in the reference */
-    GCE_ERR_QNAME_SHORT = -14      /* src/bamutil.cpp:383-386 "copyQName ERROR: desitination qname is shorter" */
+    /* fatal conditions of the reference path, reported instead of exit(-1).  When a stream has several, the one on the
+     * EARLIEST read is reported (the reference stops at the first in stream order). */
+    GCE_ERR_UNSORTED = -10,        /* src/gencore.cpp:233-241 "the input is unsorted" */
+    GCE_ERR_UMI_MISMATCH = -11,    /* src/pair.cpp:201-212 "The UMI of a read pair should be identical" */
+    GCE_ERR_NM_MISSING = -12,      /* src/group.cpp:532-535: NM dereferenced although absent (segfault in the reference) */
+    GCE_ERR_UMI_PARSE = -13,       /* src/bamutil.cpp:47-62: substr(start) with start > length throws in the reference */
+    GCE_ERR_QNAME_SHORT = -14      /* src/bamutil.cpp:343-346 "copyQName ERROR: desitination qname is shorter" */
 } gce_status;
 
 /* One read's fixed-size fields.  Byte-for-byte the BAM alignment core block (SAMv1 section 4.2), i.e. what
@@ -56,7 +57,7 @@ typedef struct gce_core {
     int32_t  pos;       /* bam1_core_t.pos   0-based leftmost                           */
     uint8_t  l_qname;   /* strlen(qname)+1 as stored in BAM; the engine applies htslib's in-memory
                            padding to a multiple of 4 (l_extranul) wherever the reference compares
-                           name lengths (src/group.cpp:143,167; src/bamutil.cpp:381-389)            */
+                           name lengths (src/group.cpp:94,117; src/bamutil.cpp:341-346)            */
     uint8_t  mapq;
     uint16_t bin;
     uint16_t n_cigar;
@@ -86,16 +87,17 @@ typedef struct gce_params {
     int32_t skip_low_complexity_cluster_threshold;  /*                              = 1000 */
     int32_t duplex_only;                    /* -x */
     int32_t disable_duplex;                 /* --no_duplex */
-    int32_t flush_period;                   /* the literal 10000 of src/gencore.cpp:410 */
+    int32_t flush_period;                   /* the literal 10000 of src/gencore.cpp:321 */
     double  score_percent_req;              /* -a  scorePercentReq                  = 0.8 */
     char    umi_prefix[32];                 /* -u, already resolved ("auto" -> gce_detect_umi_prefix) */
-    /* contig lengths of the BAM header: needed by the cross-contig key, src/gencore.cpp:400 */
+    /* contig lengths of the BAM header: needed by the cross-contig key, src/gencore.cpp:311 */
     int32_t n_targets;
     const uint32_t *target_len;             /* [n_targets], copied by gce_create */
-    /* Stream context for coordinate-sharded (multi-GPU) runs: this engine sees a contiguous slice of the
-     * globally sorted stream.  tick_offset = number of clustered reads before the slice (the reference's
-     * static `tick`, src/gencore.cpp:408); trailing_flush != 0 if a flush event occurs after the slice, so
-     * clusters still pending at the end of the slice get -d instead of the end-of-file threshold (quirk Q1). */
+    /* Stream context for contig-granular shards (multi-GPU): this engine sees a contiguous slice of the globally
+     * sorted stream.  tick_offset = number of clustered reads before the slice (the reference's static `tick`,
+     * src/gencore.cpp:319); trailing_flush != 0 if a flush event occurs after the slice, so clusters still pending
+     * at the end of the slice get -d instead of the end-of-file threshold (quirk Q1).  Shards cut INSIDE a contig by
+     * cluster key use gce_batch.tick + gce_set_flush_events instead. */
     int64_t tick_offset;
     int32_t trailing_flush;
     int32_t reserved;
@@ -103,8 +105,9 @@ typedef struct gce_params {
 
 /* A batch of reads in INPUT ORDER (coordinate-sorted), struct-of-arrays.  Offsets are start offsets, lengths
  * come from gce_core (l_qname, n_cigar, l_qseq).  seq is BAM 4-bit packed (high nibble = even base,
- * src/bamutil.cpp:173-186), qual is raw Phred.  seq/qual are MUTATED IN PLACE exactly where the reference
- * mutates its bam1_t records (src/pair.cpp:562-563, src/group.cpp:560-574,604-605, src/cluster.cpp:275-288).
+ * src/bamutil.cpp:133-147,167-189), qual is raw Phred.  seq/qual are MUTATED IN PLACE where the reference
+ * mutates its bam1_t records (src/group.cpp:503-525,555-556, src/cluster.cpp:227-232; the quality rewrite of
+ * src/pair.cpp:158-159 persists only in emitted records, see gce_result).
  * Device buffers (gce_submit_device): `core` must be 16-byte aligned and every blob readable 16 bytes past its end
  * (vector loads of the last read); gce_submit pads its own copies.  Reads longer than 65535 bases are rejected. */
 typedef struct gce_batch {
@@ -121,12 +124,16 @@ typedef struct gce_batch {
     const int32_t  *nm;          /* [n] value of the NM aux tag (bam_aux2i), ignored when nm_type==0 */
     const uint8_t  *nm_type;     /* [n] BAM aux type byte of NM ('C','c','S','s','I','i'), 0 = tag absent */
     const uint64_t *mi_off;      /* optional: [n] offset of the MI:Z string, UINT64_MAX = read has no MI tag */
-    const char     *mi;          /* optional: NUL-terminated MI:Z strings (src/bamutil.cpp:63-78); NULL if unused */
+    const char     *mi;          /* optional: NUL-terminated MI:Z strings (src/bamutil.cpp:23-38); NULL if unused */
     size_t qname_bytes, cigar_words, seq_bytes, qual_bytes, mi_bytes;   /* total sizes of the blobs */
+    /* optional (key-range shards, see gce_set_flush_events): [n] the value the reference's `tick` has right after this
+     * read was added (src/gencore.cpp:319-320), counted over the WHOLE stream; ignored for reads that never reach the
+     * cluster map.  NULL: the engine counts ticks itself from gce_params.tick_offset. */
+    const uint64_t *tick;
 } gce_batch;
 
-/* Additive QC counters touched on the path (src/stats.h:47-65; call sites src/gencore.cpp:199,235,311 and
- * src/cluster.cpp:150,184,190,206,210,221,225,233).  All int64, all additive => one RCCL all-reduce(sum). */
+/* Additive QC counters touched on the path (src/stats.h:47-65; call sites src/gencore.cpp:110,146,222 and
+ * src/cluster.cpp:102,136,142,158,162,173,177,185).  All int64, all additive => one RCCL all-reduce(sum). */
 typedef struct gce_stats {
     int64_t reads;                     /* mRead                */
     int64_t bases;                     /* mBase                */
@@ -146,43 +153,54 @@ typedef struct gce_stats {
 } gce_stats;
 #define GCE_STATS_WORDS (14 + GCE_MAX_SUPPORTING_READS)
 
-/* Per-read result table (host pointers, owned by the engine until the next gce_process/gce_destroy).
- * An output record is "input read i, with its seq/qual as left in the mutated buffers, its qname replaced by
- * the qname of read qname_src[i], NM patched to nm_new[i] if >= 0, and FR/RR aux bytes appended if >= 0". */
+/* The output of the path: one row per EMITTED record, struct-of-arrays, in the order of the reference's output set
+ * (bamComp, src/gencore.h:19-47): ascending (tid, pos, mtid, mpos, isize); where the reference breaks ties by heap
+ * address (quirk Q3) the engine uses the input index, so the order is deterministic.
+ * Row k means: "input read src[k], with seq/qual replaced by the bytes at seq_off[k]/qual_off[k] of the compact blobs
+ * below, its qname replaced by the qname of input read qname_src[k] (BamUtil::copyQName, src/bamutil.cpp:338), NM
+ * patched to nm_new[k] if >= 0 (src/group.cpp:570), FR/RR aux bytes appended if >= 0 (src/pair.cpp:57-67)".
+ * Host pointers (gce_drain) or device pointers (gce_result_device), owned by the engine until the next
+ * gce_process / gce_reset / gce_destroy. */
 typedef struct gce_result {
-    int64_t         n_reads;
-    const uint8_t  *out_flag;    /* [n] 0 = not emitted; 1 = emitted by outputPair (src/gencore.cpp:234);
-                                        2 = mate-unmapped pass-through (src/gencore.cpp:396-398) */
-    const uint32_t *qname_src;   /* [n] BamUtil::copyQName source (src/bamutil.cpp:378), == i if unchanged */
-    const int32_t  *nm_new;      /* [n] -1 = NM untouched, else the byte written at src/group.cpp:619 */
-    const int16_t  *fr;          /* [n] -1 = no tag, else the FR:C byte (src/pair.cpp:462-463, low byte, Q8) */
-    const int16_t  *rr;          /* [n] -1 = no tag, else the RR:C byte (src/pair.cpp:467-468) */
-    const uint32_t *mate;        /* [n] the other record of the same output Pair, or GCE_NONE */
-    const uint8_t  *seq;         /* mutated copies of the submitted blobs (same offsets) */
+    int64_t         n_reads;     /* reads of the processed stream */
+    int64_t         n_out;       /* emitted records */
+    const uint32_t *src;         /* [n_out] input read index of the record (the consensus template, or a pass-through read) */
+    const uint8_t  *kind;        /* [n_out] 1 = emitted by outputPair (src/gencore.cpp:145);
+                                            2 = mate-unmapped pass-through (src/gencore.cpp:307-309) */
+    const uint32_t *qname_src;   /* [n_out] == src[k] if the name is unchanged */
+    const int32_t  *nm_new;      /* [n_out] -1 = NM untouched, else the byte written at src/group.cpp:570 */
+    const int16_t  *fr;          /* [n_out] -1 = no tag, else the FR:C byte (src/pair.cpp:57-61, low byte, quirk Q8) */
+    const int16_t  *rr;          /* [n_out] -1 = no tag, else the RR:C byte (src/pair.cpp:62-67) */
+    const uint32_t *mate;        /* [n_out] ROW of the other record of the same output Pair, or GCE_NONE */
+    const uint64_t *seq_off;     /* [n_out] byte offset of the record's packed bases in `seq` (16-byte aligned) */
+    const uint64_t *qual_off;    /* [n_out] byte offset of its qualities in `qual` (16-byte aligned) */
+    const uint8_t  *seq;         /* compact blobs: emitted records only */
     const uint8_t  *qual;
-    int64_t         n_out;       /* number of reads with out_flag != 0 */
-    const uint32_t *out_index;   /* [n_out] their indices, ascending */
+    size_t          seq_bytes, qual_bytes;
     gce_stats       pre;         /* mPreStats  deltas */
-    gce_stats       post;        /* mPostStats deltas */
+    gce_stats       post;        /* mPostStats deltas: reads/bases/mismatches are Stats::addRead (src/stats.cpp:101-121)
+                                    over ALL emitted records (what writeBam accumulates once every record is written,
+                                    src/gencore.cpp:110) — see INTEGRATION.md for the report-before-drain quirk */
 } gce_result;
 
 /* Kernel timing of the last gce_process(), HIP events on the engine's stream. */
 typedef struct gce_timing {
     double total_ms;             /* first kernel start -> last kernel end */
-    double prescan_ms;           /* read classification + tick scan  */
+    double prescan_ms;           /* read classification + tick scan + table clear */
     double cluster_ms;           /* clustering scan (key + hash partition), the roofline kernel  */
-    double csr_ms;               /* bucket offsets + scatter */
+    double csr_ms;               /* cluster list + member lists */
     double pairing_ms;           /* mate pairing + UMI grouping per cluster */
-    double score_ms;             /* Pair::computeScore (mate-overlap patches) */
-    double consensus_ms;         /* template pick + column vote (fast + generic kernels) */
+    double score_ms;             /* Pair::computeScore launches of the fallback path (0 when every group takes the fused vote) */
+    double consensus_ms;         /* template pick + column vote (fused kernel + fallbacks) */
     double finish_ms;            /* duplex merge, filter, tags, stats */
+    double output_ms;            /* output order + compaction of the emitted records */
     int64_t n_clusters, n_groups, n_pairs;
 } gce_timing;
 
 /* Fill *p with the reference defaults (src/options.cpp:4-40). */
 void gce_params_default(gce_params *p);
 
-/* "auto" UMI prefix detection on the first read's qname, src/gencore.cpp:296-309.  Writes "", "umi" or "UMI". */
+/* "auto" UMI prefix detection on the first read's qname, src/gencore.cpp:207-220.  Writes "", "umi" or "UMI". */
 void gce_detect_umi_prefix(const char *first_qname, char out_prefix[32]);
 
 /* Replaces: Gencore::Gencore(Options*) + Cluster(Options*) construction, src/gencore.cpp:7-19. */
@@ -192,27 +210,40 @@ void gce_destroy(gce_engine *e);
 /* Replaces: Reference::instance(opt)->getData(tid, ...) (src/reference.cpp:33-70) as the source of the staged
  * reference.  `nibbles` is one contig in FastaReader's own 4-bit code (A=1,T=2,C=3,G=4, other=0, LOW nibble =
  * even position; src/fastareader.cpp:106-128,139-152), n_bases its length.  Contigs never set behave like
- * "contig not found in the reference" (getData returns NULL). */
+ * "contig not found in the reference" (getData returns NULL).  Host or device pointer. */
 int gce_set_reference(gce_engine *e, int32_t tid, const uint8_t *nibbles, int64_t n_bases);
-/* Convenience: pack an upper-cased ASCII contig into that code (FastaReader::to4bits, src/fastareader.cpp:139). */
+/* Same from upper-cased ASCII bases (one contig of FastaReader::mAllContigs, src/fastareader.h): packed on the GPU
+ * (FastaReader::to4bits, src/fastareader.cpp:139-152). */
+int gce_set_reference_ascii(gce_engine *e, int32_t tid, const char *bases, int64_t n_bases);
+/* Convenience: pack an upper-cased ASCII contig into that code on the host (src/fastareader.cpp:139). */
 void gce_pack_reference(const char *bases, int64_t n_bases, uint8_t *nibbles_out);
 
-/* Replaces: the per-read loop body Gencore::addToCluster(b) (src/gencore.cpp:361,558-566) for a whole batch.
+/* Key-range shards (multi-GPU cuts inside a contig): the flush events of the WHOLE stream before its first
+ * unmapped read — event j is the read on which `tick` reaches (j+1)*flush_period (src/gencore.cpp:319-322) and carries
+ * that read's (tid, pos), which bound the flush walk (src/gencore.cpp:333-354).  Used together with gce_batch.tick;
+ * host arrays, copied.  n_events = 0 with tick given means "no flush ever fires".  Unmapped reads must follow every
+ * mapped read of the stream in this mode. */
+int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid, const int32_t *ev_pos);
+
+/* Replaces: the per-read loop body Gencore::addToCluster(b) (src/gencore.cpp:272,469-476) for a whole batch.
  * Host buffers are copied to HBM; the caller keeps ownership.  May be called repeatedly; batches are
  * concatenated in call order (they must continue the same sorted stream). */
 int gce_submit(gce_engine *e, const gce_batch *batch);
-/* Same, but every pointer in *batch is a DEVICE pointer that stays valid until gce_process() returns; seq/qual
- * are mutated in place in the caller's HBM buffers (zero-copy path used by bench.py and by a GPU BAM decoder). */
+/* Same, but every pointer in *batch is a DEVICE pointer that stays valid until the next gce_submit_device / gce_reset /
+ * gce_destroy; seq/qual are mutated in place in the caller's HBM buffers (zero-copy path used by bench.py and by a
+ * GPU BAM decoder).  One batch per gce_process. */
 int gce_submit_device(gce_engine *e, const gce_batch *batch);
 
-/* Replaces: every clusterByUMI call of the stream (src/gencore.cpp:444 periodic, :498 end of file) plus
- * outputPair bookkeeping.  Runs the whole HIP pipeline over everything submitted since the last process. */
+/* Replaces: every clusterByUMI call of the stream (src/gencore.cpp:355 periodic, :409 end of file), the
+ * outputPair bookkeeping (src/gencore.cpp:145-160) and the ordering of the output set (src/gencore.h:19-47).
+ * Runs the whole HIP pipeline over everything submitted since the last process.  A second call without a new
+ * submit is an error (the stream was mutated in place). */
 int gce_process(gce_engine *e);
 
-/* Replaces: draining csPairs into Gencore::outputPair (src/gencore.cpp:445-449,499-503).  Copies the result
- * table to host memory owned by the engine. */
+/* Replaces: draining csPairs into Gencore::outputPair (src/gencore.cpp:356-360,410-414).  Copies the result
+ * table (emitted records only) to host memory owned by the engine. */
 int gce_drain(gce_engine *e, gce_result *out);
-/* Device-side view of the same table (device pointers; seq/qual are the mutated device blobs). */
+/* Device-side view of the same table (device pointers). */
 int gce_result_device(gce_engine *e, gce_result *out);
 
 int gce_get_timing(gce_engine *e, gce_timing *out);

@@ -51,6 +51,7 @@ typedef struct Ctx {
     uint32_t            *htab;      /* open-addressing index into pending[] (+1), rebuilt after each flush */
     uint64_t             hmask;
     int64_t              tick;      /* static int tick, gencore.cpp:319 */
+    int32_t              n_ev, next_ev; const int32_t *ev_tid, *ev_pos;   /* key-range shards: flush events of the whole stream */
     int                  failed;
 } Ctx;
 
@@ -922,14 +923,29 @@ static void add_to_proper_cluster(Ctx *c, uint32_t r) {
     OCluster *cl = get_cluster(c, tid, left, right);        /* :315-316 */
     if (cl->n == cl->cap) { cl->cap = cl->cap ? cl->cap * 2 : 4; cl->reads = (uint32_t *)realloc(cl->reads, sizeof(uint32_t) * (size_t)cl->cap); }
     cl->reads[cl->n++] = r;
-    c->tick++;                                              /* :319-322 */
     int period = c->prm->flush_period > 0 ? c->prm->flush_period : 10000;
+    if (c->b->tick) {
+        /* key-range shard: the global tick of this read comes with the batch, and the flush events of reads that live in
+         * OTHER shards (they fire between two of this shard's reads) are replayed from the global event table first */
+        const int64_t t = (int64_t)c->b->tick[r];
+        while (c->next_ev < c->n_ev && (int64_t)(c->next_ev + 1) * period < t) { periodic_flush(c, c->ev_tid[c->next_ev], c->ev_pos[c->next_ev]); c->next_ev++; }
+        c->tick = t;
+        if (t % period == 0 && c->next_ev < c->n_ev && (int64_t)(c->next_ev + 1) * period == t) c->next_ev++;   /* this read IS event next_ev */
+    } else
+        c->tick++;                                          /* :319-322 */
     if (c->tick % period != 0) return;
     periodic_flush(c, tid, k->pos);
 }
 
 /* Gencore::consensus — the read loop                                                  gencore.cpp:205-279 */
 int orc_run(const gce_params *prm, const orc_reference *ref, gce_batch *batch, orc_result *out) {
+    return orc_run_shard(prm, ref, batch, 0, NULL, NULL, out);
+}
+
+/* The same over a key-range shard of a stream (gencore_amd/shard.py): batch->tick carries every read's global tick and
+ * (ev_tid, ev_pos) are the reads on which the whole stream's periodic flushes fire (gencore.cpp:319-322). */
+int orc_run_shard(const gce_params *prm, const orc_reference *ref, gce_batch *batch, int32_t n_events, const int32_t *ev_tid,
+                  const int32_t *ev_pos, orc_result *out) {
     memset(out, 0, sizeof *out);
     int64_t n = batch->n_reads;
     out->n_reads = n;
@@ -945,6 +961,7 @@ int orc_run(const gce_params *prm, const orc_reference *ref, gce_batch *batch, o
     Ctx ctx; memset(&ctx, 0, sizeof ctx);
     ctx.prm = prm; ctx.ref = ref; ctx.b = batch; ctx.res = out;
     ctx.tick = prm->tick_offset;
+    ctx.n_ev = batch->tick ? n_events : 0; ctx.ev_tid = ev_tid; ctx.ev_pos = ev_pos;
     htab_rebuild(&ctx);
 
     int last_tid = -1, last_pos = -1, out_set_cleared = 0, finished = 0;
@@ -968,7 +985,8 @@ int orc_run(const gce_params *prm, const orc_reference *ref, gce_batch *batch, o
     if (!ctx.failed) {
         /* :276-279.  In a coordinate-sharded run a flush event of a LATER slice (larger tid) would have drained
          * everything pending here through the periodic path, i.e. with -d instead of the end-of-file threshold. */
-        if (!finished) { finished = 1; finish_consensus(&ctx, prm->trailing_flush ? prm->proper_umi_diff_threshold : prm->unproper_umi_diff_threshold); }
+        while (!finished && ctx.next_ev < ctx.n_ev) { periodic_flush(&ctx, ctx.ev_tid[ctx.next_ev], ctx.ev_pos[ctx.next_ev]); ctx.next_ev++; }   /* later shards' events */
+        if (!finished) { finished = 1; finish_consensus(&ctx, (prm->trailing_flush && !batch->tick) ? prm->proper_umi_diff_threshold : prm->unproper_umi_diff_threshold); }
     }
     /* clusters still pending after an earlier finish are never processed (released in ~Gencore, gencore.cpp:23) */
     for (int64_t i = 0; i < ctx.n_pending; i++) cluster_free(ctx.pending[i]);

@@ -46,6 +46,8 @@ typedef struct orc_result {
 
 /* Run the whole path over one coordinate-sorted stream.  batch->seq / batch->qual are mutated in place. */
 int  orc_run(const gce_params *prm, const orc_reference *ref, gce_batch *batch, orc_result *out);
+int  orc_run_shard(const gce_params *prm, const orc_reference *ref, gce_batch *batch, int32_t n_events, const int32_t *ev_tid,
+                   const int32_t *ev_pos, orc_result *out);   /* key-range shard: batch->tick + the stream's flush events */
 void orc_free_result(orc_result *r);
 
 /* unit-level entry points (known-answer tests) */

@@ -41,6 +41,8 @@ def lib():
             build()
         L = C.CDLL(LIB_PATH)
         L.orc_run.argtypes = [C.POINTER(GceParams), C.POINTER(OrcReference), C.POINTER(GceBatch), C.POINTER(OrcResult)]
+        L.orc_run_shard.argtypes = [C.POINTER(GceParams), C.POINTER(OrcReference), C.POINTER(GceBatch), C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.POINTER(OrcResult)]
         L.orc_free_result.argtypes = [C.POINTER(OrcResult)]
         L.orc_free_result.restype = None
         L.orc_get_umi.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
@@ -110,13 +112,19 @@ def make_reference(contigs):
     return ref, (data, nb, keep)
 
 
-def run(batch, params, contigs=None):
-    """Run the oracle over a ReadBatch (NOT mutated: works on a copy).  Returns a ResultTable."""
+def run(batch, params, contigs=None, events=None):
+    """Run the oracle over a ReadBatch (NOT mutated: works on a copy).  Returns a ResultTable.
+    events = (ev_tid, ev_pos) of the whole stream when `batch` is a key-range shard carrying batch.tick."""
     work = batch.copy()
+    work.tick = batch.tick
     st = work.as_struct()
     ref, keep = make_reference(contigs or [])
     res = OrcResult()
-    status = lib().orc_run(C.byref(params), C.byref(ref), C.byref(st), C.byref(res))
+    if events is not None:
+        et, ep = np.ascontiguousarray(events[0], np.int32), np.ascontiguousarray(events[1], np.int32)
+        status = lib().orc_run_shard(C.byref(params), C.byref(ref), C.byref(st), int(et.size), et.ctypes.data, ep.ctypes.data, C.byref(res))
+    else:
+        status = lib().orc_run(C.byref(params), C.byref(ref), C.byref(st), C.byref(res))
     n = work.n
 
     def arr(ptr, dt):

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: two gloo ranks, each owns a coordinate shard (gencore_amd/shard.py), no data-path collective,
-one all-reduce(sum) of the additive Stats blocks — the same plumbing bench.py uses with RCCL.  The per-shard
-compute stand-in is the oracle (tests may use it); the product's kernels are covered by the -m gpu tests."""
+"""N>1 path on CPU: two gloo ranks, each owns a key-range shard cut inside a contig (gencore_amd/shard.py: global ticks + the
+stream's flush events), no data-path collective, one all-reduce(sum) of the additive Stats blocks — the same plumbing
+bench.py uses with RCCL.  The per-shard compute stand-in is the oracle (tests may use it); the product's kernels are
+covered by the -m gpu tests."""
 import os
 import socket
 import sys
@@ -22,11 +23,12 @@ def _worker(rank, world, port, seed, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import fuzzgen
-    from gencore_amd.shard import shard_by_contig
+    from gencore_amd.shard import plan_shards, shard_by_plan, stream_context
     from oracle import oracle_py
     batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, umi_mode="prefix", period=13)
-    sub, idx, ctx = shard_by_contig(batch, world, rank, over["flush_period"])
-    r = oracle_py.run(sub, fuzzgen.make_params(dict(over, **ctx), contig_len), reference)
+    tick, ev_tid, ev_pos = stream_context(batch.core, over["flush_period"])
+    sub, idx = shard_by_plan(batch, plan_shards(batch.core, world, "range"), rank, tick)
+    r = oracle_py.run(sub, fuzzgen.make_params(over, contig_len), reference, events=(ev_tid, ev_pos))
     stats = torch.from_numpy(np.concatenate([r.pre.as_array(), r.post.as_array()]))
     dist.barrier()
     dist.all_reduce(stats)                     # the final Stats merge

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import fuzzgen
-from gencore_amd.batch import diff_results
+from gencore_amd.batch import check_output_order, diff_results
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ def run_both(batch, params, reference):
         assert ei.value.status == want.status
         return None, want
     got = run_stream(batch, params, reference)
-    diffs = diff_results(batch, got, want)
+    diffs = diff_results(batch, got, want) + check_output_order(batch, got.rows)
     assert not diffs, "\n".join(diffs)
     assert np.array_equal(got.out_index, np.nonzero(got.out_flag)[0])
     return got, want
@@ -54,21 +54,6 @@ def test_fuzz_deep_cluster(built, seed, deep):
     got, want = run_both(batch, fuzzgen.make_params(over, contig_len), reference)
     if seed == 200:
         assert got.fr.max() >= 0
-
-
-@pytest.mark.parametrize("seed", [0, 3, 7, 12, 29, 33, 41, 600, 603])
-def test_fused_lds_group_kernel(built, seed, monkeypatch):
-    """GCE_FUSED_GROUPS=1: the LDS-resident one-wave-per-group kernel (gce_fused.hpp) must give the same bits."""
-    monkeypatch.setenv("GCE_FUSED_GROUPS", "1")
-    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, exotic=seed >= 600)
-    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
-
-
-@pytest.mark.parametrize("name,n_pairs", [("cfg3", 60000), ("cfg2", 40000)])
-def test_fused_lds_group_kernel_synthetic(built, name, n_pairs, monkeypatch):
-    monkeypatch.setenv("GCE_FUSED_GROUPS", "1")
-    batch, prm, ref = synth_case(name, n_pairs)
-    run_both(batch, prm, ref)
 
 
 def synth_case(name, n_pairs, **over):
@@ -121,9 +106,14 @@ def test_multiple_submits_concatenate(built):
     e.add_reads(slice_batch(batch, np.arange(0, cut)))
     e.add_reads(slice_batch(batch, np.arange(cut, batch.n)))
     e.finish()
-    got = e.output()
+    got = e.output(batch)
+    with pytest.raises(Exception):          # a second gce_process without a new submit: the stream was mutated in place
+        e.finish()
+    e.add_reads(batch)                      # a new submit after a process starts a new stream (no stale sizes)
+    e.finish()
+    again = e.output(batch)
     e.close()
-    assert not diff_results(batch, got, want)
+    assert not diff_results(batch, got, want) and not diff_results(batch, again, want)
 
 
 def test_error_codes_match_reference_fatal_paths(built):
@@ -242,17 +232,143 @@ def test_full_size_shard_property(built):
     assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post_sum, whole.post.as_array())
 
 
-@pytest.mark.parametrize("switch", ["GCE_PAIR2", "GCE_SCORE2", "GCE_LEAN2"])
-def test_alternate_kernel_paths(built, switch):
-    """The one-wave-per-cluster pairing, the 8-lanes-per-pair scoring and the one-wave-per-side vote stay selectable
-    (README "Diagnostic switches").  They are read once per process, so each runs a slice of this suite in a child process."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ)
-    env[switch] = "0"
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_quirks.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "fuzz_stream or fuzz_umi_modes or quirk_cases or synthetic_configs"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ the zero-copy entry points
+def _hip_runtime():
+    """The HIP runtime this process already uses (torch's), for plain hipMemcpy of the engine's device-side table."""
+    import ctypes as C
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return C.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime loaded")
+
+
+def run_device(data, params, pad=64, shift=0):
+    """The path bench.py times: stream built on the GPU (synth), gce_submit_device -> gce_process -> gce_result_device, table
+    copied back with torch.  `shift` misaligns every blob by that many bytes; `pad` bytes stay readable behind each blob
+    (include/gencore_amd.h: 16 are required)."""
+    import ctypes as C
+    import torch
+    from gencore_amd import capi
+    from gencore_amd.batch import table_from_rows
+    from gencore_amd.capi import GceBatch, GceResult
+    lib = capi.load_library()
+    t = data.t
+    keep = {}
+
+    def blob(name, dtype=None):
+        x = t[name] if dtype is None else t[name].to(dtype)
+        y = torch.zeros(x.numel() * x.element_size() + pad + shift + 16, dtype=torch.uint8, device=x.device)
+        v = y[shift:shift + x.numel() * x.element_size()]
+        v.copy_(x.contiguous().view(torch.uint8).reshape(-1))
+        keep[name] = y
+        return y.data_ptr() + shift
+    b = GceBatch()
+    b.n_reads = data.n_reads
+    b.core = t["core"].data_ptr()
+    b.qname_off, b.cigar_off, b.seq_off, b.qual_off = (t[k].data_ptr() for k in ("qname_off", "cigar_off", "seq_off", "qual_off"))
+    b.qname, b.seq, b.qual = blob("qname"), blob("seq"), blob("qual")
+    b.cigar = t["cigar"].data_ptr()
+    b.nm, b.nm_type, b.mi_off, b.mi, b.tick = t["nm"].data_ptr(), t["nm_type"].data_ptr(), None, None, None
+    b.qname_bytes, b.cigar_words, b.seq_bytes, b.qual_bytes, b.mi_bytes = t["qname"].numel(), t["cigar"].numel(), t["seq"].numel(), t["qual"].numel(), 0
+    eng = C.c_void_p()
+    assert lib.gce_create(C.byref(params), C.byref(eng)) == 0
+    try:
+        for tid, (nib, ln) in enumerate(data.reference):
+            assert lib.gce_set_reference(eng, tid, nib.data_ptr(), ln) == 0
+        assert lib.gce_submit_device(eng, C.byref(b)) == 0
+        rc = lib.gce_process(eng)
+        assert rc == 0, lib.gce_last_error(eng)
+        r = GceResult()
+        assert lib.gce_result_device(eng, C.byref(r)) == 0
+        n = int(r.n_out)
+
+        hip = _hip_runtime()
+
+        def dev(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dt)
+            out = np.empty(count, dt)
+            assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0     # hipMemcpyDeviceToHost
+            return out
+        torch.cuda.synchronize()
+        rows = {k: dev(getattr(r, k), n, dt) for k, dt in (("src", np.uint32), ("kind", np.uint8), ("qname_src", np.uint32), ("nm_new", np.int32),
+                                                           ("fr", np.int16), ("rr", np.int16), ("mate", np.uint32), ("seq_off", np.uint64), ("qual_off", np.uint64))}
+        rows["seq"] = dev(r.seq, int(r.seq_bytes), np.uint8)
+        rows["qual"] = dev(r.qual, int(r.qual_bytes), np.uint8)
+        pre, post = capi.GceStats(), capi.GceStats()
+        C.memmove(C.byref(pre), C.byref(r.pre), C.sizeof(capi.GceStats))
+        C.memmove(C.byref(post), C.byref(r.post), C.sizeof(capi.GceStats))
+        host = data.to_batch()
+        return host, table_from_rows(host, rows, pre, post)
+    finally:
+        lib.gce_destroy(eng)
+
+
+@pytest.mark.parametrize("name,n_pairs,shift", [("cfg2", 60000, 0), ("cfg3", 60000, 0), ("cfg5", 50000, 0), ("cfg3", 30000, 3), ("cfg1s", None, 1)])
+def test_device_entry_points_against_oracle(built, name, n_pairs, shift):
+    """gce_submit_device / gce_result_device (caller-owned HBM, zero copy) — the entry points bench.py times — against the oracle;
+    shift != 0: every blob misaligned and exactly 16 readable bytes behind it (the documented contract)."""
+    import torch
+    from gencore_amd import synth
+    from gencore_amd.capi import default_params
+    from oracle import oracle_py
+    d = synth.generate(name, n_pairs=n_pairs, device="cuda")
+    tl = np.asarray(d.target_len, np.uint32)
+    prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"], cluster_size_req=d.info["supporting_reads"])
+    host, got = run_device(d, prm, pad=16 if shift else 64, shift=shift)
+    want = oracle_py.run(host, prm, d.reference_host())
+    assert want.status == 0
+    diffs = diff_results(host, got, want) + check_output_order(host, got.rows)
+    assert not diffs, "\n".join(diffs)
+    assert len(got.emitted()) > 0
+
+
+@pytest.mark.parametrize("seed,world,mode", [(700, 2, "range"), (701, 3, "range"), (702, 4, "lpt"), (703, 5, "range")])
+def test_key_range_shards_equal_whole_stream(built, seed, world, mode):
+    """Shards cut by cluster key INSIDE a contig (gencore_amd/shard.py: gce_batch.tick + gce_set_flush_events): every shard on the
+    engine equals the oracle on the same shard, and the shards together equal the whole stream."""
+    from gencore_amd.engine import run_stream
+    from gencore_amd.shard import plan_shards, shard_by_plan, stream_context
+    from oracle import oracle_py
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=90, umi_mode="prefix", period=[11, 29, 5][seed % 3])
+    prm = fuzzgen.make_params(over, contig_len)
+    whole, _ = run_both(batch, prm, reference)
+    tick, et, ep = stream_context(batch.core, over["flush_period"])
+    plan = plan_shards(batch.core, world, mode)
+    flags = np.zeros(batch.n, np.uint8); fr = np.full(batch.n, -1, np.int16)
+    pre = np.zeros(114, np.int64); post = np.zeros(114, np.int64)
+    for r in range(world):
+        sub, idx = shard_by_plan(batch, plan, r, tick)
+        got = run_stream(sub, prm, reference, events=(et, ep))
+        want = oracle_py.run(sub, prm, reference, events=(et, ep))
+        assert not diff_results(sub, got, want)
+        flags[idx], fr[idx] = got.out_flag, got.fr
+        pre += got.pre.as_array(); post += got.post.as_array()
+    assert np.array_equal(flags, whole.out_flag) and np.array_equal(fr, whole.fr)
+    assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
+
+
+def test_key_range_shards_at_scale(built):
+    """cfg3 generator, 200 k pairs cut into 4 key ranges (the cuts fall inside contigs and inside targets)."""
+    from gencore_amd import synth
+    from gencore_amd.capi import default_params
+    from gencore_amd.engine import run_stream
+    from gencore_amd.shard import plan_shards, shard_by_plan, stream_context
+    d = synth.generate("cfg3", n_pairs=200000)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"], cluster_size_req=2)
+    ref = d.reference_host()
+    whole = run_stream(batch, prm, ref)
+    tick, et, ep = stream_context(batch.core, 10000)
+    plan = plan_shards(batch.core, 4, "range")
+    flags = np.zeros(batch.n, np.uint8); pre = np.zeros(114, np.int64); post = np.zeros(114, np.int64)
+    for r in range(4):
+        sub, idx = shard_by_plan(batch, plan, r, tick)
+        got = run_stream(sub, prm, ref, events=(et, ep))
+        flags[idx] = got.out_flag
+        pre += got.pre.as_array(); post += got.post.as_array()
+    assert np.array_equal(flags, whole.out_flag)
+    assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())

@@ -67,6 +67,33 @@ def test_sharded_stream_equals_whole_stream(oracle, seed, world):
     assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
 
 
+@pytest.mark.parametrize("seed,world,mode", [(400, 2, "range"), (401, 3, "range"), (402, 4, "lpt"), (403, 5, "range"), (407, 8, "range")])
+def test_key_range_shards_equal_whole_stream(oracle, seed, world, mode):
+    """Cuts by cluster key (tid, left) INSIDE a contig: a shard's reads interleave with its neighbours' in stream order, so every
+    read carries its global tick and every shard replays the whole stream's flush events (gencore.cpp:319-354).  mode="lpt" is the
+    depth^2-weighted deal of whole clusters used for ultra-deep hotspots."""
+    from gencore_amd.shard import plan_shards, shard_by_plan, stream_context
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=70, umi_mode="prefix", period=[11, 29, 5][seed % 3])
+    prm = fuzzgen.make_params(over, contig_len)
+    whole = oracle.run(batch, prm, reference)
+    tick, et, ep = stream_context(batch.core, over["flush_period"])
+    plan = plan_shards(batch.core, world, mode)
+    flags = np.zeros(batch.n, np.uint8); fr = np.full(batch.n, -1, np.int16)
+    pre = np.zeros(114, np.int64); post = np.zeros(114, np.int64)
+    cuts_inside_contig = False
+    for r in range(world):
+        sub, idx = shard_by_plan(batch, plan, r, tick)
+        if r and len(idx) and batch.core["tid"][idx[0]] in batch.core["tid"][plan == r - 1]:
+            cuts_inside_contig = True
+        res = oracle.run(sub, prm, reference, events=(et, ep))
+        assert res.status == 0
+        flags[idx], fr[idx] = res.out_flag, res.fr
+        pre += res.pre.as_array(); post += res.post.as_array()
+    assert cuts_inside_contig
+    assert np.array_equal(flags, whole.out_flag) and np.array_equal(fr, whole.fr)
+    assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
+
+
 def test_oracle_matches_frozen_regression_vectors(oracle):
     """tests/golden/oracle_regression.json: digests of oracle outputs frozen by tests/golden/make_golden.py.
     These are REGRESSION vectors of the oracle itself (the reference ships no golden output for this path and cannot
@@ -78,3 +105,41 @@ def test_oracle_matches_frozen_regression_vectors(oracle):
     for case in frozen["cases"]:
         got = make_golden.digest_case(case["seed"], case["kwargs"])
         assert got == case["digest"], case
+
+
+def rows_from_table(batch, t):
+    """The engine's table of emitted records (gce_result) rebuilt from a per-read ResultTable: rows in bamComp order
+    (gencore.h:19-47, input index as the last key), compact 16-byte aligned blobs."""
+    em = np.nonzero(t.out_flag)[0]
+    c = batch.core[em]
+    order = np.lexsort((em, c["isize"], c["mpos"], c["mtid"], c["pos"], c["tid"]))
+    src = em[order].astype(np.uint32)
+    row_of = np.full(batch.n, 0xFFFFFFFF, np.uint32); row_of[src] = np.arange(len(src), dtype=np.uint32)
+    lq = batch.core["l_qseq"].astype(np.int64)[src]
+    su, qu = ((lq + 1) // 2 + 15) // 16 * 16, (lq + 15) // 16 * 16
+    seq_off, qual_off = np.cumsum(su) - su, np.cumsum(qu) - qu
+    seq, qual = np.zeros(int(su.sum()), np.uint8), np.zeros(int(qu.sum()), np.uint8)
+    for k, i in enumerate(src):
+        i = int(i); L = int(lq[k])
+        seq[seq_off[k]:seq_off[k] + (L + 1) // 2] = t.seq[int(batch.seq_off[i]):int(batch.seq_off[i]) + (L + 1) // 2]
+        qual[qual_off[k]:qual_off[k] + L] = t.qual[int(batch.qual_off[i]):int(batch.qual_off[i]) + L]
+    m = t.mate[src]
+    mate = np.where(m == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), row_of[np.where(m == 0xFFFFFFFF, 0, m).astype(np.int64)])
+    return dict(src=src, kind=t.out_flag[src], qname_src=t.qname_src[src], nm_new=t.nm_new[src], fr=t.fr[src], rr=t.rr[src],
+                mate=mate.astype(np.uint32), seq_off=seq_off.astype(np.uint64), qual_off=qual_off.astype(np.uint64), seq=seq, qual=qual)
+
+
+@pytest.mark.parametrize("seed", [3, 17, 604])
+def test_result_table_round_trip(oracle, seed):
+    """gce_result (rows of emitted records) <-> the per-read form diff_results compares: host-side plumbing of every GPU test."""
+    from gencore_amd.batch import check_output_order, table_from_rows
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=50, exotic=seed >= 600)
+    want = oracle.run(batch, fuzzgen.make_params(over, contig_len), reference)
+    rows = rows_from_table(batch, want)
+    assert not check_output_order(batch, rows)
+    back = table_from_rows(batch, rows, want.pre, want.post)
+    assert not diff_results(batch, back, want)
+    swapped = dict(rows)
+    if len(rows["src"]) > 1:
+        swapped["src"] = rows["src"][::-1].copy()
+        assert check_output_order(batch, swapped)
