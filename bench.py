@@ -79,17 +79,21 @@ def fetch_rows(capi, lib, eng):
     return rows, pre, post
 
 
-def _cpu_shard_worker(args):
-    """One process of the all-cores CPU baseline: the oracle over one contig-range shard of the sample."""
+_CPU_JOBS = None      # set before the fork: the workers of the all-cores CPU baseline inherit the shards copy-on-write
+
+
+def _cpu_shard_worker(k, barrier, q):
+    """One process of the all-cores CPU baseline: the oracle over one contiguous shard of the sample."""
     import numpy as np
     from gencore_amd import capi
     from oracle import oracle_py
-    sub, ctx, tl, umi_prefix, s_req, ref_host = args
+    sub, ctx, tl, umi_prefix, s_req, ref_host = _CPU_JOBS[k]
     tl = np.asarray(tl, np.uint32)
     prm = capi.default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=umi_prefix, cluster_size_req=s_req, **ctx)
+    barrier.wait()
     t0 = time.perf_counter()
     res = oracle_py.run(sub, prm, ref_host)
-    return res.status, time.perf_counter() - t0, res.pre.as_array(), res.post.as_array(), int((res.out_flag != 0).sum())
+    q.put((k, res.status, time.perf_counter() - t0, res.pre.as_array(), res.post.as_array()))
 
 
 def main():
@@ -132,6 +136,8 @@ def main():
     over = {}
     if workload == "cfg3":
         over["scale"] = args.scale if args.scale is not None else 1.0     # hg19-length contigs (3.04 Gb); tests use the 0.1 default
+    if workload == "cfg4s":
+        over["scale"] = args.scale if args.scale is not None else 0.125 * world   # 100 M pairs over hg19 at 8 GPUs; an eighth of both per GPU
 
     # ------------------------------------------------------------------ workload (synthetic, generated on the GPU)
     stream_ctx = None
@@ -252,7 +258,6 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (oracle port) + parity of the timed entry points
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from gencore_amd.shard import clustered_mask, slice_contiguous
         from oracle import oracle_py
         sample_pairs = min(args.cpu_sample_pairs, n_pairs)
         sd = synth.generate(workload, n_pairs=sample_pairs, seed=12345, device=dev, **over)
@@ -285,33 +290,35 @@ def main():
                            "(bases, quals, NM, qname source, FR/RR, mate), both Stats blocks, bamComp order")
         if diffs:
             parity["first_diffs"] = diffs[:3]
-        # all host cores: N independent processes on contig-range shards of the same sample (the only way the single-threaded
-        # reference scales), Stats merged; wall time of the slowest
+        # all host cores: N independent processes on contiguous shards of the same sample cut where no cluster spans (the only way
+        # the single-threaded reference scales), Stats merged and compared; wall time from a common start to the last result
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         multi = None
         if cores > 1:
             import multiprocessing as mp
-            tid = sb.core["tid"].astype(np.int64)
-            cm = clustered_mask(sb.core)
-            counts = np.bincount(tid[tid >= 0], minlength=len(stl))
-            cum = np.cumsum(counts)
-            nshard = min(cores, len(stl))
-            bounds = sorted(set([0] + [int(np.searchsorted(cum, cum[-1] * r / nshard, side="left")) + 1 for r in range(1, nshard)] + [len(stl)]))
-            total_ticks = int(cm.sum())
-            jobs = []
-            for lo, hi in zip(bounds[:-1], bounds[1:]):
-                idx = np.nonzero((tid >= lo) & (tid < hi))[0]
-                if not len(idx):
-                    continue
-                before, mine = int(cm[tid < lo].sum()), int(cm[idx].sum())
-                ctx = dict(tick_offset=before, trailing_flush=int(total_ticks // 10000 > (before + mine) // 10000))
-                jobs.append((slice_contiguous(sb, int(idx[0]), int(idx[-1]) + 1), ctx, sd.target_len, sd.info["umi_prefix"], sd.info["supporting_reads"], ref_host))
+            from gencore_amd.shard import contiguous_cuts, shard_contiguous
+            global _CPU_JOBS
+            nproc = min(cores, 64)
+            bounds = contiguous_cuts(sb.core, nproc, sd.target_len)
+            _CPU_JOBS = []
+            for r in range(nproc):
+                if bounds[r] < bounds[r + 1]:
+                    sub, _, ctx = shard_contiguous(sb, bounds, r)
+                    _CPU_JOBS.append((sub, ctx, sd.target_len, sd.info["umi_prefix"], sd.info["supporting_reads"], ref_host))
+            ctxm = mp.get_context("fork")
+            barrier, q = ctxm.Barrier(len(_CPU_JOBS) + 1), ctxm.Queue()
+            procs = [ctxm.Process(target=_cpu_shard_worker, args=(k, barrier, q)) for k in range(len(_CPU_JOBS))]
+            for pr in procs:
+                pr.start()
+            barrier.wait()
             m0 = time.perf_counter()
-            with mp.get_context("fork").Pool(len(jobs)) as pool:
-                outs = pool.map(_cpu_shard_worker, jobs)
+            outs = [q.get(timeout=600) for _ in procs]
             ms_ = time.perf_counter() - m0
-            ok = all(o[0] == 0 for o in outs) and np.array_equal(sum(o[2] for o in outs), res.pre.as_array()) and np.array_equal(sum(o[3] for o in outs), res.post.as_array())
-            multi = dict(value=round(sd.info["n_pairs"] / ms_, 1), processes=len(jobs), host_cores=cores, seconds=round(ms_, 2), stats_equal_single=bool(ok))
+            for pr in procs:
+                pr.join(60)
+            ok = all(o[1] == 0 for o in outs) and np.array_equal(sum(o[3] for o in outs), res.pre.as_array()) and np.array_equal(sum(o[4] for o in outs), res.post.as_array())
+            multi = dict(value=round(sd.info["n_pairs"] / ms_, 1), processes=len(procs), host_cores=cores, seconds=round(ms_, 2),
+                         slowest_process_seconds=round(max(o[2] for o in outs), 2), stats_equal_single=bool(ok))
         cpu = dict(value=round(sd.info["n_pairs"] / cs, 1), unit="read-pairs/s", cores=1, kind="port",
                    sample="%s generator, %d pairs, oracle/gencore_oracle.c single thread, %.1f s" % (workload, sd.info["n_pairs"], cs),
                    all_cores=multi)

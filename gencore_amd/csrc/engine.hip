@@ -56,7 +56,7 @@ struct gce_engine {
     // output table (gce_result): device arrays + host copies
     DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_rowof, o_units, o_soff, o_qoff, o_seq, o_qual, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
-    DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, tcount, toff;
+    DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
     DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
@@ -132,7 +132,7 @@ void gce_destroy(gce_engine *e) {
                      &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
                      &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->chunk_cnt,
-                     &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->tcount, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
+                     &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
@@ -344,6 +344,12 @@ int gce_process(gce_engine *e) {
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
     p.tick_offset = e->have_tick ? 0 : e->prm.tick_offset; p.trailing_flush = e->have_tick ? 0 : e->prm.trailing_flush;
+    {   // packed cluster key of the bucket table: bits of the largest tid and of the longest contig
+        uint32_t mx = 1; for (uint32_t v : e->target_len) mx = std::max(mx, v);
+        int bt = 1; while (bt < 31 && (1ll << bt) < (long long)std::max<size_t>(e->target_len.size(), 1)) bt++;
+        int bl = 1; while (bl < 32 && (1ull << bl) <= (uint64_t)mx) bl++;
+        p.key_bt = bt; p.key_bl = bl;
+    }
     p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
 
     // ---- allocations that only depend on N
@@ -353,7 +359,7 @@ int gce_process(gce_engine *e) {
     const int64_t max_events = e->have_tick ? (int64_t)e->h_ev_tid.size() + 2 : (p.tick_offset % p.period + N) / p.period + 2;
     w.max_events = (int)max_events;
     // buckets: 1.25 x reads (worst case, every read its own cluster, still probes at load 0.8; typical load is a few percent).
-    // Every per-step pass over the table (clear, count scan, offsets) is proportional to T, so T is not rounded to a power of two.
+    // The per-step clear is proportional to T, so T is not rounded to a power of two.
     uint64_t T = ((uint64_t)n1 + (uint64_t)n1 / 4 + 2 * SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
     w.tsize = T; w.tinv = 1.0 / (double)T;
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
@@ -362,7 +368,7 @@ int gce_process(gce_engine *e) {
     ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
     ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
-    ENS(table, T * 8); ENS(tcount, T * 4); ENS(toff, T * 4);
+    ENS(table, T * sizeof(TabEntry)); ENS(toff, T * 4);
     ENS(k64, n1 * 24); ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
     ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
     w.slow_list = e->slow_list.as<uint32_t>();
@@ -373,7 +379,7 @@ int gce_process(gce_engine *e) {
     w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
     w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
-    w.table = e->table.as<uint64_t>(); w.tcount = e->tcount.as<uint32_t>(); w.toff = e->toff.as<uint32_t>();
+    w.tab = e->table.as<TabEntry>(); w.toff = e->toff.as<uint32_t>();
     w.k64 = e->k64.as<uint64_t>(); w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
     w.pu = e->pu.as<uint32_t>(); w.pg = e->pg.as<uint32_t>(); w.gpl = e->gpl.as<uint32_t>(); w.gpr = e->gpr.as<uint32_t>();
     w.grp_begin = e->grp_begin.as<uint32_t>(); w.grp_n = e->grp_n.as<uint32_t>();
@@ -388,8 +394,7 @@ int gce_process(gce_engine *e) {
     }
     hipStream_t s = e->stream;
     HIPCHK(hipEventRecord(e->ev[EV_START], s));
-    HIPCHK(hipMemsetAsync(e->table.p, 0xFF, T * 8, s));
-    HIPCHK(hipMemsetAsync(e->tcount.p, 0, T * 4, s));
+    HIPCHK(hipMemsetAsync(e->table.p, 0, T * sizeof(TabEntry), s));
     HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
     if (N > 0) {
         // ---- prescan + tick scan + flush events (the latter two come with the batch for key-range shards)
@@ -406,9 +411,9 @@ int gce_process(gce_engine *e) {
     // ---- bucket offsets + compact cluster list.  cl_* arrays are sized by N (a cluster has >= 1 read).
     ENS(cl_slot, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);
     w.cl_slot = e->cl_slot.as<uint32_t>(); w.cl_start = e->cl_start.as<uint32_t>(); w.cl_n = e->cl_n.as<uint32_t>();
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_T), dim3(256), 0, s, (const uint32_t *)w.tcount, (uint64_t)T, w.scan_part);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_T, &w.si->n_clusters, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(k_table_apply, dim3(nblk_T), dim3(256), 0, s, w, (uint64_t)T);
+    hipLaunchKernelGGL(k_own_reduce, dim3(nblk_N), dim3(256), 0, s, w, (uint64_t)N);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_clusters, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_own_apply, dim3(nblk_N), dim3(256), 0, s, w, (uint64_t)N);
     if (N > 0) hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, s, N, w);
     HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
     if ((rc = read_si(e)) != GCE_OK) return rc;

@@ -41,6 +41,7 @@ struct DevParams {
     int32_t n_targets;
     const uint32_t *target_len;
     const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
+    int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
     int64_t tick_offset;
     int32_t trailing_flush;
     int32_t n_ref;
@@ -404,17 +405,6 @@ __device__ __forceinline__ ClusterKey d_key(const gce_core &c, const DevParams &
     }
     return k;
 }
-// Bucket of a cluster key.  The stream is coordinate sorted, so consecutive reads carry neighbouring `left` values:
-// a LOCALITY-PRESERVING bucket index (genome-linear left, two buckets per position, low bit from right/instance) makes
-// the table accesses of the clustering scan a sliding window that lives in L2 instead of 64-byte random HBM touches.
-// Collisions (same left, other right/instance, or positions 2^k apart) fall through to linear probing.
-__device__ __forceinline__ uint64_t d_key_hash(const ClusterKey &k, uint32_t inst, const DevParams &p) {
-    uint64_t g = (k.tid >= 0 && k.tid < p.n_targets && p.target_cum) ? p.target_cum[k.tid] : (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
-    uint64_t m = ((uint64_t)k.right * 0x165667B19E3779F9ull) ^ ((uint64_t)inst * 0xD6E8FEB86659FD93ull);
-    m ^= m >> 29;
-    return ((g + (uint64_t)(uint32_t)k.left) << 1) | (m & 1);
-}
-
 // x mod T for a table size that is not a power of two: double-reciprocal quotient estimate (exact after one correction
 // step while x < 2^52, which covers every genome-linear bucket index); anything larger takes the 64-bit remainder.
 __device__ __forceinline__ uint64_t d_bucket(uint64_t x, uint64_t T, double tinv) {

@@ -39,7 +39,7 @@ struct Work {
     // events
     int32_t *ev_tid, *ev_pos; uint32_t *ev_read; int max_events;
     // hash table
-    uint64_t *table; uint32_t *tcount, *toff; uint64_t tsize; double tinv;      // tsize buckets (any size, not a power of two)
+    struct TabEntry *tab; uint32_t *toff; uint64_t tsize; double tinv;   // tsize buckets (any size, not a power of two); toff is written sparsely
     // clusters
     uint32_t *cl_slot, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
     // cluster-local arrays (indexed by cl_start + k)
@@ -213,8 +213,48 @@ __device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *
     return ((int)(inst + 1) <= si->n_events) ? THR_PROPER : THR_NEVER;
 }
 
+// The bucket table: 16 bytes per bucket, the cluster's whole identity in the CAS word itself so that nobody ever has to WAIT for a
+// claimer to publish something (a wait on a lane of one's own wave deadlocks as soon as the compiler schedules the divergent blocks
+// the other way round -- it did).
+//   key   bit 63 = occupied (0 = empty: the table is cleared with one memset), bit 62 = EXOTIC
+//         normal : tid | left << bt | (right - left + 1) << (bt + bl)  -- an injective packing of the cluster key (bt / bl = bits of
+//                  the largest tid / contig length of the header).  The instance is NOT part of it: a read whose instance is the one
+//                  its key implies (inst = f(k) - 1, the overwhelming case: it arrives before the first flush that can take its
+//                  cluster) shares it with every other such read of the key.  Equal word <=> same cluster, no second load.
+//         exotic : instance (29 bits) | segment << 29 in bits 32..61, the CLAIMING READ's index in bits 0..31 -- for everything else:
+//                  cross-contig keys (negative right), fields that overflow the packing, reads that arrive after their key was
+//                  flushed (instance = own epoch), reads behind an unmapped read.  A follower compares the upper half, then the
+//                  cluster key of the claiming read (one dependent load of its key record; rare).
+//   ikey  instance | segment << 31 of the cluster (read by the per-cluster kernels for the UMI threshold, quirk Q1)
+//   count reads of the cluster so far: one atomicAdd per run of neighbouring reads gives the in-cluster ranks
+struct __attribute__((aligned(16))) TabEntry { unsigned long long key; uint32_t ikey; uint32_t count; };
+static_assert(sizeof(TabEntry) == 16, "TabEntry must stay 16 bytes");
+#define TAB_OCC (1ull << 63)
+#define TAB_EXO (1ull << 62)
+#define RANK_OWNER 0x80000000u          // bit 31 of rank[]: this read claimed its cluster's bucket (exactly one per cluster)
+
+// Bucket of a cluster key.  The stream is coordinate sorted, so consecutive reads carry neighbouring `left` values: a
+// LOCALITY-PRESERVING bucket index (genome-linear left, TAB_WAYS buckets per position, the way from right / instance) makes the
+// table accesses of the scan a sliding window that lives in L2 instead of 64-byte random HBM touches.  Capture panels stack
+// hundreds of clusters on a few hundred positions: 8 ways keep the local load low there.  Collisions fall through to linear probing.
+#define TAB_WAYS 8
+__device__ __forceinline__ uint64_t d_tab_index(const ClusterKey &k, uint32_t ikey, const DevParams &p) {
+    uint64_t g = (k.tid >= 0 && k.tid < p.n_targets && p.target_cum) ? p.target_cum[k.tid] : (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
+    uint64_t m = ((uint64_t)k.right * 0x165667B19E3779F9ull) ^ ((uint64_t)ikey * 0xD6E8FEB86659FD93ull);
+    m ^= m >> 29;
+    return (((g + (uint64_t)(uint32_t)k.left) & 0x0000FFFFFFFFFFFFull) * TAB_WAYS) | (m & (TAB_WAYS - 1));
+}
+__device__ __forceinline__ unsigned long long d_tab_key(const ClusterKey &k, uint32_t ikey, bool implied_instance, uint32_t read, const DevParams &p) {
+    const long long delta1 = k.right - (long long)k.left + 1;                     // |isize| for a nearby pair
+    const int bd = 62 - p.key_bt - p.key_bl;
+    if (implied_instance && !(ikey >> 31) && k.tid >= 0 && ((uint64_t)(uint32_t)k.tid >> p.key_bt) == 0 && k.left >= 0 && ((uint64_t)(uint32_t)k.left >> p.key_bl) == 0 &&
+        delta1 >= 0 && bd > 0 && ((uint64_t)delta1 >> bd) == 0)
+        return TAB_OCC | (uint64_t)(uint32_t)k.tid | ((uint64_t)(uint32_t)k.left << p.key_bt) | ((uint64_t)delta1 << (p.key_bt + p.key_bl));
+    return TAB_OCC | TAB_EXO | ((uint64_t)((ikey & 0x1FFFFFFFu) | ((ikey >> 31) << 29)) << 32) | read;
+}
+
 // CL_U consecutive 256-read chunks per block, one read of each per thread, written stage by stage so that the CL_U
-// dependent chains (key record -> flush events -> bucket probe -> CAS -> owner check -> rank atomic) overlap their
+// dependent chains (key record -> flush events -> bucket probe -> CAS -> rank atomic) overlap their
 // memory round trips: the scan is bound by latency x occupancy, not by issue.
 #define CL_U 2
 __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
@@ -264,8 +304,10 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
             T0[u] = w.ev_tid[j0]; P0[u] = w.ev_pos[j0]; T1[u] = w.ev_tid[j1]; P1[u] = w.ev_pos[j1]; T2[u] = w.ev_tid[j2]; P2[u] = w.ev_pos[j2];
         }
     }
+    bool implied[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
+        implied[u] = false;
         if (cl[u]) {
             // first event of this segment whose walk takes the key (gencore.cpp:333-354):
             //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
@@ -282,94 +324,106 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
                 if (takes(w.ev_tid[mid], w.ev_pos[mid])) z = mid; else a = mid + 1;
             }
             const int f = a + 1;                                                            // 1-based; hi+1 if none
+            implied[u] = e_[u] <= f - 1;                                                    // the instance every early read of the key gets
             ikey[u] |= (uint32_t)max(e_[u], f - 1);
         }
     }
     // ---- neighbouring lanes with the same (key, instance) are one run of one cluster (sorted input): only the run head
-    //      probes the table and issues the CAS; the others copy its bucket.
+    //      probes the table; it claims or finds the bucket and draws the ranks of the whole run with one atomicAdd.
     // (all shuffles are executed by every lane: a shuffle inside a divergent branch reads inactive source lanes as 0)
-    bool khead[CL_U], done[CL_U]; uint64_t h[CL_U], cur[CL_U];
+    bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U], hl[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
         const int p_cl = __shfl_up((int)cl[u], 1), p_tid = __shfl_up(key[u].tid, 1), p_left = __shfl_up(key[u].left, 1), p_ik = __shfl_up((int)ikey[u], 1);
         const long long p_right = __shfl_up((long long)key[u].right, 1);
         const bool same_prev = lane > 0 && cl[u] && p_cl && p_tid == key[u].tid && p_left == key[u].left && p_right == (long long)key[u].right && p_ik == (int)ikey[u];
         khead[u] = cl[u] && !same_prev;
-        h[u] = ~0ull; cur[u] = 0; done[u] = !khead[u];
-        if (khead[u]) { h[u] = d_bucket(d_key_hash(key[u], ikey[u], p), w.tsize, w.tinv); cur[u] = w.table[h[u]]; }
-    }
-#pragma unroll
-    for (int u = 0; u < CL_U; u++)                                                         // first probe: claim an empty bucket
-        if (khead[u] && cur[u] == EMPTY64) {
-            const uint64_t mine = ((uint64_t)ikey[u] << 32) | (uint32_t)idx[u];
-            cur[u] = atomicCAS((unsigned long long *)&w.table[h[u]], (unsigned long long)EMPTY64, (unsigned long long)mine);
-            if (cur[u] == EMPTY64) done[u] = true;                                          // claimed: this read owns the bucket
+        const unsigned long long heads = __ballot(khead[u]), bounds = __ballot(khead[u] || !cl[u]);
+        const unsigned long long later = bounds & ~((2ull << lane) - 1ull);
+        runlen[u] = (later ? __ffsll((long long)later) - 1 : 64) - lane;                    // valid on head lanes
+        hl[u] = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));                // my run's head lane (valid when cl)
+        h[u] = 0; tk[u] = 0; cur[u] = 0; rbase[u] = 0; owner[u] = false;
+        if (khead[u]) {
+            tk[u] = d_tab_key(key[u], ikey[u], implied[u], (uint32_t)idx[u], p);
+            if ((tk[u] & TAB_EXO) && (ikey[u] & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)idx[u]);   // > 2^29 flush events
+            h[u] = d_bucket(d_tab_index(key[u], ikey[u], p), w.tsize, w.tinv);
+            cur[u] = w.tab[h[u]].key;
         }
-    gce_core oc[CL_U];
+    }
+    bool done[CL_U];
 #pragma unroll
-    for (int u = 0; u < CL_U; u++) {                                                       // occupied by the same instance: whose key is it?
+    for (int u = 0; u < CL_U; u++) {                                                       // first probe: claim an empty bucket
+        done[u] = !khead[u];
+        if (khead[u] && cur[u] == 0ull) {
+            cur[u] = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
+            if (cur[u] == 0ull) { owner[u] = true; cur[u] = tk[u]; }
+        }
+    }
+    gce_core oc[CL_U];                                                                     // exotic followers: the claiming read's key record
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
         union { gce_core c; uint4 q[2]; } t;
         t.q[0] = make_uint4(0, 0, 0, 0); t.q[1] = t.q[0];
-        if (!done[u] && (uint32_t)(cur[u] >> 32) == ikey[u]) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + (uint32_t)cur[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
+        if (!done[u] && !owner[u] && (tk[u] & TAB_EXO) && (cur[u] >> 32) == (tk[u] >> 32)) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + (uint32_t)cur[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
         oc[u] = t.c;
     }
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
-        if (!done[u] && (uint32_t)(cur[u] >> 32) == ikey[u]) {
-            const ClusterKey ok = d_key(oc[u], p);
-            if (ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right) done[u] = true;
-        }
-        if (!done[u]) {                                                                     // collision: linear probing (rare)
-            const uint64_t mine = ((uint64_t)ikey[u] << 32) | (uint32_t)idx[u];
-            uint64_t hh = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
-            for (;;) {
-                uint64_t c = w.table[hh];
-                if (c == EMPTY64) {
-                    c = atomicCAS((unsigned long long *)&w.table[hh], (unsigned long long)EMPTY64, (unsigned long long)mine);
-                    if (c == EMPTY64) break;
-                }
-                if ((uint32_t)(c >> 32) == ikey[u]) {
-                    const gce_core o2 = b.core[(uint32_t)c];
-                    const ClusterKey ok = d_key(o2, p);
-                    if (ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right) break;
-                }
-                hh = hh + 1 == w.tsize ? 0 : hh + 1;
+        // in the usual case the first bucket is the cluster's (claimed just now, or found occupied by the same word) and this
+        // settles it; collisions walk on (linear probing, rare)
+        if (!done[u]) {
+            bool mine = owner[u];
+            if (!mine && (cur[u] >> 32) == (tk[u] >> 32)) {
+                if (!(tk[u] & TAB_EXO)) mine = (uint32_t)cur[u] == (uint32_t)tk[u];
+                else { const ClusterKey ok = d_key(oc[u], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
             }
-            h[u] = hh;
+            while (!mine) {
+                h[u] = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
+                unsigned long long c = w.tab[h[u]].key;
+                if (c == 0ull) {
+                    c = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
+                    if (c == 0ull) { owner[u] = true; break; }
+                }
+                if ((c >> 32) == (tk[u] >> 32)) {
+                    if (!(tk[u] & TAB_EXO)) mine = (uint32_t)c == (uint32_t)tk[u];
+                    else { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
+                }
+            }
+            if (owner[u]) w.tab[h[u]].ikey = ikey[u];
+            rbase[u] = atomicAdd(&w.tab[h[u]].count, (unsigned)runlen[u]);
         }
-    }
-    // ---- in-cluster rank: neighbouring lanes that landed in the same bucket (sorted input => runs) share ONE atomicAdd
-    uint32_t rbase[CL_U]; int hl[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        const unsigned long long kheads = __ballot(khead[u]);
-        const int kh = 63 - __clzll((long long)(kheads & ((2ull << lane) - 1ull)));
-        const uint64_t hh = (uint64_t)__shfl((long long)h[u], kh < 0 ? 0 : kh);
-        if (cl[u]) h[u] = hh;
-        const uint64_t hprev = (uint64_t)__shfl_up((long long)h[u], 1);
-        const bool head = cl[u] && (lane == 0 || hprev != h[u]);
-        const unsigned long long heads = __ballot(head), bounds = __ballot(head || !cl[u]);
-        rbase[u] = 0;
-        if (head) {
-            const unsigned long long later = bounds & ~((2ull << lane) - 1ull);
-            const int next = later ? __ffsll((long long)later) - 1 : 64;
-            rbase[u] = atomicAdd(&w.tcount[h[u]], (unsigned)(next - lane));
-        }
-        hl[u] = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));                // my run's head lane (valid when cl)
     }
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
-        const uint32_t hb = (uint32_t)__shfl((int)rbase[u], hl[u] < 0 ? 0 : hl[u]);
+        const int src = hl[u] < 0 ? 0 : hl[u];
+        const uint32_t hb = (uint32_t)__shfl((int)rbase[u], src), hh = (uint32_t)__shfl((int)(uint32_t)h[u], src);
         if (idx[u] < b.n) {
-            if (cl[u]) { w.slot[idx[u]] = (uint32_t)h[u]; w.rank[idx[u]] = hb + (uint32_t)(lane - hl[u]); }
+            if (cl[u]) { w.slot[idx[u]] = hh; w.rank[idx[u]] = (hb + (uint32_t)(lane - hl[u])) | (owner[u] ? RANK_OWNER : 0u); }
             else w.slot[idx[u]] = NONE32;
         }
     }
 }
 
-// ===================================================================================================== table scan (3 phases)
-// element(h) = (count>0) << 32 | count ; exclusive scan gives (cluster id, member offset)
+// ===================================================================================================== cluster list + member lists
+// Every cluster has exactly one claiming read (RANK_OWNER): the clusters are numbered in the order of those reads, and an
+// exclusive scan of (1 << 32 | reads of the cluster) over them gives (cluster id, first member slot).  The scans run over the
+// READS (4 bytes each), not over the bucket table (16 bytes x 1.25 per read).
 #define SCAN_TILE 2048
+__device__ __forceinline__ uint64_t own_elem(const Work &w, uint64_t i, uint64_t n) {
+    if (i >= n) return 0;
+    if (w.slot[i] == NONE32 || !(w.rank[i] & RANK_OWNER)) return 0;
+    return (1ull << 32) | w.tab[w.slot[i]].count;
+}
+__global__ __launch_bounds__(256) void k_own_reduce(Work w, uint64_t n) {
+    __shared__ uint64_t s[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE, v = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) v += own_elem(w, base + k * 256 + threadIdx.x, n);
+    v = (uint64_t)wave_sum64((long long)v);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) w.scan_part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+// element(h) = (count>0) << 32 | count ; used by the small per-cluster scans below
 __device__ __forceinline__ uint64_t tab_elem(const uint32_t *cnt, uint64_t h, uint64_t n) {
     if (h >= n) return 0;
     uint32_t c = cnt[h];
@@ -406,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_scan_partials(uint64_t *part, uint64_t
     }
     if (threadIdx.x == 0) { *total_hi = s_carry >> 32; if (total_lo) *total_lo = s_carry & 0xFFFFFFFFull; }
 }
-__global__ __launch_bounds__(256) void k_table_apply(Work w, uint64_t n) {
+__global__ __launch_bounds__(256) void k_own_apply(Work w, uint64_t n) {
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -414,8 +468,8 @@ __global__ __launch_bounds__(256) void k_table_apply(Work w, uint64_t n) {
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
     for (int k = 0; k < SCAN_TILE / 256; k++) {
-        uint64_t h = base + k * 256 + threadIdx.x;
-        uint64_t v = tab_elem(w.tcount, h, n), x = v;
+        uint64_t i = base + k * 256 + threadIdx.x;
+        uint64_t v = own_elem(w, i, n), x = v;
         for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
         if (lane == 63) s_w[wv] = x;
         __syncthreads();
@@ -423,10 +477,9 @@ __global__ __launch_bounds__(256) void k_table_apply(Work w, uint64_t n) {
         for (int q = 0; q < wv; q++) woff += s_w[q];
         uint64_t carry = s_carry;
         uint64_t ex = carry + woff + x - v;
-        if (h < n) {
-            uint32_t c = (uint32_t)v;
-            w.toff[h] = (uint32_t)ex;
-            if (c) { uint32_t cid = (uint32_t)(ex >> 32); w.cl_slot[cid] = (uint32_t)h; w.cl_start[cid] = (uint32_t)ex; w.cl_n[cid] = c; }
+        if (v) {
+            const uint32_t cid = (uint32_t)(ex >> 32), sl = w.slot[i];
+            w.cl_slot[cid] = sl; w.cl_start[cid] = (uint32_t)ex; w.cl_n[cid] = (uint32_t)v; w.toff[sl] = (uint32_t)ex;
         }
         __syncthreads();
         if (threadIdx.x == 255) s_carry = carry + woff + x;
@@ -439,7 +492,7 @@ __global__ void k_scatter(int64_t n, Work w) {
     if (i >= n) return;
     uint32_t s = w.slot[i];
     if (s == NONE32) return;
-    w.members[w.toff[s] + w.rank[i]] = (uint32_t)i;
+    w.members[w.toff[s] + (w.rank[i] & ~RANK_OWNER)] = (uint32_t)i;
 }
 
 // ===================================================================================================== pairing + UMI grouping
@@ -470,8 +523,7 @@ __device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (
 template <int PHASE>
 __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane, uint32_t ib0 = 0, uint32_t ibstep = 1) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint64_t entry = w.table[w.cl_slot[c]];
-    uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
+    uint32_t mode = d_thr_mode(w.tab[w.cl_slot[c]].ikey, w.si, p);
     if (mode == THR_NEVER) {                      // pending after an early finishConsensus: never processed (gencore.cpp:23)
         if (PHASE == 2 && lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
         return;
@@ -668,8 +720,7 @@ __device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
 // One wave per cluster, <= 64 reads, names <= 64 bytes, UMIs <= 24 bytes: everything in registers.
 __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint64_t entry = w.table[w.cl_slot[c]];
-    uint32_t mode = d_thr_mode((uint32_t)(entry >> 32), w.si, p);
+    uint32_t mode = d_thr_mode(w.tab[w.cl_slot[c]].ikey, w.si, p);
     if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     bool defer = n > 64;

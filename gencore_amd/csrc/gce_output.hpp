@@ -123,7 +123,12 @@ __global__ __launch_bounds__(256) void k_out_offsets(OutTable o, const unsigned 
     }
 }
 
-typedef uint4 uint4_unaligned __attribute__((aligned(1)));
+// 16 bytes from an arbitrary byte address
+__device__ __forceinline__ uint4 ld16_unaligned(const uint8_t *p_) {
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    const uint64_t a = *(const u64u *)p_, c = *(const u64u *)(p_ + 8);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c, (uint32_t)(c >> 32));
+}
 // 16 lanes per record: 16-byte pieces of its bases, then of its qualities (sources are unaligned, destinations 16-byte aligned;
 // the pad bytes behind a record's last base come from the bytes that follow it in the source blob, readable by contract)
 __global__ __launch_bounds__(256) void k_out_gather(DevBatch b, Work w, OutTable o) {
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void k_out_gather(DevBatch b, Work w, OutTable
         const uint8_t *ss = b.seq + b.seq_off[i], *qs = b.qual + b.qual_off[i];
         uint8_t *sd = o.seq + o.seq_off[row], *qd = o.qual + o.qual_off[row];
         for (uint32_t u = sub; u < su + qu; u += 16) {
-            if (u < su) *(uint4 *)(sd + 16 * u) = *(const uint4_unaligned *)(ss + 16 * u);
-            else *(uint4 *)(qd + 16 * (u - su)) = *(const uint4_unaligned *)(qs + 16 * (u - su));
+            if (u < su) *(uint4 *)(sd + 16 * u) = ld16_unaligned(ss + 16 * u);
+            else *(uint4 *)(qd + 16 * (u - su)) = ld16_unaligned(qs + 16 * (u - su));
         }
     }
 }

@@ -152,3 +152,50 @@ def shard_by_plan(batch, plan, rank, tick):
     sub = slice_batch(batch, idx)
     sub.tick = np.ascontiguousarray(tick[idx], np.uint64)
     return sub, idx
+
+
+def cluster_right(core, target_len):
+    """`right` of the cluster key (gencore.cpp:304,311); negative or not, the cross-contig form is just a number to the flush walk."""
+    tid, pos, mtid, mpos, isize = (core[k].astype(np.int64) for k in ("tid", "pos", "mtid", "mpos", "isize"))
+    near = (mtid == tid) & (np.abs(mpos - pos) < 100000)
+    tl = np.asarray(target_len, np.int64)
+    tlr = np.where((tid >= 0) & (tid < len(tl)), tl[tid.clip(0, max(len(tl) - 1, 0))] if len(tl) else 0, 0)
+    return np.where(near, cluster_left(core) + np.abs(isize) - 1, -tlr * (mtid + 1) + mpos)
+
+
+def contiguous_cuts(core, world, target_len):
+    """Read indices at which the sorted stream can be cut into CONTIGUOUS slices that are exact shards with the two scalars
+    tick_offset / trailing_flush (like whole contigs) and cost nothing to make (array views): in front of a cut no read may reach
+    the first position behind it — neither itself, nor its nearby mate (gencore.cpp:300-304), nor the `right` of its cluster key:
+    a flush takes a cluster only once it has passed BOTH ends of the key (gencore.cpp:344-354), so a key with a far right end is
+    still open behind the cut.  Returns world + 1 boundaries chosen among the valid cuts next to the equal-read-count quantiles."""
+    n = len(core)
+    tid, pos, mtid, mpos = (core[k].astype(np.int64) for k in ("tid", "pos", "mtid", "mpos"))
+    t = np.where(tid < 0, np.int64(1) << 30, tid)
+    near = (mtid == tid) & (np.abs(mpos - pos) < 100000)
+    ext = np.maximum(np.where(near, np.maximum(pos, mpos), pos), np.where(clustered_mask(core), cluster_right(core, target_len), pos))
+    reach = (t << 32) | ext.clip(0, (1 << 31) - 1)
+    key = (t << 32) | pos.clip(0)
+    valid = np.ones(n + 1, bool)
+    if n:
+        valid[1:n] = np.maximum.accumulate(reach)[:-1] < key[1:]
+    cand = np.nonzero(valid)[0]
+    bounds = [0]
+    for r in range(1, world):
+        want = (n * r) // world
+        k = int(np.searchsorted(cand, want))
+        best = cand[min(k, len(cand) - 1)]
+        if k > 0 and abs(int(cand[k - 1]) - want) <= abs(int(best) - want):
+            best = cand[k - 1]
+        bounds.append(max(int(best), bounds[-1]))
+    bounds.append(n)
+    return bounds
+
+
+def shard_contiguous(batch, bounds, rank, flush_period=10000):
+    """Slice [bounds[rank], bounds[rank+1]) of the stream (views, no copy of the blobs beyond the slice) + its stream context."""
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    cm = clustered_mask(batch.core)
+    before, mine, total = int(cm[:lo].sum()), int(cm[lo:hi].sum()), int(cm.sum())
+    ctx = dict(tick_offset=before, trailing_flush=int(total // flush_period > (before + mine) // flush_period))
+    return slice_contiguous(batch, lo, hi), np.arange(lo, hi), ctx

@@ -10,7 +10,8 @@ Workloads (BASELINE.json `configs`):
   cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean depth 8, -s 2; 24 hg19-shaped contigs (`scale` x hg19 lengths:
           0.1 = 300 Mb by default, bench.py uses 1.0 = 3.04 Gb); molecules concentrated on 5 k x 200 bp BED targets (the target
           count follows n_pairs so that a down-scaled stream keeps ~250 molecules per target)
-  cfg4s : per-GPU shard of configs[3] (12.5 M pairs, UMI, depth 16)
+  cfg4s : per-GPU eighth of configs[3] (12.5 M pairs, UMI, depth 16, whole-genome coverage of `scale` x hg19; the 8-GPU stream is
+          n_pairs = 100 M at scale = 1.0, cut into key ranges by generate(shard=(rank, world)))
   cfg5  : ultra-deep hotspots, 250 bp, duplex UMIs AAAA_BBBB, depth U[500,2000]
 Every size can be scaled with `n_pairs=`.
 """
@@ -67,8 +68,10 @@ CONFIGS = {
                  contigs=[w * 1_000_000 for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
                                                   90, 81, 78, 59, 63, 48, 51, 155, 59)],      # hg19 chr1..22, X, Y (Mb)
                  bed_targets=5000, bed_len=200, ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),
-    "cfg4s": dict(n_pairs=12_500_000, L=150, umi=8, duplex=False, mean_depth=16, contigs=[125_000_000] * 3, ins_mu=300, ins_sd=30,
-                  ins_max=600, supporting_reads=2),
+    "cfg4s": dict(n_pairs=12_500_000, L=150, umi=8, duplex=False, mean_depth=16, scale=0.125,      # one GPU's eighth of configs[3]:
+                  contigs=[w * 1_000_000 for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
+                                                   90, 81, 78, 59, 63, 48, 51, 155, 59)],          # hg19-shaped, whole-genome coverage;
+                  ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),                         # bench.py scales the genome with the GPUs
     "cfg5": dict(n_pairs=0, n_molecules=1250, L=250, umi=4, duplex=True, depth_lo=500, depth_hi=2000, contigs=[50_000_000],
                  ins_mu=450, ins_sd=50, ins_max=900, supporting_reads=1, shard_mode="lpt"),
 }

@@ -94,6 +94,52 @@ def test_key_range_shards_equal_whole_stream(oracle, seed, world, mode):
     assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
 
 
+@pytest.mark.parametrize("seed", range(420, 432))
+def test_contiguous_cut_shards_equal_whole_stream(oracle, seed):
+    """Contiguous slices cut where no cluster key is open (neither a mate nor the key's right end reaches over the cut) are exact
+    shards with tick_offset / trailing_flush alone: the cheap way to spread one stream over processes or GPUs."""
+    from gencore_amd.shard import contiguous_cuts, shard_contiguous
+    world = 2 + seed % 7
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=70, umi_mode="prefix", period=[11, 29, 5][seed % 3])
+    whole = oracle.run(batch, fuzzgen.make_params(over, contig_len), reference)
+    bounds = contiguous_cuts(batch.core, world, contig_len)
+    assert bounds[0] == 0 and bounds[-1] == batch.n and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    flags = np.zeros(batch.n, np.uint8); pre = np.zeros(114, np.int64); post = np.zeros(114, np.int64)
+    for r in range(world):
+        if bounds[r] == bounds[r + 1]:
+            continue
+        sub, idx, ctx = shard_contiguous(batch, bounds, r, over["flush_period"])
+        res = oracle.run(sub, fuzzgen.make_params(dict(over, **ctx), contig_len), reference)
+        assert res.status == 0
+        flags[idx] = res.out_flag
+        pre += res.pre.as_array(); post += res.post.as_array()
+    assert np.array_equal(flags, whole.out_flag)
+    assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
+
+
+def test_sharded_generator_equals_whole_stream():
+    """synth.generate(shard=(rank, world)): every rank plans the whole stream and materialises its own key range — the records, the
+    global ticks and the flush events are those of the unsharded stream (what bench.py --gpus N runs)."""
+    from gencore_amd import synth
+    from gencore_amd.shard import stream_context
+    for name, n_pairs, world in (("cfg4s", 20000, 3), ("cfg5", 12000, 2)):
+        kw = dict(scale=0.01) if name == "cfg4s" else {}
+        whole = synth.generate(name, n_pairs=n_pairs, **kw).to_batch()
+        tick, et, ep = stream_context(whole.core, 10000)
+        cover = np.zeros(whole.n, bool)
+        for r in range(world):
+            d = synth.generate(name, n_pairs=n_pairs, shard=(r, world), **kw)
+            b, gi = d.to_batch(), d.global_index.numpy()
+            cover[gi] = True
+            assert np.array_equal(b.core, whole.core[gi]) and np.array_equal(b.nm, whole.nm[gi])
+            assert np.array_equal(d.stream_context["tick"].numpy(), tick[gi].astype(np.int64))
+            assert np.array_equal(d.stream_context["ev_tid"], et) and np.array_equal(d.stream_context["ev_pos"], ep)
+            for i in range(0, b.n, max(1, b.n // 40)):
+                g = int(gi[i])
+                assert b.qname_of(i) == whole.qname_of(g) and b.seq_of(i) == whole.seq_of(g) and np.array_equal(b.qual_of(i), whole.qual_of(g))
+        assert cover.all()
+
+
 def test_oracle_matches_frozen_regression_vectors(oracle):
     """tests/golden/oracle_regression.json: digests of oracle outputs frozen by tests/golden/make_golden.py.
     These are REGRESSION vectors of the oracle itself (the reference ships no golden output for this path and cannot
