@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4s | cfg5 (gencore_amd/synth.py); default cfg3 on 1 GPU, cfg4s on N > 1")
     ap.add_argument("--pairs", type=int, default=None, help="override the workload's pair count (per GPU)")
     ap.add_argument("--scale", type=float, default=None, help="genome scale of cfg3 (1.0 = hg19 lengths, the default here)")
+    ap.add_argument("--bed-targets", type=int, default=None, help="override the number of BED targets of cfg3 (0 = molecules spread uniformly)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
@@ -136,6 +137,8 @@ def main():
     over = {}
     if workload == "cfg3":
         over["scale"] = args.scale if args.scale is not None else 1.0     # hg19-length contigs (3.04 Gb); tests use the 0.1 default
+    if args.bed_targets is not None:
+        over["bed_targets"] = args.bed_targets
     if workload == "cfg4s":
         over["scale"] = args.scale if args.scale is not None else 0.125 * world   # 100 M pairs over hg19 at 8 GPUs; an eighth of both per GPU
 

@@ -349,6 +349,7 @@ int gce_process(gce_engine *e) {
         int bt = 1; while (bt < 31 && (1ll << bt) < (long long)std::max<size_t>(e->target_len.size(), 1)) bt++;
         int bl = 1; while (bl < 32 && (1ull << bl) <= (uint64_t)mx) bl++;
         p.key_bt = bt; p.key_bl = bl;
+        { const char *d = getenv("GCE_DBG"); p.dbg = d ? atoi(d) : 0; }
     }
     p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
 

@@ -42,6 +42,7 @@ struct DevParams {
     const uint32_t *target_len;
     const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
     int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
+    int32_t dbg;                      // GCE_DBG: timing experiments only (results invalid)
     int64_t tick_offset;
     int32_t trailing_flush;
     int32_t n_ref;

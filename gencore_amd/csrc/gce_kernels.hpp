@@ -225,9 +225,10 @@ __device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *
 //                  cross-contig keys (negative right), fields that overflow the packing, reads that arrive after their key was
 //                  flushed (instance = own epoch), reads behind an unmapped read.  A follower compares the upper half, then the
 //                  cluster key of the claiming read (one dependent load of its key record; rare).
-//   ikey  instance | segment << 31 of the cluster (read by the per-cluster kernels for the UMI threshold, quirk Q1)
-//   count reads of the cluster so far: one atomicAdd per run of neighbouring reads gives the in-cluster ranks
-struct __attribute__((aligned(16))) TabEntry { unsigned long long key; uint32_t ikey; uint32_t count; };
+//   ic    low half: reads of the cluster so far -- one 64-bit atomicAdd per (cluster, block) gives the in-cluster ranks; high half:
+//         instance | segment << 31 of the cluster (read by the per-cluster kernels for the UMI threshold, quirk Q1), added in by the
+//         claimer with the same atomic (a separate store to the entry in front of the atomic cost more than the whole rest)
+struct __attribute__((aligned(16))) TabEntry { unsigned long long key; unsigned long long ic; };   // ic = ikey << 32 | count
 static_assert(sizeof(TabEntry) == 16, "TabEntry must stay 16 bytes");
 #define TAB_OCC (1ull << 63)
 #define TAB_EXO (1ull << 62)
@@ -257,8 +258,11 @@ __device__ __forceinline__ unsigned long long d_tab_key(const ClusterKey &k, uin
 // dependent chains (key record -> flush events -> bucket probe -> CAS -> rank atomic) overlap their
 // memory round trips: the scan is bound by latency x occupancy, not by issue.
 #define CL_U 2
+#define CL_LDS_SLOTS 1024          // LDS hash slots for the <= 512 distinct keys of a block
 __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
-    __shared__ unsigned int s_cnt[CL_U][WAVES_PER_BLOCK];
+    __shared__ unsigned int s_wcnt[CL_U][WAVES_PER_BLOCK];
+    __shared__ uint32_t s_slot[CL_LDS_SLOTS], s_cnt[CL_U * CHUNK], s_ik[CL_U * CHUNK], s_h[CL_U * CHUNK], s_base[CL_U * CHUNK];
+    __shared__ int4 s_key[CL_U * CHUNK];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const StreamInfo *si = w.si;
     const unsigned int first_unm = si->first_unmapped;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
     for (int u = 0; u < CL_U; u++) {
         cl[u] = idx[u] < b.n && d_classify(k[u]) == CLS_CLUSTERED;
         m[u] = __ballot(cl[u]);
-        if (lane == 0) s_cnt[u][wv] = __popcll(m[u]);
+        if (lane == 0) s_wcnt[u][wv] = __popcll(m[u]);
     }
     __syncthreads();
     // ---- instance of each read: events before it (own epoch) vs. the first event whose walk takes its key
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         T0[u] = P0[u] = T1[u] = P1[u] = T2[u] = P2[u] = 0;
         if (cl[u]) {
             unsigned int inblock = lanes_below(m[u]) + 1;
-            for (int q = 0; q < wv; q++) inblock += s_cnt[u][q];
+            for (int q = 0; q < wv; q++) inblock += s_wcnt[u][q];
             // the reference's `tick` after ++ (gencore.cpp:319-320): counted here, or handed in with the batch (key-range shards)
             const long long tick = b.tick ? (long long)b.tick[idx[u]] : p.tick_offset + (long long)w.chunk_base[blockIdx.x * CL_U + u] + inblock;
             e_[u] = (int)((tick - 1) / per - p.tick_offset / per);                          // flush events before this read
@@ -328,33 +332,67 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
             ikey[u] |= (uint32_t)max(e_[u], f - 1);
         }
     }
-    // ---- neighbouring lanes with the same (key, instance) are one run of one cluster (sorted input): only the run head
-    //      probes the table; it claims or finds the bucket and draws the ranks of the whole run with one atomicAdd.
-    // (all shuffles are executed by every lane: a shuffle inside a divergent branch reads inactive source lanes as 0)
-    bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U], hl[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
+    // ---- block-level aggregation.  The stream is sorted, so the reads of a cluster sit close together -- but a capture panel stacks
+    //      several clusters on every position and their reads interleave, so neighbouring lanes rarely share a key.  The block's
+    //      512 reads first meet in a small LDS hash table: the first read of every distinct (key, instance) becomes its LEADER,
+    //      the others compare their key with the leader's (kept in LDS) and draw a block-local rank from the leader's LDS
+    //      counter.  Only leaders go to the bucket table in HBM: one probe and one atomicAdd per cluster and block instead of
+    //      one per read.
+    const int id0 = threadIdx.x;                                                           // read id inside the block: u * CHUNK + threadIdx.x
+    for (int k = threadIdx.x; k < CL_LDS_SLOTS; k += CHUNK) s_slot[k] = 0;
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
-        const int p_cl = __shfl_up((int)cl[u], 1), p_tid = __shfl_up(key[u].tid, 1), p_left = __shfl_up(key[u].left, 1), p_ik = __shfl_up((int)ikey[u], 1);
-        const long long p_right = __shfl_up((long long)key[u].right, 1);
-        const bool same_prev = lane > 0 && cl[u] && p_cl && p_tid == key[u].tid && p_left == key[u].left && p_right == (long long)key[u].right && p_ik == (int)ikey[u];
-        khead[u] = cl[u] && !same_prev;
-        const unsigned long long heads = __ballot(khead[u]), bounds = __ballot(khead[u] || !cl[u]);
-        const unsigned long long later = bounds & ~((2ull << lane) - 1ull);
-        runlen[u] = (later ? __ffsll((long long)later) - 1 : 64) - lane;                    // valid on head lanes
-        hl[u] = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));                // my run's head lane (valid when cl)
-        h[u] = 0; tk[u] = 0; cur[u] = 0; rbase[u] = 0; owner[u] = false;
+        const int id = u * CHUNK + id0;
+        s_cnt[id] = 0;
+        s_key[id] = make_int4(key[u].tid, key[u].left, (int)(uint32_t)key[u].right, (int)(uint32_t)((uint64_t)key[u].right >> 32));
+        s_ik[id] = ikey[u];
+    }
+    __syncthreads();
+    int leader[CL_U]; uint32_t lrank[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        leader[u] = -1; lrank[u] = 0;
+        if (cl[u]) {
+            const int id = u * CHUNK + id0;
+            uint32_t hs = ((uint32_t)key[u].left * 0x9E3779B1u) ^ ((uint32_t)key[u].right * 0x85EBCA77u) ^ (ikey[u] * 0xC2B2AE3Du) ^ ((uint32_t)key[u].tid * 0x27D4EB2Fu);
+            hs = (hs ^ (hs >> 15)) & (CL_LDS_SLOTS - 1);
+            if (p.dbg & 4) { leader[u] = id; lrank[u] = 0; s_cnt[id] = 1; continue; }
+            for (;;) {                                                                      // (no waiting: a claimed slot's key was stored before the barrier)
+                const uint32_t old = atomicCAS(&s_slot[hs], 0u, (uint32_t)id + 1u);
+                if (old == 0u) { leader[u] = id; break; }
+                const int L = (int)old - 1;
+                const int4 lk = s_key[L];
+                if (lk.x == key[u].tid && lk.y == key[u].left && lk.z == (int)(uint32_t)key[u].right && lk.w == (int)(uint32_t)((uint64_t)key[u].right >> 32) && s_ik[L] == ikey[u]) { leader[u] = L; break; }
+                hs = (hs + 1) & (CL_LDS_SLOTS - 1);
+            }
+            lrank[u] = atomicAdd(&s_cnt[leader[u]], 1u);
+        }
+    }
+    __syncthreads();
+    if (p.dbg & 8) {
+#pragma unroll
+        for (int u = 0; u < CL_U; u++) if (idx[u] < b.n) w.slot[idx[u]] = NONE32;
+        return;
+    }
+    // ---- leaders: the bucket table
+    bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+        khead[u] = cl[u] && leader[u] == u * CHUNK + id0;
+        h[u] = 0; tk[u] = 0; cur[u] = 0; rbase[u] = 0; owner[u] = false; runlen[u] = 0;
         if (khead[u]) {
+            runlen[u] = (int)s_cnt[u * CHUNK + id0];
             tk[u] = d_tab_key(key[u], ikey[u], implied[u], (uint32_t)idx[u], p);
             if ((tk[u] & TAB_EXO) && (ikey[u] & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)idx[u]);   // > 2^29 flush events
             h[u] = d_bucket(d_tab_index(key[u], ikey[u], p), w.tsize, w.tinv);
-            cur[u] = w.tab[h[u]].key;
+            if (p.dbg & 1) h[u] = d_bucket((d_tab_index(key[u], ikey[u], p) * 0x9E3779B97F4A7C15ull) >> 16, w.tsize, w.tinv);
         }
     }
     bool done[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {                                                       // first probe: claim an empty bucket
-        done[u] = !khead[u];
-        if (khead[u] && cur[u] == 0ull) {
+        done[u] = !khead[u] || (p.dbg & 64);
+        if (khead[u] && !(p.dbg & 64)) {                                                   // (no load first: the CAS returns what is there)
             cur[u] = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
             if (cur[u] == 0ull) { owner[u] = true; cur[u] = tk[u]; }
         }
@@ -377,28 +415,40 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
                 if (!(tk[u] & TAB_EXO)) mine = (uint32_t)cur[u] == (uint32_t)tk[u];
                 else { const ClusterKey ok = d_key(oc[u], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
             }
+            bool first_miss = true;
             while (!mine) {
-                h[u] = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
-                unsigned long long c = w.tab[h[u]].key;
-                if (c == 0ull) {
-                    c = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
-                    if (c == 0ull) { owner[u] = true; break; }
-                }
+                // collision: leave the neighbourhood.  A deep amplicon stacks thousands of clusters on a few hundred positions; their
+                // buckets are full, and walking on linearly would crawl through the whole pile.  The probe sequence continues at a
+                // hashed place of the table (load there: a few percent), linearly from then on.
+                if (first_miss) {
+                    uint64_t x = ((uint64_t)(uint32_t)key[u].tid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)key[u].left * 0xC2B2AE3D27D4EB4Full) ^ ((uint64_t)key[u].right * 0x165667B19E3779F9ull) ^ ((uint64_t)ikey[u] * 0xD6E8FEB86659FD93ull);
+                    x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+                    h[u] = d_bucket(x >> 14, w.tsize, w.tinv);
+                    first_miss = false;
+                } else h[u] = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
+                const unsigned long long c = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
+                if (c == 0ull) { owner[u] = true; break; }
                 if ((c >> 32) == (tk[u] >> 32)) {
                     if (!(tk[u] & TAB_EXO)) mine = (uint32_t)c == (uint32_t)tk[u];
                     else { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
                 }
             }
-            if (owner[u]) w.tab[h[u]].ikey = ikey[u];
-            rbase[u] = atomicAdd(&w.tab[h[u]].count, (unsigned)runlen[u]);
+            if (!(p.dbg & 16)) rbase[u] = (uint32_t)atomicAdd(&w.tab[h[u]].ic, (unsigned long long)(unsigned)runlen[u] | (owner[u] ? (unsigned long long)ikey[u] << 32 : 0ull));
         }
     }
+    if (p.dbg & 32) {
+#pragma unroll
+        for (int u = 0; u < CL_U; u++) if (idx[u] < b.n) w.slot[idx[u]] = (cur[u] == 12345ull && rbase[u] == 77u) ? 0u : NONE32;
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < CL_U; u++)
+        if (khead[u]) { s_h[u * CHUNK + id0] = (uint32_t)h[u]; s_base[u * CHUNK + id0] = rbase[u]; }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
-        const int src = hl[u] < 0 ? 0 : hl[u];
-        const uint32_t hb = (uint32_t)__shfl((int)rbase[u], src), hh = (uint32_t)__shfl((int)(uint32_t)h[u], src);
         if (idx[u] < b.n) {
-            if (cl[u]) { w.slot[idx[u]] = hh; w.rank[idx[u]] = (hb + (uint32_t)(lane - hl[u])) | (owner[u] ? RANK_OWNER : 0u); }
+            if (cl[u]) { w.slot[idx[u]] = s_h[leader[u]]; w.rank[idx[u]] = (s_base[leader[u]] + lrank[u]) | (owner[u] ? RANK_OWNER : 0u); }
             else w.slot[idx[u]] = NONE32;
         }
     }
@@ -412,7 +462,7 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
 __device__ __forceinline__ uint64_t own_elem(const Work &w, uint64_t i, uint64_t n) {
     if (i >= n) return 0;
     if (w.slot[i] == NONE32 || !(w.rank[i] & RANK_OWNER)) return 0;
-    return (1ull << 32) | w.tab[w.slot[i]].count;
+    return (1ull << 32) | (uint32_t)w.tab[w.slot[i]].ic;
 }
 __global__ __launch_bounds__(256) void k_own_reduce(Work w, uint64_t n) {
     __shared__ uint64_t s[4];
@@ -523,7 +573,7 @@ __device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (
 template <int PHASE>
 __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane, uint32_t ib0 = 0, uint32_t ibstep = 1) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint32_t mode = d_thr_mode(w.tab[w.cl_slot[c]].ikey, w.si, p);
+    uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
     if (mode == THR_NEVER) {                      // pending after an early finishConsensus: never processed (gencore.cpp:23)
         if (PHASE == 2 && lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
         return;
@@ -720,7 +770,7 @@ __device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
 // One wave per cluster, <= 64 reads, names <= 64 bytes, UMIs <= 24 bytes: everything in registers.
 __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint32_t mode = d_thr_mode(w.tab[w.cl_slot[c]].ikey, w.si, p);
+    uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
     if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     bool defer = n > 64;
