@@ -12,6 +12,7 @@
 #include "gce_kernels.hpp"
 #include "gce_lean2.hpp"
 #include "gce_pair2.hpp"
+#include "gce_vote.hpp"
 #include "gce_output.hpp"
 
 namespace {
@@ -59,7 +60,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -134,7 +135,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -340,6 +341,12 @@ int gce_process(gce_engine *e) {
         p.q2s_lut = by(p.s_bad) | by(p.s_low) << 8 | by(p.s_moderate) << 16 | by(p.s_high) << 24;
         p.thr_low4 = 0x01010101u * (uint32_t)(p.low_q & 0xFF); p.thr_mod4 = 0x01010101u * (uint32_t)(p.moderate_q & 0xFF); p.thr_high4 = 0x01010101u * (uint32_t)(p.high_q & 0xFF);
         p.q2s_swar_ok = p.low_q >= 0 && p.low_q <= p.moderate_q && p.moderate_q <= p.high_q && p.high_q <= 127;
+        // k_vote (gce_vote.hpp): scores in a sane range (the packed tally keys of decide_column_packed), and whether a unanimous column whose
+        // top quality reaches `moderate` is bound to reach baseScoreReq too: that voter scores s_moderate or s_high (or >= min + 4 inside a
+        // matching mate overlap) and nobody scores below 0
+        p.s_min_lb = mn;
+        p.vote_ok = mn >= 0 && mx + 4 <= 120 && p.moderate_q >= 0 && p.moderate_q <= 127 && p.base_score_req <= 100;
+        p.vote_accept_by_qual = std::min(std::min(p.s_moderate, p.s_high), mn + 4) >= std::max(p.base_score_req, 1);
     }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
@@ -450,16 +457,28 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_scan_reduce, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, (uint64_t)C, w.scan_part);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_C, &w.si->n_pairs /*scratch*/, &w.si->n_groups);
         hipLaunchKernelGGL(k_u32_apply, dim3(nblk_C), dim3(256), 0, s, (const uint32_t *)w.cl_ngroups, w.cl_gbase, (uint64_t)C, (const uint64_t *)w.scan_part);
+        // the compact group list and the batches of k_vote: sized by N (groups <= pairs <= reads) so that all of it runs before the one
+        // host round trip that fetches the group count and the batch count together
+        ENS(gl_cluster, n1 * 4); ENS(g_begin, n1 * 4); ENS(g_np, n1 * 4); ENS(gw, n1 * 8); ENS(g_wbase, n1 * 4);
+        const size_t vb_cap = (7 * n1) / VB_W + 8;                 // sum of weights <= 4 x groups + pairs + 64 x deep groups
+        ENS(vb_start, vb_cap * 4);
+        w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>();
+        w.gw = e->gw.as<uint64_t>(); w.g_wbase = e->g_wbase.as<uint32_t>(); w.vb_start = e->vb_start.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(e->vb_start.p, 0xFF, vb_cap * 4, s));
+        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr);
+        hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)w.gw, (const unsigned long long *)&w.si->n_groups, w.scan_part);
+        hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_groups, &w.si->vote_weight);
+        hipLaunchKernelGGL(k_vote_batches, dim3(nblk_N), dim3(256), 0, s, w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);
         HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
         if ((rc = read_si(e)) != GCE_OK) return rc;
         HIPCHK(hipGetLastError());
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gl_cluster, g1 * 4); ENS(g_begin, g1 * 4); ENS(g_np, g1 * 4); ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4); ENS(rp_nm, g1 * 8); ENS(rp_qsl, g1 * 4); ENS(rp_qsr, g1 * 4);
     w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
-    w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>(); w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
+    w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     w.rp_nm = e->rp_nm.as<int32_t>(); w.rp_qsl = e->rp_qsl.as<uint32_t>(); w.rp_qsr = e->rp_qsr.as<uint32_t>();
@@ -467,10 +486,18 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
         HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
         HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
-        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C);
-        hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 0);
-        HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-        hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        static const bool use_vote = !(getenv("GCE_VOTE") && atoi(getenv("GCE_VOTE")) == 0);     // 0: the round-1 pair k_score2 + k_consensus_lean2 (A/B)
+        if (use_vote) {
+            HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
+            const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
+            hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(256), 0, s, b, p, w, NG);
+            HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);   // the handed-on groups only
+        } else {
+            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 0);
+            HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+            hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
+        }
         {   // compact the flagged sides into gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
             hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
@@ -570,6 +597,25 @@ int gce_drain(gce_engine *e, gce_result *out) {
     out->seq_off = e->r_soff.data(); out->qual_off = e->r_qoff.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
     out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
+    return GCE_OK;
+}
+
+// debugging aid (not part of the ABI): per-group result records and group tables of the last gce_process as text
+int gce_debug_dump(gce_engine *e, const char *path) {
+    if (!e || !e->processed) return GCE_ERR_INVALID;
+    const size_t NG = (size_t)e->h_si.n_groups, n = (size_t)e->n;
+    std::vector<uint32_t> rl(NG), rr(NG), gb(NG), gn(NG), gpl(n), gpr(n); std::vector<uint8_t> gf(2 * NG);
+    (void)hipMemcpy(rl.data(), e->rp_left.p, NG * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(rr.data(), e->rp_right.p, NG * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(gb.data(), e->g_begin.p, NG * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(gn.data(), e->g_np.p, NG * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(gpl.data(), e->gpl.p, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(gpr.data(), e->gpr.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(gf.data(), e->gen_flag.p, 2 * NG, hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "w"); if (!f) return GCE_ERR_INVALID;
+    for (size_t g = 0; g < NG; g++) {
+        fprintf(f, "g %zu np %u gen %d%d L %d R %d :", g, gn[g], gf[2 * g], gf[2 * g + 1], (int)rl[g], (int)rr[g]);
+        for (uint32_t k = 0; k < gn[g]; k++) fprintf(f, " (%d,%d)", (int)gpl[gb[g] + k], (int)gpr[gb[g] + k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
     return GCE_OK;
 }
 

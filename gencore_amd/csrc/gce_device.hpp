@@ -43,6 +43,7 @@ struct DevParams {
     const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
     int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
     int32_t dbg;                      // GCE_DBG: timing experiments only (results invalid)
+    int32_t vote_ok, vote_accept_by_qual, s_min_lb;   // gce_vote.hpp: score constants in range; "top quality >= moderate" implies "score sum >= baseScoreReq"; smallest score
     int64_t tick_offset;
     int32_t trailing_flush;
     int32_t n_ref;
@@ -81,6 +82,7 @@ struct StreamInfo {
     unsigned int pad0, pad1;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     unsigned long long n_pairs_total;    // pairs over all processed clusters
+    unsigned long long vote_weight;      // sum of the group weights: k_vote runs vote_weight / VB_W + 1 batches
     unsigned long long out_units;        // size of the compact output blobs in 16-byte units: bases << 32 | qualities
     unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one

@@ -47,6 +47,7 @@ struct Work {
     uint64_t *k64;                       // generic pairing scratch: 3 words per read (name window / UMI words)
     // groups (compact)
     uint32_t *gl_cluster, *g_begin, *g_np;   // per compact group: owning cluster, first pair slot, pair count
+    uint64_t *gw; uint32_t *g_wbase, *vb_start;   // k_vote batching: weight of every group, its exclusive prefix, first group of every batch
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint8_t *pf_flag; uint32_t *pf_list;      // clusters the half-wave pairing kernel hands to the full-wave one (same scheme)
     uint8_t *pq_flag; uint32_t *pq_list;      // ... and the quarter-wave kernel to the half-wave one
@@ -936,12 +937,17 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
 }
 
 // exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word
-__global__ void k_group_fill(Work w, uint32_t n_clusters) {
+__global__ void k_group_fill(Work w, uint32_t n_clusters, int skip_thr) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_clusters) return;
     uint32_t g0 = w.cl_gbase[c], ng = w.cl_ngroups[c];
     const uint32_t cs = w.cl_start[c];
-    for (uint32_t g = 0; g < ng; g++) { w.gl_cluster[g0 + g] = c; w.g_begin[g0 + g] = w.grp_begin[cs + g]; w.g_np[g0 + g] = w.grp_n[cs + g]; }
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t np = w.grp_n[cs + g];
+        w.gl_cluster[g0 + g] = c; w.g_begin[g0 + g] = w.grp_begin[cs + g]; w.g_np[g0 + g] = np;
+        // k_vote batches (gce_vote.hpp): a group weighs its pairs (at least 4: <= 16 groups per batch); a deep group is handed on by a batch of its own
+        w.gw[g0 + g] = (np > 32u || (int)np > skip_thr) ? 64ull : (uint64_t)(np < 4u ? 4u : np);
+    }
 }
 // scan of cl_ngroups -> cl_gbase : same 3-phase scheme on the plain counts
 __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t *out, uint64_t n, const uint64_t *part) {

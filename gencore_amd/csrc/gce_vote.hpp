@@ -1,0 +1,454 @@
+// gce_vote.hpp — Pair::computeScore + Group::consensusMergeBam + Group::makeConsensus for the usual groups, one WORKGROUP per batch of
+// groups (pair.cpp:88-172, group.cpp:136-579).
+//
+// The per-group kernels of round 1 (one wave per group, k_score2 in front) were bound by their own instruction stream: ~1800 wave
+// instructions per group, most of them bookkeeping executed with 6-19 of 64 lanes busy.  Here a workgroup of 256 threads takes a
+// batch of ~14 groups (<= 16 groups, <= 95 pairs) through a few FLAT phases, every phase with one lane per independent item:
+//   P1  lane = pair            the two reads' descriptors into LDS; the pair's mate-overlap window (pair.cpp:108-120)
+//   P2  lane = (group, side)   consensusMergeBam for the sides this kernel covers: one class of reads with the same CIGAR and length
+//                              (+ a provably unrelated minority), template = first read of the class, voters = the class
+//   P3  lane = pair            mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
+//   P4  lane = (side, 16 columns)  "pass A": OR / AND of the voters' packed bases (unanimity), packed max of their quals; a column
+//                              all voters agree on with top quality >= moderate takes group.cpp:421-428 (base kept, qual = max qual)
+//   P5  lane = (side, contested column)  "pass B": 5-bin tallies over the voters with the exact scores of pair.cpp:132-169 computed on
+//                              the fly (qualities of mismatching overlap bases rewritten to max(0, own - mate)), rule cascade + reference
+//                              arbitration (group.cpp:394-501)
+//   P6  lane = (group, side)   mismatchInc -> NM patch or restore (group.cpp:528-573), result records
+//   P7  lane = (side, 16 columns)  write the template back
+// Nothing is written to the reads before P7, and only the templates are: the quality rewrite of pair.cpp:158-159 exists in registers
+// for the vote and persists exactly where the reference's persists in an emitted record (the template's columns are either voted
+// columns, or — after a restore — rewritten here).  Scores are never materialised: no k_score2 launch, no score array traffic.
+//
+// A group with a side outside that scope (unrelated reads, right reads on different positions, > 32 pairs, IUPAC codes, quals >= 128,
+// unusual score constants ...) is handed on UNTOUCHED, both sides: gen_flag (-> k_consensus_fast / k_consensus_slow) and slot_flag
+// (-> k_score2 scores just those pairs).
+#pragma once
+
+#define VB_W 64            // batch capacity in weight units (weight of a group = max(pairs, 4); a handed-on deep group takes a whole batch)
+#define VB_MINW 4
+#define VB_MAXG 16
+#define VB_MAXP 96
+#define VB_SIDES (2 * VB_MAXG)
+#define VB_COLS 256
+
+struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
+static_assert(sizeof(VRead) == 32, "VRead must stay 32 bytes");
+struct VOv { uint16_t ls, rs, cmp, fl; };                   // fl: 1 = every score of the pair is the constant (pair.cpp:89-105), 2 = overlap [ls|rs, +cmp)
+enum : uint8_t { VS_FINAL = 0, VS_ACTIVE = 1, VS_GEN = 2, VS_RESTORE = 3 };
+struct __attribute__((aligned(8))) VSide {
+    uint64_t ref; int64_t ref_len;
+    uint32_t vmask, o_c0, result; int32_t o_pos, minc;
+    uint16_t len, item0; uint8_t tmpl, nvot, o_nc, state, grp, pad[3];
+};
+
+typedef unsigned short vb_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t c) {
+    union { uint32_t u; vb_us2 v; } x, y, z; x.u = a; y.u = c; z.v = __builtin_elementwise_max(x.v, y.v); return z.u;
+}
+__device__ __forceinline__ uint64_t ld8_unaligned(const uint8_t *p_) { typedef uint64_t u64u __attribute__((aligned(1))); return *(const u64u *)p_; }
+// gather the top bit of each of the 4 bytes of x into bits 0..3
+__device__ __forceinline__ uint32_t msb4(uint32_t x) { return (((x >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu; }
+// one bit per nibble of an 8-byte packed-base word (memory order: byte k = columns 2k (high nibble), 2k+1 (low nibble)) -> 16-bit column mask
+__device__ __forceinline__ uint32_t nib_mask16(uint64_t nz /* bit 0 of every nibble */) {
+    auto half = [](uint32_t v) { const uint32_t y = ((v >> 4) & 0x01010101u) | ((v << 1) & 0x02020202u); return ((y * 0x01041040u) >> 24) & 0xFFu; };
+    return half((uint32_t)nz) | (half((uint32_t)(nz >> 32)) << 8);
+}
+__device__ __forceinline__ uint64_t nib_nonzero(uint64_t d) { return (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x1111111111111111ull; }
+// nibbles that are one of the BAM codes 1, 2, 4, 8, 15 (A C G T N): popcount per nibble is 1 or 4
+__device__ __forceinline__ uint64_t nib_acgtn(uint64_t v) {
+    uint64_t t = v - ((v >> 1) & 0x5555555555555555ull);
+    t = (t & 0x3333333333333333ull) + ((t >> 2) & 0x3333333333333333ull);        // popcount 0..4 in every nibble
+    const uint64_t one = ~nib_nonzero(t ^ 0x1111111111111111ull), four = ~nib_nonzero(t ^ 0x4444444444444444ull);
+    return (one | four) & 0x1111111111111111ull;
+}
+
+// weights + batch starts: exclusive scan of the group weights (k_u64_reduce / k_u64_partials in front), first group of every batch
+__global__ __launch_bounds__(256) void k_vote_batches(Work w, const unsigned long long *n_ptr, const uint64_t *part) {
+    __shared__ uint64_t s_w[4];
+    __shared__ uint64_t s_carry;
+    const uint64_t n = *n_ptr, base = (uint64_t)blockIdx.x * SCAN_TILE;
+    if (base >= n) return;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = part[blockIdx.x];
+    __syncthreads();
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        const uint64_t i = base + k * 256 + threadIdx.x;
+        uint64_t v = i < n ? w.gw[i] : 0, x = v;
+        for (int q = 1; q < 64; q <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, q); if (lane >= q) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        const uint64_t carry = s_carry, ex = carry + woff + x - v;
+        if (i < n) { w.g_wbase[i] = (uint32_t)ex; atomicMin(&w.vb_start[ex / VB_W], (uint32_t)i); }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {       // largest s < n with pre[s] <= it  (pre ascending, pre[0] = 0)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)pre[mid] <= it) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+    __shared__ VRead s_rd[2][VB_MAXP];
+    __shared__ VOv s_ov[VB_MAXP];
+    __shared__ VSide s_side[VB_SIDES];
+    __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
+    __shared__ __attribute__((aligned(16))) uint8_t s_resq[VB_SIDES][VB_COLS];
+    __shared__ uint8_t s_resb[VB_SIDES][VB_COLS];
+    __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
+    __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
+    __shared__ uint8_t s_glp0[VB_MAXG + 1], s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
+    __shared__ int s_ng;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t g0 = w.vb_start[blockIdx.x];
+    if (g0 == NONE32) return;
+    // ---------------------------------------------------------------- P0: the groups of this batch
+    if (tid < 64) {
+        const uint32_t gi = g0 + (uint32_t)lane;
+        bool in = lane < VB_MAXG && gi < n_groups && w.g_wbase[gi] < (blockIdx.x + 1u) * VB_W;
+        uint32_t np = in ? w.g_np[gi] : 0u;
+        const bool deep = in && (np > 32u || (int)np > p.skip_low_complexity_thr || !p.vote_ok);
+        const unsigned long long im = __ballot(in);
+        const int ng = __popcll(im);                                                   // (groups of a batch are consecutive: im = low bits)
+        int x = deep ? 0 : (int)np, pre = x;
+        for (int o = 1; o < VB_MAXG; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+        if (in) { s_ggi[lane] = gi; s_gbeg[lane] = w.g_begin[gi]; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
+        if (lane == ng - 1) s_glp0[ng] = (uint8_t)pre;
+        if (lane == 0) s_ng = ng;
+        if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
+            w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
+            const uint32_t gb = w.g_begin[gi];
+            for (uint32_t k = 0; k < np; k++) w.slot_flag[gb + k] = 1;
+        }
+    }
+    for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += 256) (&s_cmask[0][0])[k] = 0u;
+    __syncthreads();
+    const int ng = s_ng, npairs = s_glp0[ng];
+    // ---------------------------------------------------------------- P1: pairs -> read descriptors, overlap window
+    if (tid < npairs) {
+        int j = 0;
+        while (j + 1 < ng && (int)s_glp0[j + 1] <= tid) j++;
+        const uint32_t slot = s_gbeg[j] + (uint32_t)(tid - (int)s_glp0[j]);
+        const uint32_t L = w.gpl[slot], R = w.gpr[slot];
+        ReadDesc lk{}, rk{};
+        if (L != NONE32) lk = load_desc(w.rdesc, L);
+        if (R != NONE32) rk = load_desc(w.rdesc, R);
+        VRead vl, vr;
+        vl.so = lk.so; vl.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
+        vr.so = rk.so; vr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
+        s_rd[0][tid] = vl; s_rd[1][tid] = vr;
+        VOv ov; ov.ls = 0; ov.rs = 0; ov.cmp = 0; ov.fl = 0;
+        if (L == NONE32 || R == NONE32 || !(lk.ml > 0 && rk.ml > 0)) ov.fl = 1;        // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
+        else {
+            const int dis = rk.pos - lk.pos;                                            // pair.cpp:108-120
+            int ls, rs, cmp;
+            if (dis >= 0) { ls = lk.mo + dis; rs = rk.mo; cmp = min(lk.ml - dis, rk.ml); }
+            else { ls = lk.mo; rs = rk.mo - dis; cmp = min(lk.ml, rk.ml + dis); }
+            if (cmp > 0) {
+                if (lk.lq > 65535 || rk.lq > 65535) raise_error(w.si, GCE_ERR_INVALID, L);
+                else { ov.ls = (uint16_t)ls; ov.rs = (uint16_t)rs; ov.cmp = (uint16_t)cmp; ov.fl = 2; }
+            }
+        }
+        s_ov[tid] = ov;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
+    if (tid < 64) {
+        const int j = lane >> 1, side = lane & 1;
+        const bool mine = lane < 2 * ng && s_gflag[j] == 0;
+        VSide sd; sd.ref = 0; sd.ref_len = 0; sd.vmask = 0; sd.o_c0 = 0; sd.result = NONE32; sd.o_pos = 0; sd.minc = 0; sd.len = 0; sd.item0 = 0;
+        sd.tmpl = 0; sd.nvot = 0; sd.o_nc = 0; sd.state = VS_FINAL; sd.grp = (uint8_t)j; sd.pad[0] = sd.pad[1] = sd.pad[2] = 0;
+        bool to_gen = false;
+        if (mine) {
+            const int np = s_gnp[j], lp0 = s_glp0[j];
+            const VRead *rds = s_rd[side] + lp0;
+            if (np == 1 && s_rd[1][lp0].rd == NONE32) {                                 // group.cpp:73-77: returned untouched
+                sd.result = side == 0 ? s_rd[0][lp0].rd : NONE32;
+            } else {
+                uint32_t hm = 0, single = 0;
+                for (int k = 0; k < np; k++) {
+                    const VRead r = rds[k];
+                    if (r.rd != NONE32) { hm |= 1u << k; if (r.nc == 1 && cig_op(r.c0) == 0) single |= 1u << k; }
+                }
+                if (hm != 0) {
+                    // The side's majority class = CIGAR and length of its first single-M read (see gce_lean2.hpp for the argument):
+                    // group.cpp:177-261 collapse to "template = first read of the class, voters = the class" when every other read is
+                    // provably unrelated to it (>= 2 CIGAR ops and a first op that is not an M block of >= len bases) and in the
+                    // minority, and — right side — all positions are equal (leftReadMode).  No single-M read: one class with the same
+                    // 2-/3-op CIGAR and nothing else.
+                    const bool multi = single == 0;
+                    const int fl = multi ? __ffs((int)hm) - 1 : __ffs((int)single) - 1;
+                    const VRead t = rds[fl];
+                    uint32_t o_cw1 = 0, o_cw2 = 0;
+                    if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
+                    const int len = t.lq;
+                    uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1;
+                    for (int k = 0; k < np; k++) {
+                        if (!((hm >> k) & 1u)) continue;
+                        const VRead r = rds[k];
+                        uint32_t cw1 = 0, cw2 = 0;
+                        if (multi && r.nc >= 2 && r.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[r.rd]; cw1 = cg[1]; if (r.nc == 3) cw2 = cg[2]; }
+                        const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq;
+                        if (major) vm |= 1u << k;
+                        if ((!major && (multi || r.nc < 2 || (cig_op(r.c0) == 0 && cig_len(r.c0) >= len))) || (side == 1 && r.pos != t.pos)) unfit = true;
+                    }
+                    const int nvot = __popc(vm);
+                    to_gen = unfit || nvot <= __popc(hm) - nvot || len > VB_COLS || len < 1;
+                    if (!to_gen && !((double)nvot < (double)np * 0.4 && np != 1)) {    // group.cpp:264-266: else "no majority", result stays NONE
+                        sd.state = VS_ACTIVE; sd.vmask = vm; sd.tmpl = (uint8_t)fl; sd.nvot = (uint8_t)nvot; sd.len = (uint16_t)len;
+                        sd.o_pos = t.pos; sd.o_c0 = t.c0; sd.o_nc = t.nc; sd.result = t.rd;
+                        if (t.fl & 1) {                                                 // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
+                            const int o_tid = b.core[t.rd].tid;
+                            if (o_tid >= 0 && o_tid < p.n_ref) {
+                                const uint8_t *rdp = p.ref_data[o_tid];
+                                const int64_t need_len = (int64_t)(t.nc == 1 ? ((len - 1) < cig_len(t.c0) ? (len - 1) : -1) : d_ref_offset(b.cigar + b.cigar_off[t.rd], t.nc, len - 1)) + 1;
+                                if (rdp && (int64_t)t.pos + need_len < p.ref_len[o_tid]) { sd.ref = (uint64_t)rdp; sd.ref_len = p.ref_len[o_tid]; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // a group goes on as a whole (all shuffles on wave-uniform paths)
+        const int other_gen = __shfl_xor((int)to_gen, 1);                              // (unconditional: `a || shfl(..)` would shuffle in a divergent branch)
+        const bool grp_gen = to_gen || other_gen != 0;
+        if (mine && grp_gen) {
+            sd.state = VS_GEN; sd.result = NONE32;
+            if (side == 0) {
+                const uint32_t gi = s_ggi[j];
+                w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
+                for (int k = 0; k < (int)s_gnp[j]; k++) w.slot_flag[s_gbeg[j] + k] = 1;
+                s_gflag[j] = 2;
+            }
+        }
+        // pass-A items: 16-column chunks of the active sides, prefix over the sides
+        const int nchunk = (mine && sd.state == VS_ACTIVE) ? (sd.len + 15) >> 4 : 0;
+        int pre = nchunk;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o); if (lane >= o) pre += t2; }
+        sd.item0 = (uint16_t)(pre - nchunk);
+        if (lane < VB_SIDES) { s_side[lane] = sd; s_ipre[lane] = (uint16_t)(pre - nchunk); }
+        if (lane == VB_SIDES - 1) s_ipre[VB_SIDES] = (uint16_t)pre;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
+    //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten)
+    if (tid < npairs) {
+        const VOv ov = s_ov[tid];
+        int j = 0;
+        while (j + 1 < ng && (int)s_glp0[j + 1] <= tid) j++;
+        if ((ov.fl & 2) && s_gflag[j] == 0) {
+            const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
+            for (int i = 0; i < (int)ov.cmp; i += 8) {
+                const int l0 = ov.ls + i, r0 = ov.rs + i, nv = min(8, (int)ov.cmp - i);
+                // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
+                auto cols8 = [](const uint8_t *s, int c0) {
+                    const uint64_t x = ld8_unaligned(s + (c0 >> 1));
+                    const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
+                    return (uint32_t)(y >> (4 * (c0 & 1)));
+                };
+                uint32_t d = (cols8(ls, l0) ^ cols8(rs, r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
+                d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
+                while (d) {
+                    const int k = (__ffs((int)d) - 1) >> 2;
+                    d &= d - 1;
+                    const int l = l0 + k, r = r0 + k;
+                    if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
+                    if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P4: pass A, one lane per (side, 16 columns)
+    {
+        const int n_items = s_ipre[VB_SIDES];
+        for (int it = tid; it < n_items; it += 256) {
+            const int s = vb_find(s_ipre, VB_SIDES, it);
+            const VSide sd = s_side[s];
+            const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
+            const VRead *rds = s_rd[s & 1] + s_glp0[sd.grp];
+            uint64_t sor = 0, sand = ~0ull; uint32_t qor = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+            for (uint32_t vm = sd.vmask; vm; vm &= vm - 1) {
+                const VRead *r = rds + (__ffs((int)vm) - 1);
+                const uint64_t so = r->so, qo = r->qo;
+                const uint64_t sq = ld8_unaligned(b.seq + so + 8 * chunk);
+                const uint64_t qa = ld8_unaligned(b.qual + qo + c16), qb = ld8_unaligned(b.qual + qo + c16 + 8);
+                sor |= sq; sand &= sq;
+                const uint32_t q0 = (uint32_t)qa, q1 = (uint32_t)(qa >> 32), q2 = (uint32_t)qb, q3 = (uint32_t)(qb >> 32);
+                qor |= q0 | q1 | q2 | q3;
+                m0 = pk_max_u16(m0, __builtin_amdgcn_perm(0u, q0, 0x0c010c00u)); m1 = pk_max_u16(m1, __builtin_amdgcn_perm(0u, q0, 0x0c030c02u));
+                m2 = pk_max_u16(m2, __builtin_amdgcn_perm(0u, q1, 0x0c010c00u)); m3 = pk_max_u16(m3, __builtin_amdgcn_perm(0u, q1, 0x0c030c02u));
+                m4 = pk_max_u16(m4, __builtin_amdgcn_perm(0u, q2, 0x0c010c00u)); m5 = pk_max_u16(m5, __builtin_amdgcn_perm(0u, q2, 0x0c030c02u));
+                m6 = pk_max_u16(m6, __builtin_amdgcn_perm(0u, q3, 0x0c010c00u)); m7 = pk_max_u16(m7, __builtin_amdgcn_perm(0u, q3, 0x0c030c02u));
+            }
+            // columns beyond the read (last chunk) read the neighbouring bytes: masked out of every test below
+            const uint32_t colmask = nval >= 16 ? 0xFFFFu : ((1u << nval) - 1u);
+            const uint32_t t0 = __builtin_amdgcn_perm(m1, m0, 0x06040200u), t1 = __builtin_amdgcn_perm(m3, m2, 0x06040200u);
+            const uint32_t t2 = __builtin_amdgcn_perm(m5, m4, 0x06040200u), t3 = __builtin_amdgcn_perm(m7, m6, 0x06040200u);   // max quals, one byte per column
+            const uint32_t differ = nib_mask16(nib_nonzero(sor ^ sand));
+            const uint32_t valid = nib_mask16(nib_acgtn(sor));
+            const uint32_t mod4 = 0x01010101u * (uint32_t)(p.moderate_q & 0x7F);
+            auto ge4 = [&](uint32_t t) { return msb4(((t | 0x80808080u) - mod4)); };                 // per byte: t >= moderate (bytes < 128)
+            const uint32_t geq = ge4(t0) | (ge4(t1) << 4) | (ge4(t2) << 8) | (ge4(t3) << 12);
+            uint32_t contested = (differ | ~valid | ~geq) & colmask;
+            if (!p.vote_accept_by_qual && (int)sd.nvot * p.s_min_lb < max(p.base_score_req, 1)) contested = colmask;   // scores cannot be bounded: vote everything
+            if (((qor & 0x80808080u) != 0) || p.moderate_q > 127) s_gflag[sd.grp] = 2;                  // quals >= 128: out of scope (checked over whole chunks: conservative)
+            *(uint4 *)(&s_resq[s][c16]) = make_uint4(t0, t1, t2, t3);
+            if (contested) atomicOr(&s_cmask[s][chunk >> 1], contested << (16 * (chunk & 1)));
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P5: pass B, one lane per (side, contested column)
+    if (tid < 64) {
+        int cnt = 0;
+        if (lane < VB_SIDES && s_side[lane].state == VS_ACTIVE && s_gflag[s_side[lane].grp] == 0) {
+            const int len = s_side[lane].len;
+            for (int k = 0; k < VB_COLS / 32; k++) {
+                uint32_t m = s_cmask[lane][k];
+                const int hi = len - 32 * k;                                            // forced columns beyond the template (longer mates) do not exist
+                if (hi < 32) m &= hi <= 0 ? 0u : ((1u << hi) - 1u);
+                s_cmask[lane][k] = m;
+                cnt += __popc(m);
+            }
+        }
+        int pre = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o); if (lane >= o) pre += t2; }
+        if (lane < VB_SIDES) s_cpre[lane] = (uint16_t)(pre - cnt);
+        if (lane == VB_SIDES - 1) s_cpre[VB_SIDES] = (uint16_t)pre;
+    }
+    __syncthreads();
+    {
+        const int n_items = s_cpre[VB_SIDES];
+        for (int it = tid; it < n_items; it += 256) {
+            const int s = vb_find(s_cpre, VB_SIDES, it);
+            int kth = it - (int)s_cpre[s], col = 0;
+            for (int k = 0; k < VB_COLS / 32; k++) {                                    // the kth-th contested column of the side
+                uint32_t m = s_cmask[s][k];
+                const int c = __popc(m);
+                if (kth >= c) { kth -= c; continue; }
+                for (int q = 0; q < kth; q++) m &= m - 1;
+                col = 32 * k + __ffs((int)m) - 1;
+                break;
+            }
+            const VSide sd = s_side[s];
+            const int side = s & 1, lp0 = s_glp0[sd.grp];
+            Tally5 t; tally_clear(t);
+            bool odd = false; int out_base = 0;
+            for (uint32_t vm = sd.vmask; vm; vm &= vm - 1) {
+                const int v = __ffs((int)vm) - 1;
+                const VRead *r = &s_rd[side][lp0 + v];
+                const uint64_t so = r->so, qo = r->qo;
+                const int nb = d_nib(b.seq + so, col);
+                int q = b.qual[qo + col], sc;
+                const VOv ov = s_ov[lp0 + v];
+                const int mystart = side ? ov.rs : ov.ls;
+                if (ov.fl & 1) sc = p.s_moderate;                                       // pair.cpp:89-105
+                else if ((ov.fl & 2) && (unsigned)(col - mystart) < (unsigned)ov.cmp) {  // pair.cpp:132-168
+                    const VRead *mt = &s_rd[side ^ 1][lp0 + v];
+                    const int mc = col - mystart + (side ? ov.ls : ov.rs);
+                    const int mn = d_nib(b.seq + mt->so, mc), mq = b.qual[mt->qo + mc];
+                    if (nb == mn) sc = d_qual2score(p, ((q + mq) / 2) & 0xFF) + 4;
+                    else {
+                        const bool left_wins = side ? (mq >= q) : (q >= mq);          // `if(lq >= rq)`: the left read keeps a score
+                        const int dq = max(0, q - mq);
+                        sc = (side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
+                        q = dq;                                                         // the rewritten quality is what the vote sees
+                    }
+                } else sc = d_qual2score(p, q);
+                if (v == (int)sd.tmpl) out_base = nb;
+                if ((q & 0x80) || !tally_add(t, nb, q, sc)) odd = true;
+            }
+            int ref4 = 0;
+            if (sd.ref) {                                                               // group.cpp:430-439
+                const int ro = sd.o_nc == 1 ? (col < cig_len(sd.o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[sd.result], sd.o_nc, col);
+                if (ro >= 0 && (int64_t)sd.o_pos + ro < sd.ref_len) ref4 = d_ref_nib((const uint8_t *)sd.ref, (int64_t)sd.o_pos + ro);
+            }
+            if (odd) s_gflag[sd.grp] = 2;
+            else {
+                const ColOut r = decide_column_packed(t, p, out_base, ref4);
+                s_resb[s][col] = (uint8_t)r.base; s_resq[s][col] = (uint8_t)r.qual;
+                if (r.minc) atomicAdd(&s_side[s].minc, r.minc);
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P6: results per (group, side); NM patch or restore (group.cpp:528-573)
+    if (tid < 2 * ng) {
+        const int j = tid >> 1, side = tid & 1;
+        const uint32_t gi = s_ggi[j];
+        VSide *sd = &s_side[tid];
+        if (s_gflag[j] == 2) {                                                          // found out of scope on the way: the whole group goes on, untouched
+            if (sd->state == VS_ACTIVE || sd->state == VS_FINAL) sd->state = VS_GEN;
+            if (side == 0) {
+                w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
+                for (int k = 0; k < (int)s_gnp[j]; k++) w.slot_flag[s_gbeg[j] + k] = 1;
+            }
+        } else if (s_gflag[j] == 0) {
+            uint32_t *rp_out = side ? w.rp_right : w.rp_left;
+            if (sd->state == VS_ACTIVE) {
+                const uint32_t out = sd->result;
+                const int minc = sd->minc;
+                bool restore = false;
+                if (minc != 0) {
+                    const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
+                    if (o_nm_type == 0) { raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+                    else if (minc > 5) restore = true;
+                    else { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.rp_nm[2 * gi + side] = nn; }
+                }
+                if (restore) {
+                    // seq and qual restored wholesale from the backup taken AFTER computeScore (group.cpp:327-333,555-556): the bases stay,
+                    // the quals are the original ones except where the overlap check rewrote them (pair.cpp:158-159, quirk Q7)
+                    sd->state = VS_RESTORE;
+                    const int lp = s_glp0[j] + sd->tmpl;
+                    const VRead *r = &s_rd[side][lp], *mt = &s_rd[side ^ 1][lp];
+                    const VOv ov = s_ov[lp];
+                    const int mystart = side ? ov.rs : ov.ls, len = sd->len;
+                    for (int c = 0; c < len; c++) {
+                        int q = b.qual[r->qo + c];
+                        if ((ov.fl & 2) && (unsigned)(c - mystart) < (unsigned)ov.cmp) {
+                            const int mc = c - mystart + (side ? ov.ls : ov.rs);
+                            if (d_nib(b.seq + r->so, c) != d_nib(b.seq + mt->so, mc)) q = max(0, q - (int)b.qual[mt->qo + mc]);
+                        }
+                        s_resq[tid][c] = (uint8_t)q;
+                    }
+                    for (int k = 0; k < VB_COLS / 32; k++) s_cmask[tid][k] = 0u;         // no base of the template changes
+                }
+                rp_out[gi] = out;
+            } else if (sd->state == VS_FINAL) rp_out[gi] = sd->result;
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- P7: the templates go back (the only writes to the reads)
+    {
+        const int n_items = s_ipre[VB_SIDES];
+        for (int it = tid; it < n_items; it += 256) {
+            const int s = vb_find(s_ipre, VB_SIDES, it);
+            const VSide sd = s_side[s];
+            if (sd.state != VS_ACTIVE && sd.state != VS_RESTORE) continue;
+            const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
+            const VRead *r = &s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl];
+            uint8_t *oq = b.qual + r->qo + c16, *os = b.seq + r->so + 8 * chunk;
+            const uint4 q4 = *(const uint4 *)(&s_resq[s][c16]);
+            typedef uint64_t u64u __attribute__((aligned(1)));
+            if (nval == 16) { *(u64u *)oq = (uint64_t)q4.x | ((uint64_t)q4.y << 32); *(u64u *)(oq + 8) = (uint64_t)q4.z | ((uint64_t)q4.w << 32); }
+            else for (int k = 0; k < nval; k++) oq[k] = s_resq[s][c16 + k];
+            uint32_t cm = (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu;
+            if (cm) {
+                const int nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
+                uint64_t x = 0;
+                for (int k = 0; k < nbytes; k++) x |= (uint64_t)os[k] << (8 * k);
+                const uint64_t x0 = x;
+                for (; cm; cm &= cm - 1) {
+                    const int k = __ffs((int)cm) - 1, sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
+                    x = (x & ~(0xFull << sh)) | ((uint64_t)(s_resb[s][c16 + k] & 0xF) << sh);
+                }
+                if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
+            }
+        }
+    }
+}
