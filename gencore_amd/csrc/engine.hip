@@ -465,7 +465,7 @@ int gce_process(gce_engine *e) {
         w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>();
         w.gw = e->gw.as<uint64_t>(); w.g_wbase = e->g_wbase.as<uint32_t>(); w.vb_start = e->vb_start.as<uint32_t>();
         HIPCHK(hipMemsetAsync(e->vb_start.p, 0xFF, vb_cap * 4, s));
-        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr);
+        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr, (uint32_t)VB_W);
         hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)w.gw, (const unsigned long long *)&w.si->n_groups, w.scan_part);
         hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_groups, &w.si->vote_weight);
         hipLaunchKernelGGL(k_vote_batches, dim3(nblk_N), dim3(256), 0, s, w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);
@@ -490,7 +490,7 @@ int gce_process(gce_engine *e) {
         if (use_vote) {
             HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
             const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
-            hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(256), 0, s, b, p, w, NG);
+            hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
             HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
             hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);   // the handed-on groups only
         } else {

@@ -10,9 +10,12 @@
 //   P3  lane = pair            mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
 //   P4  lane = (side, 16 columns)  "pass A": OR / AND of the voters' packed bases (unanimity), packed max of their quals; a column
 //                              all voters agree on with top quality >= moderate takes group.cpp:421-428 (base kept, qual = max qual)
-//   P5  lane = (side, contested column)  "pass B": 5-bin tallies over the voters with the exact scores of pair.cpp:132-169 computed on
-//                              the fly (qualities of mismatching overlap bases rewritten to max(0, own - mate)), rule cascade + reference
-//                              arbitration (group.cpp:394-501)
+//   P5  lane = (side, voter, contested column)  "pass B": the voter's base, quality and exact score (pair.cpp:132-169 computed on the fly,
+//                              the qualities of mismatching overlap bases rewritten to max(0, own - mate)) go into the column's 5-bin tally
+//                              in LDS; consecutive lanes = consecutive contested columns of ONE voter, so a wave's 64 byte loads fall
+//                              into a dozen cache lines (column-major items made every lane touch a line of its own: the texture
+//                              addresser, not HBM, was the limit).  Then lane = contested column: rule cascade + reference arbitration
+//                              (group.cpp:394-501)
 //   P6  lane = (group, side)   mismatchInc -> NM patch or restore (group.cpp:528-573), result records
 //   P7  lane = (side, 16 columns)  write the template back
 // Nothing is written to the reads before P7, and only the templates are: the quality rewrite of pair.cpp:158-159 exists in registers
@@ -24,12 +27,18 @@
 // (-> k_score2 scores just those pairs).
 #pragma once
 
+#ifndef VB_T
+#define VB_T 256           // threads per batch
+#endif
 #define VB_W 64            // batch capacity in weight units (weight of a group = max(pairs, 4); a handed-on deep group takes a whole batch)
 #define VB_MINW 4
 #define VB_MAXG 16
 #define VB_MAXP 96
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
+#define VB_CCAP 192        // contested columns voted per round (LDS tallies)
+#define VB_SMAX 32         // a side with more contested columns than this hands its group on
+#define VB_RCAP (VB_SIDES * VB_SMAX)
 
 struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
 static_assert(sizeof(VRead) == 32, "VRead must stay 32 bytes");
@@ -93,18 +102,23 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+__global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
     __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
-    __shared__ __attribute__((aligned(16))) uint8_t s_resq[VB_SIDES][VB_COLS];
-    __shared__ uint8_t s_resb[VB_SIDES][VB_COLS];
+    __shared__ uint16_t s_tid[2][VB_MAXP];
+    __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index inside the group), ascending
+    __shared__ __attribute__((aligned(16))) uint32_t s_tal[VB_CCAP][5][4];         // pass B: per contested column and bin {count, score sum, qual sum, top qual}
+    __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
+    __shared__ uint16_t s_jpre[VB_SIDES + 1];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
     __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
     __shared__ uint8_t s_glp0[VB_MAXG + 1], s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng;
-    const int tid = threadIdx.x, lane = tid & 63;
+    // work index of a thread: rotated by the batch number, so that the single-wave phases (P0, P2, P5a, P6) and the half-empty ones
+    // do not all land on the same SIMD of the CU (wave k of every workgroup runs on SIMD k)
+    const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
     const uint32_t g0 = w.vb_start[blockIdx.x];
     if (g0 == NONE32) return;
     // ---------------------------------------------------------------- P0: the groups of this batch
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
             for (uint32_t k = 0; k < np; k++) w.slot_flag[gb + k] = 1;
         }
     }
-    for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += 256) (&s_cmask[0][0])[k] = 0u;
+    for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
     __syncthreads();
     const int ng = s_ng, npairs = s_glp0[ng];
     // ---------------------------------------------------------------- P1: pairs -> read descriptors, overlap window
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
         VRead vl, vr;
         vl.so = lk.so; vl.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
         vr.so = rk.so; vr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
-        s_rd[0][tid] = vl; s_rd[1][tid] = vr;
+        s_rd[0][tid] = vl; s_rd[1][tid] = vr; s_tid[0][tid] = lk.tid16; s_tid[1][tid] = rk.tid16;
         VOv ov; ov.ls = 0; ov.rs = 0; ov.cmp = 0; ov.fl = 0;
         if (L == NONE32 || R == NONE32 || !(lk.ml > 0 && rk.ml > 0)) ov.fl = 1;        // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
         else {
@@ -187,15 +201,27 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
                     uint32_t o_cw1 = 0, o_cw2 = 0;
                     if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
                     const int len = t.lq;
-                    uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1;
+                    // right reads on different positions: not leftReadMode (group.cpp:177-194) -- isPartOf then compares CIGARs from their
+                    // END, containedBy only counts reads with the same right end (:220-224), columns align at the right end.  For one
+                    // class of identical reads (same CIGAR, length AND position) nothing changes, as long as every other read is unrelated
+                    // to it from the end as well: >= 2 ops and a LAST op that is not an M block of >= len bases (a leading soft clip,
+                    // typically) -- such a read neither votes (group.cpp:287-313) nor contains or is contained.
+                    bool ralign = false;
+                    if (side == 1) for (int k = 0; k < np; k++) if (((hm >> k) & 1u) && rds[k].pos != t.pos) ralign = true;
+                    uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1 || (ralign && multi);
                     for (int k = 0; k < np; k++) {
                         if (!((hm >> k) & 1u)) continue;
                         const VRead r = rds[k];
                         uint32_t cw1 = 0, cw2 = 0;
                         if (multi && r.nc >= 2 && r.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[r.rd]; cw1 = cg[1]; if (r.nc == 3) cw2 = cg[2]; }
-                        const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq;
-                        if (major) vm |= 1u << k;
-                        if ((!major && (multi || r.nc < 2 || (cig_op(r.c0) == 0 && cig_len(r.c0) >= len))) || (side == 1 && r.pos != t.pos)) unfit = true;
+                        const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq && (!ralign || r.pos == t.pos);
+                        if (major) { s_vlist[lane][__popc(vm)] = (uint8_t)k; vm |= 1u << k; }
+                        else {
+                            uint32_t edge = r.c0;                                       // the op isPartOf looks at first: the first one, or the last when right aligned
+                            if (ralign && r.nc >= 2) edge = b.cigar[b.cigar_off[r.rd] + r.nc - 1];
+                            if (multi || r.nc < 2 || (cig_op(edge) == 0 && cig_len(edge) >= len)) unfit = true;
+                        }
+                        if (side == 1 && !ralign && r.pos != t.pos) unfit = true;
                     }
                     const int nvot = __popc(vm);
                     to_gen = unfit || nvot <= __popc(hm) - nvot || len > VB_COLS || len < 1;
@@ -203,11 +229,12 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
                         sd.state = VS_ACTIVE; sd.vmask = vm; sd.tmpl = (uint8_t)fl; sd.nvot = (uint8_t)nvot; sd.len = (uint16_t)len;
                         sd.o_pos = t.pos; sd.o_c0 = t.c0; sd.o_nc = t.nc; sd.result = t.rd;
                         if (t.fl & 1) {                                                 // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
-                            const int o_tid = b.core[t.rd].tid;
+                            const int t16 = s_tid[side][lp0 + fl], o_tid = t16 != 0xFFFF ? t16 : b.core[t.rd].tid;
                             if (o_tid >= 0 && o_tid < p.n_ref) {
                                 const uint8_t *rdp = p.ref_data[o_tid];
+                                const int64_t rl = p.ref_len[o_tid];
                                 const int64_t need_len = (int64_t)(t.nc == 1 ? ((len - 1) < cig_len(t.c0) ? (len - 1) : -1) : d_ref_offset(b.cigar + b.cigar_off[t.rd], t.nc, len - 1)) + 1;
-                                if (rdp && (int64_t)t.pos + need_len < p.ref_len[o_tid]) { sd.ref = (uint64_t)rdp; sd.ref_len = p.ref_len[o_tid]; }
+                                if (rdp && (int64_t)t.pos + need_len < rl) { sd.ref = (uint64_t)rdp; sd.ref_len = rl; }
                             }
                         }
                     }
@@ -243,48 +270,74 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
         while (j + 1 < ng && (int)s_glp0[j + 1] <= tid) j++;
         if ((ov.fl & 2) && s_gflag[j] == 0) {
             const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
-            for (int i = 0; i < (int)ov.cmp; i += 8) {
-                const int l0 = ov.ls + i, r0 = ov.rs + i, nv = min(8, (int)ov.cmp - i);
-                // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
-                auto cols8 = [](const uint8_t *s, int c0) {
-                    const uint64_t x = ld8_unaligned(s + (c0 >> 1));
-                    const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
-                    return (uint32_t)(y >> (4 * (c0 & 1)));
-                };
-                uint32_t d = (cols8(ls, l0) ^ cols8(rs, r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
-                d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
-                while (d) {
-                    const int k = (__ffs((int)d) - 1) >> 2;
-                    d &= d - 1;
-                    const int l = l0 + k, r = r0 + k;
-                    if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
-                    if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
+            // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
+            auto cols8 = [](uint64_t x, int c0) {
+                const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
+                return (uint32_t)(y >> (4 * (c0 & 1)));
+            };
+            for (int i = 0; i < (int)ov.cmp; i += 32) {                                 // four 8-column words per step, loads first
+                uint64_t lw[4], rw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = min(i + 8 * u, (int)ov.cmp - 1);                     // (clamped: a short last step re-reads a valid word)
+                    lw[u] = ld8_unaligned(ls + ((ov.ls + ii) >> 1)); rw[u] = ld8_unaligned(rs + ((ov.rs + ii) >> 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i0 = i + 8 * u, nv = min(8, (int)ov.cmp - i0);
+                    if (nv <= 0) continue;
+                    const int l0 = ov.ls + i0, r0 = ov.rs + i0;
+                    uint32_t d = (cols8(lw[u], l0) ^ cols8(rw[u], r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
+                    d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
+                    while (d) {
+                        const int k = (__ffs((int)d) - 1) >> 2;
+                        d &= d - 1;
+                        const int l = l0 + k, r = r0 + k;
+                        if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
+                        if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // ---------------------------------------------------------------- P4: pass A, one lane per (side, 16 columns)
-    {
-        const int n_items = s_ipre[VB_SIDES];
-        for (int it = tid; it < n_items; it += 256) {
+    // ---------------------------------------------------------------- P4: pass A, one lane per (side, 16 columns); the 16 top qualities stay
+    //      in registers until the write-back (an item keeps its lane: it = tid + VB_T k, k < VB_IPL)
+#define VB_IPL (VB_SIDES * (VB_COLS / 16) / VB_T)
+    uint4 keep[VB_IPL];
+    const int n_items = s_ipre[VB_SIDES];
+#pragma unroll
+    for (int kk = 0; kk < VB_IPL; kk++) {
+        keep[kk] = make_uint4(0, 0, 0, 0);
+        const int it = tid + VB_T * kk;
+        if (it < n_items) {
             const int s = vb_find(s_ipre, VB_SIDES, it);
             const VSide sd = s_side[s];
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
             const VRead *rds = s_rd[s & 1] + s_glp0[sd.grp];
-            uint64_t sor = 0, sand = ~0ull; uint32_t qor = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
-            for (uint32_t vm = sd.vmask; vm; vm &= vm - 1) {
-                const VRead *r = rds + (__ffs((int)vm) - 1);
-                const uint64_t so = r->so, qo = r->qo;
-                const uint64_t sq = ld8_unaligned(b.seq + so + 8 * chunk);
-                const uint64_t qa = ld8_unaligned(b.qual + qo + c16), qb = ld8_unaligned(b.qual + qo + c16 + 8);
-                sor |= sq; sand &= sq;
-                const uint32_t q0 = (uint32_t)qa, q1 = (uint32_t)(qa >> 32), q2 = (uint32_t)qb, q3 = (uint32_t)(qb >> 32);
-                qor |= q0 | q1 | q2 | q3;
-                m0 = pk_max_u16(m0, __builtin_amdgcn_perm(0u, q0, 0x0c010c00u)); m1 = pk_max_u16(m1, __builtin_amdgcn_perm(0u, q0, 0x0c030c02u));
-                m2 = pk_max_u16(m2, __builtin_amdgcn_perm(0u, q1, 0x0c010c00u)); m3 = pk_max_u16(m3, __builtin_amdgcn_perm(0u, q1, 0x0c030c02u));
-                m4 = pk_max_u16(m4, __builtin_amdgcn_perm(0u, q2, 0x0c010c00u)); m5 = pk_max_u16(m5, __builtin_amdgcn_perm(0u, q2, 0x0c030c02u));
-                m6 = pk_max_u16(m6, __builtin_amdgcn_perm(0u, q3, 0x0c010c00u)); m7 = pk_max_u16(m7, __builtin_amdgcn_perm(0u, q3, 0x0c030c02u));
+            uint64_t sor = 0, sand = ~0ull; uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+            // four voters per step: their twelve 8-byte loads are issued before the first byte is looked at; a short last step repeats the
+            // step's first voter -- OR, AND and max do not mind
+            for (uint32_t vm = sd.vmask; vm;) {
+                const VRead *r0 = rds + (__ffs((int)vm) - 1); vm &= vm - 1;
+                const VRead *r1 = vm ? rds + (__ffs((int)vm) - 1) : r0; vm &= vm ? vm - 1 : 0u;
+                const VRead *r2 = vm ? rds + (__ffs((int)vm) - 1) : r0; vm &= vm ? vm - 1 : 0u;
+                const VRead *r3 = vm ? rds + (__ffs((int)vm) - 1) : r0; vm &= vm ? vm - 1 : 0u;
+                const uint64_t so0 = r0->so, qo0 = r0->qo, so1 = r1->so, qo1 = r1->qo, so2 = r2->so, qo2 = r2->qo, so3 = r3->so, qo3 = r3->qo;
+                uint64_t sq[4], qa[4], qb[4];
+                sq[0] = ld8_unaligned(b.seq + so0 + 8 * chunk); qa[0] = ld8_unaligned(b.qual + qo0 + c16); qb[0] = ld8_unaligned(b.qual + qo0 + c16 + 8);
+                sq[1] = ld8_unaligned(b.seq + so1 + 8 * chunk); qa[1] = ld8_unaligned(b.qual + qo1 + c16); qb[1] = ld8_unaligned(b.qual + qo1 + c16 + 8);
+                sq[2] = ld8_unaligned(b.seq + so2 + 8 * chunk); qa[2] = ld8_unaligned(b.qual + qo2 + c16); qb[2] = ld8_unaligned(b.qual + qo2 + c16 + 8);
+                sq[3] = ld8_unaligned(b.seq + so3 + 8 * chunk); qa[3] = ld8_unaligned(b.qual + qo3 + c16); qb[3] = ld8_unaligned(b.qual + qo3 + c16 + 8);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    sor |= sq[k]; sand &= sq[k];
+                    const uint32_t q0 = (uint32_t)qa[k], q1 = (uint32_t)(qa[k] >> 32), q2 = (uint32_t)qb[k], q3 = (uint32_t)(qb[k] >> 32);
+                    m0 = pk_max_u16(m0, __builtin_amdgcn_perm(0u, q0, 0x0c010c00u)); m1 = pk_max_u16(m1, __builtin_amdgcn_perm(0u, q0, 0x0c030c02u));
+                    m2 = pk_max_u16(m2, __builtin_amdgcn_perm(0u, q1, 0x0c010c00u)); m3 = pk_max_u16(m3, __builtin_amdgcn_perm(0u, q1, 0x0c030c02u));
+                    m4 = pk_max_u16(m4, __builtin_amdgcn_perm(0u, q2, 0x0c010c00u)); m5 = pk_max_u16(m5, __builtin_amdgcn_perm(0u, q2, 0x0c030c02u));
+                    m6 = pk_max_u16(m6, __builtin_amdgcn_perm(0u, q3, 0x0c010c00u)); m7 = pk_max_u16(m7, __builtin_amdgcn_perm(0u, q3, 0x0c030c02u));
+                }
             }
             // columns beyond the read (last chunk) read the neighbouring bytes: masked out of every test below
             const uint32_t colmask = nval >= 16 ? 0xFFFFu : ((1u << nval) - 1u);
@@ -297,86 +350,120 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
             const uint32_t geq = ge4(t0) | (ge4(t1) << 4) | (ge4(t2) << 8) | (ge4(t3) << 12);
             uint32_t contested = (differ | ~valid | ~geq) & colmask;
             if (!p.vote_accept_by_qual && (int)sd.nvot * p.s_min_lb < max(p.base_score_req, 1)) contested = colmask;   // scores cannot be bounded: vote everything
-            if (((qor & 0x80808080u) != 0) || p.moderate_q > 127) s_gflag[sd.grp] = 2;                  // quals >= 128: out of scope (checked over whole chunks: conservative)
-            *(uint4 *)(&s_resq[s][c16]) = make_uint4(t0, t1, t2, t3);
+            // quals >= 128: out of scope (checked over the columns of the read only: the bytes behind a short last chunk are a neighbour's)
+            const uint32_t hib = (msb4(t0) | (msb4(t1) << 4) | (msb4(t2) << 8) | (msb4(t3) << 12)) & colmask;
+            if (hib != 0 || p.moderate_q > 127) s_gflag[sd.grp] = 2;
+            keep[kk] = make_uint4(t0, t1, t2, t3);
             if (contested) atomicOr(&s_cmask[s][chunk >> 1], contested << (16 * (chunk & 1)));
         }
     }
     __syncthreads();
-    // ---------------------------------------------------------------- P5: pass B, one lane per (side, contested column)
+    // ---------------------------------------------------------------- P5: pass B
+    // (a) contested columns per side (forced columns behind the template's end do not exist); a side with too many hands its group on;
+    //     prefixes over the sides: of the columns, and of the (voter, column) items
     if (tid < 64) {
         int cnt = 0;
-        if (lane < VB_SIDES && s_side[lane].state == VS_ACTIVE && s_gflag[s_side[lane].grp] == 0) {
+        const bool act = lane < VB_SIDES && s_side[lane].state == VS_ACTIVE && s_gflag[s_side[lane].grp] == 0;
+        if (act) {
             const int len = s_side[lane].len;
             for (int k = 0; k < VB_COLS / 32; k++) {
                 uint32_t m = s_cmask[lane][k];
-                const int hi = len - 32 * k;                                            // forced columns beyond the template (longer mates) do not exist
+                const int hi = len - 32 * k;
                 if (hi < 32) m &= hi <= 0 ? 0u : ((1u << hi) - 1u);
                 s_cmask[lane][k] = m;
                 cnt += __popc(m);
             }
         }
-        int pre = cnt;
-        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o); if (lane >= o) pre += t2; }
-        if (lane < VB_SIDES) s_cpre[lane] = (uint16_t)(pre - cnt);
-        if (lane == VB_SIDES - 1) s_cpre[VB_SIDES] = (uint16_t)pre;
+        const int over = cnt > VB_SMAX, other_over = __shfl_xor(over, 1);
+        if (over && lane < VB_SIDES) s_gflag[s_side[lane].grp] = 2;
+        if (over || other_over || !act) cnt = 0;
+        const int nit = act ? cnt * (int)s_side[lane].nvot : 0;
+        int pre = cnt, pre2 = nit;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o), t3 = __shfl_up(pre2, o); if (lane >= o) { pre += t2; pre2 += t3; } }
+        if (lane < VB_SIDES) { s_cpre[lane] = (uint16_t)(pre - cnt); s_jpre[lane] = (uint16_t)(pre2 - nit); }
+        if (lane == VB_SIDES - 1) { s_cpre[VB_SIDES] = (uint16_t)pre; s_jpre[VB_SIDES] = (uint16_t)pre2; }
     }
     __syncthreads();
-    {
-        const int n_items = s_cpre[VB_SIDES];
-        for (int it = tid; it < n_items; it += 256) {
-            const int s = vb_find(s_cpre, VB_SIDES, it);
-            int kth = it - (int)s_cpre[s], col = 0;
-            for (int k = 0; k < VB_COLS / 32; k++) {                                    // the kth-th contested column of the side
-                uint32_t m = s_cmask[s][k];
-                const int c = __popc(m);
-                if (kth >= c) { kth -= c; continue; }
-                for (int q = 0; q < kth; q++) m &= m - 1;
-                col = 32 * k + __ffs((int)m) - 1;
-                break;
+    // (b) the list of contested columns, side by side: thread = (side, mask word)
+    for (int q = tid; q < VB_SIDES * (VB_COLS / 32); q += VB_T) {
+        const int s = q / (VB_COLS / 32), k = q % (VB_COLS / 32);
+        if (s_cpre[s + 1] > s_cpre[s]) {
+            int base = s_cpre[s];
+            for (int x = 0; x < k; x++) base += __popc(s_cmask[s][x]);
+            for (uint32_t m = s_cmask[s][k]; m; m &= m - 1) s_ccol[base++] = (uint8_t)(32 * k + __ffs((int)m) - 1);
+        }
+    }
+    const int n_cont = s_cpre[VB_SIDES];
+    // sides are voted in rounds of whole sides whose columns fit the tallies (usually one round)
+    for (int s0 = 0; s0 < VB_SIDES;) {
+        int s1 = s0;
+        while (s1 < VB_SIDES && (int)s_cpre[s1 + 1] - (int)s_cpre[s0] <= VB_CCAP) s1++;          // sides [s0, s1) : a side has <= VB_SMAX columns
+        const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
+        for (int k = tid; k < ncol * 5; k += VB_T) *(uint4 *)(&s_tal[0][0][0] + 4 * k) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        // (c) one lane per (side, voter, contested column), columns fastest
+        for (int it = j0 + tid; it < j0 + njob; it += VB_T) {
+            const int s = s0 + vb_find(s_jpre + s0, s1 - s0, it), side = s & 1;
+            const int ncs = (int)s_cpre[s + 1] - (int)s_cpre[s], local = it - (int)s_jpre[s];
+            const int kv = (int)(((uint32_t)local * ((65536u + (uint32_t)ncs - 1u) / (uint32_t)ncs)) >> 16), c = local - kv * ncs;
+            const int ci = (int)s_cpre[s] + c, col = s_ccol[ci];
+            const VSide *sd = &s_side[s];
+            const int lp = s_glp0[sd->grp] + s_vlist[s][kv];
+            const VRead *r = &s_rd[side][lp];
+            const VOv ov = s_ov[lp];
+            const int mystart = side ? ov.rs : ov.ls;
+            const bool inov = (ov.fl & 2) && (unsigned)(col - mystart) < (unsigned)ov.cmp;
+            const int sb = b.seq[r->so + (col >> 1)];
+            int q = b.qual[r->qo + col], sc, mb = 0, mq = 0, mc = 0;
+            if (inov) {                                                                 // pair.cpp:132-168: the mate's base and quality on the same reference position
+                const VRead *mt = &s_rd[side ^ 1][lp];
+                mc = col - mystart + (side ? ov.ls : ov.rs);
+                mb = b.seq[mt->so + (mc >> 1)]; mq = b.qual[mt->qo + mc];
             }
+            const int nb = (col & 1) ? (sb & 0xF) : (sb >> 4);
+            if (ov.fl & 1) sc = p.s_moderate;                                           // pair.cpp:89-105
+            else if (inov) {
+                const int mn = (mc & 1) ? (mb & 0xF) : (mb >> 4);
+                if (nb == mn) sc = d_qual2score(p, ((q + mq) / 2) & 0xFF) + 4;
+                else {
+                    const bool left_wins = side ? (mq >= q) : (q >= mq);              // `if(lq >= rq)`: the left read keeps a score
+                    const int dq = max(0, q - mq);
+                    sc = (side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
+                    q = dq;                                                             // the rewritten quality is what the vote sees
+                }
+            } else sc = d_qual2score(p, q);
+            const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
+            if (bin < 0 || (q & 0x80)) s_gflag[sd->grp] = 2;
+            else {
+                uint32_t *t4 = &s_tal[ci - c0][bin][0];
+                atomicAdd(t4, 1u); atomicAdd(t4 + 1, (uint32_t)sc); atomicAdd(t4 + 2, (uint32_t)q); atomicMax(t4 + 3, (uint32_t)q);
+            }
+        }
+        __syncthreads();
+        // (d) one lane per column of the round: rule cascade + reference arbitration (group.cpp:394-501)
+        for (int ci = c0 + tid; ci < c0 + ncol; ci += VB_T) {
+            const int s = s0 + vb_find(s_cpre + s0, s1 - s0, ci), col = s_ccol[ci];
             const VSide sd = s_side[s];
-            const int side = s & 1, lp0 = s_glp0[sd.grp];
-            Tally5 t; tally_clear(t);
-            bool odd = false; int out_base = 0;
-            for (uint32_t vm = sd.vmask; vm; vm &= vm - 1) {
-                const int v = __ffs((int)vm) - 1;
-                const VRead *r = &s_rd[side][lp0 + v];
-                const uint64_t so = r->so, qo = r->qo;
-                const int nb = d_nib(b.seq + so, col);
-                int q = b.qual[qo + col], sc;
-                const VOv ov = s_ov[lp0 + v];
-                const int mystart = side ? ov.rs : ov.ls;
-                if (ov.fl & 1) sc = p.s_moderate;                                       // pair.cpp:89-105
-                else if ((ov.fl & 2) && (unsigned)(col - mystart) < (unsigned)ov.cmp) {  // pair.cpp:132-168
-                    const VRead *mt = &s_rd[side ^ 1][lp0 + v];
-                    const int mc = col - mystart + (side ? ov.ls : ov.rs);
-                    const int mn = d_nib(b.seq + mt->so, mc), mq = b.qual[mt->qo + mc];
-                    if (nb == mn) sc = d_qual2score(p, ((q + mq) / 2) & 0xFF) + 4;
-                    else {
-                        const bool left_wins = side ? (mq >= q) : (q >= mq);          // `if(lq >= rq)`: the left read keeps a score
-                        const int dq = max(0, q - mq);
-                        sc = (side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
-                        q = dq;                                                         // the rewritten quality is what the vote sees
-                    }
-                } else sc = d_qual2score(p, q);
-                if (v == (int)sd.tmpl) out_base = nb;
-                if ((q & 0x80) || !tally_add(t, nb, q, sc)) odd = true;
-            }
             int ref4 = 0;
             if (sd.ref) {                                                               // group.cpp:430-439
                 const int ro = sd.o_nc == 1 ? (col < cig_len(sd.o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[sd.result], sd.o_nc, col);
                 if (ro >= 0 && (int64_t)sd.o_pos + ro < sd.ref_len) ref4 = d_ref_nib((const uint8_t *)sd.ref, (int64_t)sd.o_pos + ro);
             }
-            if (odd) s_gflag[sd.grp] = 2;
-            else {
-                const ColOut r = decide_column_packed(t, p, out_base, ref4);
-                s_resb[s][col] = (uint8_t)r.base; s_resq[s][col] = (uint8_t)r.qual;
-                if (r.minc) atomicAdd(&s_side[s].minc, r.minc);
+            const int out_base = d_nib(b.seq + s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl].so, col);
+            Tally5 t; t.total = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint4 v4 = *(const uint4 *)(&s_tal[ci - c0][k][0]);
+                t.cnt[k] = (int)v4.x; t.ss[k] = (int)v4.y; t.qs[k] = (int)v4.z; t.tq[k] = (int)v4.w; t.total += (int)v4.y;
             }
+            const ColOut r = decide_column_packed(t, p, out_base, ref4);
+            s_cq[ci] = (uint8_t)r.qual; s_cb[ci] = (uint8_t)r.base;
+            if (r.minc) atomicAdd(&s_side[s].minc, r.minc);
         }
+        __syncthreads();
+        s0 = s1;
+        if (s_cpre[s0] >= n_cont) break;
     }
-    __syncthreads();
     // ---------------------------------------------------------------- P6: results per (group, side); NM patch or restore (group.cpp:528-573)
     if (tid < 2 * ng) {
         const int j = tid >> 1, side = tid & 1;
@@ -400,55 +487,76 @@ __global__ __launch_bounds__(256) void k_vote(DevBatch b, DevParams p, Work w, u
                     else if (minc > 5) restore = true;
                     else { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.rp_nm[2 * gi + side] = nn; }
                 }
-                if (restore) {
-                    // seq and qual restored wholesale from the backup taken AFTER computeScore (group.cpp:327-333,555-556): the bases stay,
-                    // the quals are the original ones except where the overlap check rewrote them (pair.cpp:158-159, quirk Q7)
-                    sd->state = VS_RESTORE;
-                    const int lp = s_glp0[j] + sd->tmpl;
-                    const VRead *r = &s_rd[side][lp], *mt = &s_rd[side ^ 1][lp];
-                    const VOv ov = s_ov[lp];
-                    const int mystart = side ? ov.rs : ov.ls, len = sd->len;
-                    for (int c = 0; c < len; c++) {
-                        int q = b.qual[r->qo + c];
-                        if ((ov.fl & 2) && (unsigned)(c - mystart) < (unsigned)ov.cmp) {
-                            const int mc = c - mystart + (side ? ov.ls : ov.rs);
-                            if (d_nib(b.seq + r->so, c) != d_nib(b.seq + mt->so, mc)) q = max(0, q - (int)b.qual[mt->qo + mc]);
-                        }
-                        s_resq[tid][c] = (uint8_t)q;
-                    }
-                    for (int k = 0; k < VB_COLS / 32; k++) s_cmask[tid][k] = 0u;         // no base of the template changes
-                }
+                if (restore) sd->state = VS_RESTORE;
                 rp_out[gi] = out;
             } else if (sd->state == VS_FINAL) rp_out[gi] = sd->result;
         }
     }
     __syncthreads();
     // ---------------------------------------------------------------- P7: the templates go back (the only writes to the reads)
-    {
-        const int n_items = s_ipre[VB_SIDES];
-        for (int it = tid; it < n_items; it += 256) {
+    // (a) a restored template (mismatchInc > 5, group.cpp:528-558): seq and qual come back from the backup taken AFTER computeScore
+    //     (group.cpp:327-333): the bases stay, the quals are the original ones except where the overlap check rewrote them (pair.cpp:158-159,
+    //     quirk Q7).  Read here, written below: the mate may be the other side's template.
+    bool any_restore = false;
+#pragma unroll
+    for (int kk = 0; kk < VB_IPL; kk++) {
+        const int it = tid + VB_T * kk;
+        if (it < n_items) {
+            const int s = vb_find(s_ipre, VB_SIDES, it);
+            const VSide sd = s_side[s];
+            if (sd.state == VS_RESTORE) {
+                any_restore = true;
+                const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16), side = s & 1;
+                const int lp = s_glp0[sd.grp] + sd.tmpl;
+                const VRead *r = &s_rd[side][lp], *mt = &s_rd[side ^ 1][lp];
+                const VOv ov = s_ov[lp];
+                const int mystart = side ? ov.rs : ov.ls;
+                uint32_t qq[4] = {0, 0, 0, 0};
+                for (int k = 0; k < nval; k++) {
+                    const int c = c16 + k;
+                    int q = b.qual[r->qo + c];
+                    if ((ov.fl & 2) && (unsigned)(c - mystart) < (unsigned)ov.cmp) {
+                        const int mc = c - mystart + (side ? ov.ls : ov.rs);
+                        if (d_nib(b.seq + r->so, c) != d_nib(b.seq + mt->so, mc)) q = max(0, q - (int)b.qual[mt->qo + mc]);
+                    }
+                    qq[k >> 2] |= (uint32_t)q << (8 * (k & 3));
+                }
+                keep[kk] = make_uint4(qq[0], qq[1], qq[2], qq[3]);
+            }
+        }
+    }
+    (void)__syncthreads_or(any_restore);            // (every read of the originals above precedes every write below)
+#pragma unroll
+    for (int kk = 0; kk < VB_IPL; kk++) {
+        const int it = tid + VB_T * kk;
+        if (it < n_items) {
             const int s = vb_find(s_ipre, VB_SIDES, it);
             const VSide sd = s_side[s];
             if (sd.state != VS_ACTIVE && sd.state != VS_RESTORE) continue;
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
             const VRead *r = &s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl];
             uint8_t *oq = b.qual + r->qo + c16, *os = b.seq + r->so + 8 * chunk;
-            const uint4 q4 = *(const uint4 *)(&s_resq[s][c16]);
-            typedef uint64_t u64u __attribute__((aligned(1)));
-            if (nval == 16) { *(u64u *)oq = (uint64_t)q4.x | ((uint64_t)q4.y << 32); *(u64u *)(oq + 8) = (uint64_t)q4.z | ((uint64_t)q4.w << 32); }
-            else for (int k = 0; k < nval; k++) oq[k] = s_resq[s][c16 + k];
-            uint32_t cm = (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu;
+            uint32_t qq[4] = {keep[kk].x, keep[kk].y, keep[kk].z, keep[kk].w};
+            uint32_t cm = sd.state == VS_ACTIVE ? (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu : 0u;
+            uint64_t x = 0, x0 = 0; int nbytes = 0;
             if (cm) {
-                const int nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
-                uint64_t x = 0;
+                // the voted columns of this chunk: their place in the side's list = contested columns in front of them
+                int ci = s_cpre[s];
+                for (int q = 0; q < (chunk >> 1); q++) ci += __popc(s_cmask[s][q]);
+                if (chunk & 1) ci += __popc(s_cmask[s][chunk >> 1] & 0xFFFFu);
+                nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
                 for (int k = 0; k < nbytes; k++) x |= (uint64_t)os[k] << (8 * k);
-                const uint64_t x0 = x;
-                for (; cm; cm &= cm - 1) {
+                x0 = x;
+                for (; cm; cm &= cm - 1, ci++) {
                     const int k = __ffs((int)cm) - 1, sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
-                    x = (x & ~(0xFull << sh)) | ((uint64_t)(s_resb[s][c16 + k] & 0xF) << sh);
+                    x = (x & ~(0xFull << sh)) | ((uint64_t)(s_cb[ci] & 0xF) << sh);
+                    qq[k >> 2] = (qq[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)s_cq[ci] << (8 * (k & 3)));
                 }
-                if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
             }
+            typedef uint64_t u64u __attribute__((aligned(1)));
+            if (nval == 16) { *(u64u *)oq = (uint64_t)qq[0] | ((uint64_t)qq[1] << 32); *(u64u *)(oq + 8) = (uint64_t)qq[2] | ((uint64_t)qq[3] << 32); }
+            else for (int k = 0; k < nval; k++) oq[k] = (uint8_t)(qq[k >> 2] >> (8 * (k & 3)));
+            if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
         }
     }
 }
