@@ -247,7 +247,7 @@ def main():
             kk = hj["kernels"]
             names = {"consensus": hj.get("consensus_kernels", []), "cluster": ["k_cluster"]}
             traffic = {k: sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in v if n in kk) for k, v in names.items()}
-    roofline = dict(bound="hbm", kernel={"consensus": "k_score2+k_consensus_* (Pair::computeScore + Group::makeConsensus)",
+    roofline = dict(bound="hbm", kernel={"consensus": "k_vote (+ k_score2/k_consensus_fast/_slow for handed-on groups): Pair::computeScore + Group::makeConsensus",
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic and traffic[dom] else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),

@@ -10,7 +10,6 @@
 #include <vector>
 
 #include "gce_kernels.hpp"
-#include "gce_lean2.hpp"
 #include "gce_pair2.hpp"
 #include "gce_vote.hpp"
 #include "gce_output.hpp"
@@ -356,7 +355,6 @@ int gce_process(gce_engine *e) {
         int bt = 1; while (bt < 31 && (1ll << bt) < (long long)std::max<size_t>(e->target_len.size(), 1)) bt++;
         int bl = 1; while (bl < 32 && (1ull << bl) <= (uint64_t)mx) bl++;
         p.key_bt = bt; p.key_bl = bl;
-        { const char *d = getenv("GCE_DBG"); p.dbg = d ? atoi(d) : 0; }
     }
     p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
 
@@ -486,18 +484,11 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
         HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
         HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
-        static const bool use_vote = !(getenv("GCE_VOTE") && atoi(getenv("GCE_VOTE")) == 0);     // 0: the round-1 pair k_score2 + k_consensus_lean2 (A/B)
-        if (use_vote) {
-            HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
-            const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
-            hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
-            HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);   // the handed-on groups only
-        } else {
-            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 0);
-            HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
-            hipLaunchKernelGGL(k_consensus_lean2, dim3(cdiv(NG, WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, NG);
-        }
+        HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
+        const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
+        hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
+        HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
         {   // compact the flagged sides into gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
             hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
@@ -597,25 +588,6 @@ int gce_drain(gce_engine *e, gce_result *out) {
     out->seq_off = e->r_soff.data(); out->qual_off = e->r_qoff.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
     out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
-    return GCE_OK;
-}
-
-// debugging aid (not part of the ABI): per-group result records and group tables of the last gce_process as text
-int gce_debug_dump(gce_engine *e, const char *path) {
-    if (!e || !e->processed) return GCE_ERR_INVALID;
-    const size_t NG = (size_t)e->h_si.n_groups, n = (size_t)e->n;
-    std::vector<uint32_t> rl(NG), rr(NG), gb(NG), gn(NG), gpl(n), gpr(n); std::vector<uint8_t> gf(2 * NG);
-    (void)hipMemcpy(rl.data(), e->rp_left.p, NG * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(rr.data(), e->rp_right.p, NG * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(gb.data(), e->g_begin.p, NG * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(gn.data(), e->g_np.p, NG * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(gpl.data(), e->gpl.p, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(gpr.data(), e->gpr.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(gf.data(), e->gen_flag.p, 2 * NG, hipMemcpyDeviceToHost);
-    FILE *f = fopen(path, "w"); if (!f) return GCE_ERR_INVALID;
-    for (size_t g = 0; g < NG; g++) {
-        fprintf(f, "g %zu np %u gen %d%d L %d R %d :", g, gn[g], gf[2 * g], gf[2 * g + 1], (int)rl[g], (int)rr[g]);
-        for (uint32_t k = 0; k < gn[g]; k++) fprintf(f, " (%d,%d)", (int)gpl[gb[g] + k], (int)gpr[gb[g] + k]);
-        fprintf(f, "\n");
-    }
-    fclose(f);
     return GCE_OK;
 }
 

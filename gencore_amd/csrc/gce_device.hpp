@@ -42,7 +42,6 @@ struct DevParams {
     const uint32_t *target_len;
     const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
     int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
-    int32_t dbg;                      // GCE_DBG: timing experiments only (results invalid)
     int32_t vote_ok, vote_accept_by_qual, s_min_lb;   // gce_vote.hpp: score constants in range; "top quality >= moderate" implies "score sum >= baseScoreReq"; smallest score
     int64_t tick_offset;
     int32_t trailing_flush;

@@ -357,7 +357,6 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
             const int id = u * CHUNK + id0;
             uint32_t hs = ((uint32_t)key[u].left * 0x9E3779B1u) ^ ((uint32_t)key[u].right * 0x85EBCA77u) ^ (ikey[u] * 0xC2B2AE3Du) ^ ((uint32_t)key[u].tid * 0x27D4EB2Fu);
             hs = (hs ^ (hs >> 15)) & (CL_LDS_SLOTS - 1);
-            if (p.dbg & 4) { leader[u] = id; lrank[u] = 0; s_cnt[id] = 1; continue; }
             for (;;) {                                                                      // (no waiting: a claimed slot's key was stored before the barrier)
                 const uint32_t old = atomicCAS(&s_slot[hs], 0u, (uint32_t)id + 1u);
                 if (old == 0u) { leader[u] = id; break; }
@@ -370,11 +369,6 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
         }
     }
     __syncthreads();
-    if (p.dbg & 8) {
-#pragma unroll
-        for (int u = 0; u < CL_U; u++) if (idx[u] < b.n) w.slot[idx[u]] = NONE32;
-        return;
-    }
     // ---- leaders: the bucket table
     bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
 #pragma unroll
@@ -386,14 +380,13 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
             tk[u] = d_tab_key(key[u], ikey[u], implied[u], (uint32_t)idx[u], p);
             if ((tk[u] & TAB_EXO) && (ikey[u] & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)idx[u]);   // > 2^29 flush events
             h[u] = d_bucket(d_tab_index(key[u], ikey[u], p), w.tsize, w.tinv);
-            if (p.dbg & 1) h[u] = d_bucket((d_tab_index(key[u], ikey[u], p) * 0x9E3779B97F4A7C15ull) >> 16, w.tsize, w.tinv);
         }
     }
     bool done[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {                                                       // first probe: claim an empty bucket
-        done[u] = !khead[u] || (p.dbg & 64);
-        if (khead[u] && !(p.dbg & 64)) {                                                   // (no load first: the CAS returns what is there)
+        done[u] = !khead[u];
+        if (khead[u]) {                                                                    // (no load first: the CAS returns what is there)
             cur[u] = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
             if (cur[u] == 0ull) { owner[u] = true; cur[u] = tk[u]; }
         }
@@ -434,13 +427,8 @@ __global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work
                     else { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
                 }
             }
-            if (!(p.dbg & 16)) rbase[u] = (uint32_t)atomicAdd(&w.tab[h[u]].ic, (unsigned long long)(unsigned)runlen[u] | (owner[u] ? (unsigned long long)ikey[u] << 32 : 0ull));
+            rbase[u] = (uint32_t)atomicAdd(&w.tab[h[u]].ic, (unsigned long long)(unsigned)runlen[u] | (owner[u] ? (unsigned long long)ikey[u] << 32 : 0ull));
         }
-    }
-    if (p.dbg & 32) {
-#pragma unroll
-        for (int u = 0; u < CL_U; u++) if (idx[u] < b.n) w.slot[idx[u]] = (cur[u] == 12345ull && rbase[u] == 77u) ? 0u : NONE32;
-        return;
     }
 #pragma unroll
     for (int u = 0; u < CL_U; u++)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of tools/profile_round.sh
 into profiles/<tag>_hbm_traffic.csv and profiles/hbm_traffic.json (the per-launch figures bench.py quotes in roofline.traffic).
-    python tools/hbm_summary.py gpurun_out/r01g profiles/r01_g "<command note>"
+    python tools/hbm_summary.py gpurun_out/r02a profiles/r02_a "<command note>" [workload]
 Counter units: KB per dispatch as reported by rocprofv3.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of
 wide coalesced reads (the x2 column); WRITE_SIZE and narrow access widths are uncalibrated, so both columns are given."""
 import collections
@@ -26,6 +26,7 @@ def per_kernel(d):
 
 def main():
     src, dst, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+    workload = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
     fe, wr = per_kernel(src + "_pmc_FETCH_SIZE"), per_kernel(src + "_pmc_WRITE_SIZE")
     rows = sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, (0, 0))[0] + wr.get(k, (0, 0))[0]))
     with open(dst + "_hbm_traffic.csv", "w") as f:
@@ -36,7 +37,8 @@ def main():
         for k in rows:
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, fe.get(k, (0, 0))[1] or wr.get(k, (0, 0))[1], fe.get(k, (0, 0))[0] / 1e3, 2 * fe.get(k, (0, 0))[0] / 1e3, wr.get(k, (0, 0))[0] / 1e3))
     js = {k: {"fetch_bytes": fe.get(k, (0, 0))[0] * 1e3, "fetch_bytes_x2": 2e3 * fe.get(k, (0, 0))[0], "write_bytes": wr.get(k, (0, 0))[0] * 1e3} for k in rows}
-    json.dump({"note": note, "kernels": js}, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)
+    cons = [k for k in rows if k in ("k_vote", "k_score2", "k_consensus_fast", "k_consensus_slow")]
+    json.dump({"note": note, "workload": workload, "consensus_kernels": cons, "kernels": js}, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)
     print(open(dst + "_hbm_traffic.csv").read())
 
 

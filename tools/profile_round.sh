@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the same default command  -> kernel summary
 #   3. separate --pmc passes for HBM traffic of the two roofline kernels (FETCH_SIZE, WRITE_SIZE), kernel-trace only
 # Output: gpurun_out/<tag>_*   (copy the summaries into profiles/ afterwards)
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 600 python bench.py 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg3.json
 timeout 300 python bench.py --workload cfg2 --cpu-sample-pairs 1000000 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg2.json
