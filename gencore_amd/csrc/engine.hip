@@ -12,6 +12,7 @@
 #include "gce_kernels.hpp"
 #include "gce_pair2.hpp"
 #include "gce_vote.hpp"
+#include "gce_deep.hpp"
 #include "gce_output.hpp"
 
 namespace {
@@ -59,7 +60,7 @@ struct gce_engine {
     DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, toff;
     DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -134,7 +135,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->chunk_cnt,
                      &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (auto &b : e->ref_buf) b.release();
@@ -378,6 +379,7 @@ int gce_process(gce_engine *e) {
     ENS(k64, n1 * 24); ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
     ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
     w.slow_list = e->slow_list.as<uint32_t>();
+    ENS(deep_list, (n1 / 64 + 64) * 16); w.deep_list = e->deep_list.p;
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, (size_t)(nblk_T > 2 * nblk_N ? nblk_T : 2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
     w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>(); w.spatch = e->spatch.as<uint32_t>();
@@ -448,6 +450,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
         compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
         hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
+        hipLaunchKernelGGL(k_pairing_deep, dim3(1024), dim3(PD_T), 0, s, b, p, w);             // deep clusters in LDS; the rest -> pq_list
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
         hipLaunchKernelGGL(k_pairing_slow<2>, dim3(1024), dim3(256), 0, s, b, p, w);
@@ -496,6 +499,8 @@ int gce_process(gce_engine *e) {
             hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
         }
         hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_vote_deep, dim3(2048), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);

@@ -1,0 +1,496 @@
+// gce_deep.hpp — deep group sides (> 64 pairs: ultra-deep amplicons, BASELINE.json configs[4]): one BLOCK per (group, side).
+//
+// k_consensus_slow walks every voter per column on one wave (O(voters x columns) dependent byte loads); a side of 600 voters x 250
+// columns keeps that wave busy for milliseconds while the chip idles.  Here the template pick and the voter list (side_prepare:
+// CIGAR classes, group.cpp:136-315) still run on one wave, but the votes -- the O(voters x columns) part -- are spread over the
+// block: every wave takes every 4th voter, a lane covers 4 adjacent columns of it with one 4-byte quality load, one 4-byte load of
+// packed bases and (inside a mate-overlap patch) one 4-byte score load, DV_UNROLL voters in flight per wave.  The tallies of the
+// five real bins (A, C, G, T, N) of every column live in LDS: one 64-bit atomic add of (count | score sum | quality sum) and one
+// 32-bit atomic max (top quality) per vote.  Then a lane per column decides (decide_column: the same code as the <= 64 pair path),
+// results are buffered in LDS, and the block writes the template back unless mismatchInc > 5 (group.cpp:537-558).
+// Sides it cannot take -- a nibble outside A,C,G,T,N, a quality >= 128, a template longer than DV_COLS -- are left to
+// k_consensus_slow untouched (gen_flag stays != 2).
+#pragma once
+#include "gce_kernels.hpp"
+
+#define DV_T 256                 // threads per block
+#define DV_COLS 512              // template columns per block
+#define DV_CHUNK 256             // voters staged per round
+#define DV_UNROLL 4
+#define DV_DONE 2                // gen_flag value: side finished here
+
+struct DVoter { uint64_t so, qo; int rl, ld; uint32_t patch, pad; };
+
+// column -> LDS slot: the four columns of a lane go to four different 64-slot groups, so that one atomic instruction of a wave
+// (one column j of every lane) touches consecutive slots
+__device__ __forceinline__ int dv_slot(int col) { return ((col & 3) << 7) | ((col >> 2) & 127); }        // DV_COLS = 512: 4 x 128
+
+struct DeepRec { uint32_t e, out, nv, len_mode; };      // len | left_mode << 16
+
+// template pick + voter list of every deep side, a wave per side (side_prepare keeps one wave busy; four sides per block keep the CU
+// busy): sides k_vote_deep can take are appended to deep_list, sides without a template are finished here
+__global__ __launch_bounds__(256) void k_deep_prepare(DevBatch b, DevParams p, Work w) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t n_slow = (uint32_t)w.si->n_slow;
+    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
+        const uint32_t e = w.slow_list[idx], gi = e >> 1; const bool is_left = !(e & 1);
+        const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
+        if (np <= 64) continue;                                                   // here for another reason (exotic bases, long reads)
+        const SidePrep sp = side_prepare(b, p, w, begin, np, is_left, lane);
+        if (lane == 0) {
+            if (sp.out == NONE32) { (is_left ? w.rp_left : w.rp_right)[gi] = NONE32; w.gen_flag[e] = DV_DONE; }
+            else if (sp.len <= DV_COLS && sp.nv < 65536u) {
+                DeepRec r; r.e = e; r.out = sp.out; r.nv = sp.nv; r.len_mode = (uint32_t)sp.len | (sp.left_mode ? 1u << 16 : 0u);
+                ((DeepRec *)w.deep_list)[atomicAdd(&w.si->n_deep, 1u)] = r;
+            }
+        }
+        WAVE_SYNC();
+    }
+}
+
+__global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Work w) {
+    __shared__ unsigned long long s_acc[5][DV_COLS];      // count (16) | biased score sum (24) << 16 | quality sum (24) << 40
+    __shared__ uint32_t s_tq[5][DV_COLS];
+    __shared__ DVoter s_v[DV_CHUNK];
+    __shared__ uint8_t s_nb[DV_COLS], s_nq[DV_COLS];
+    __shared__ int s_minc, s_exotic;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t n_deep = w.si->n_deep;
+    for (uint32_t idx = blockIdx.x; idx < n_deep; idx += gridDim.x) {
+        const DeepRec rec = ((const DeepRec *)w.deep_list)[idx];
+        const uint32_t e = rec.e, gi = e >> 1; const bool is_left = !(e & 1);
+        const uint32_t begin = w.g_begin[gi];
+        __syncthreads();
+        for (int k = tid; k < 5 * DV_COLS; k += DV_T) { (&s_acc[0][0])[k] = 0ull; (&s_tq[0][0])[k] = 0u; }
+        if (tid == 0) { s_minc = 0; s_exotic = 0; }
+        SidePrep sp; sp.out = rec.out; sp.nv = rec.nv; sp.len = (int)(rec.len_mode & 0xFFFFu); sp.left_mode = (rec.len_mode >> 16) & 1u;
+        sp.voters = is_left ? w.pl : w.pu; sp.vld = is_left ? w.pr : w.members;      // side_prepare's scratch
+        sp.ref = nullptr; sp.ref_len = 0;
+        {
+            const gce_core ok = b.core[sp.out];                                        // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
+            if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {
+                const uint8_t *rd = p.ref_data[ok.tid];
+                const int64_t need_len = (int64_t)d_ref_offset(b.cigar + b.cigar_off[sp.out], ok.n_cigar, sp.len - 1) + 1;
+                if (rd && (int64_t)ok.pos + need_len < p.ref_len[ok.tid]) { sp.ref = rd; sp.ref_len = p.ref_len[ok.tid]; }
+            }
+        }
+        uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
+        const int len = sp.len;
+        // ---- votes
+        for (uint32_t qb = 0; qb < sp.nv; qb += DV_CHUNK) {
+            __syncthreads();
+            if (qb + tid < sp.nv) {
+                const uint32_t r = sp.voters[begin + qb + tid];
+                DVoter v; v.so = b.seq_off[r]; v.qo = b.qual_off[r]; v.rl = b.core[r].l_qseq; v.ld = (int)sp.vld[begin + qb + tid]; v.patch = w.spatch[r]; v.pad = 0;
+                s_v[tid] = v;
+            }
+            __syncthreads();
+            const int lim = (int)min((uint32_t)DV_CHUNK, sp.nv - qb);
+            for (int cb = 0; cb < len; cb += 256) {
+                const int c0 = cb + 4 * lane;
+                for (int q0 = wv; q0 < lim; q0 += (DV_T / 64) * DV_UNROLL) {
+                    uint32_t q4[DV_UNROLL], s4[DV_UNROLL], sc4[DV_UNROLL]; int rp0[DV_UNROLL]; bool on[DV_UNROLL], bytewise[DV_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < DV_UNROLL; u++) {
+                        const int q = q0 + u * (DV_T / 64);
+                        on[u] = q < lim && c0 < len; bytewise[u] = false; q4[u] = s4[u] = sc4[u] = 0; rp0[u] = 0;
+                        if (on[u]) {
+                            const DVoter v = s_v[q];
+                            rp0[u] = sp.left_mode ? c0 : c0 + v.ld;
+                            if (rp0[u] + 4 <= 0 || rp0[u] >= v.rl) on[u] = false;        // no column of this lane meets the read
+                            else if (rp0[u] < 0) bytewise[u] = true;                     // (the first lane of a shorter right-aligned voter)
+                            else {
+                                q4[u] = *(const u32_unaligned *)(b.qual + v.qo + rp0[u]);
+                                s4[u] = *(const u32_unaligned *)(b.seq + v.so + (rp0[u] >> 1));
+                                const uint32_t pt = v.patch;
+                                if (pt != GCE_PATCH_CONST && pt != 0u && rp0[u] < (int)((pt & 0xFFFF) + (pt >> 16)) && rp0[u] + 4 > (int)(pt & 0xFFFF))
+                                    sc4[u] = *(const u32_unaligned *)((const uint8_t *)w.score + v.qo + rp0[u]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < DV_UNROLL; u++) {
+                        if (!on[u]) continue;
+                        const int q = q0 + u * (DV_T / 64);
+                        const DVoter v = s_v[q];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int col = c0 + j, rp = rp0[u] + j;
+                            if (col >= len || rp < 0 || rp >= v.rl) continue;            // outside the voter: UB in the reference, skipped (as the oracle)
+                            int nib, qu, sc;
+                            if (bytewise[u]) {
+                                nib = d_nib(b.seq + v.so, rp); qu = b.qual[v.qo + rp];
+                                sc = d_score_at(p, w.score + v.qo, v.patch, rp, qu);
+                            } else {
+                                const int ni = (rp0[u] & 1) + j;                          // nibble index inside the loaded word (high nibble first)
+                                const uint32_t by = (s4[u] >> (8 * (ni >> 1))) & 0xFFu;
+                                nib = (ni & 1) ? (int)(by & 0xF) : (int)(by >> 4);
+                                qu = (int)((q4[u] >> (8 * j)) & 0xFFu);
+                                if (v.patch == GCE_PATCH_CONST) sc = p.s_moderate;
+                                else if ((unsigned)(rp - (int)(v.patch & 0xFFFF)) < (v.patch >> 16)) sc = (int)((sc4[u] >> (8 * j)) & 0xFFu) - p.score_bias;
+                                else sc = d_qual2score(p, qu);
+                            }
+                            const int k = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : -1;
+                            if (k < 0 || qu >= 128) { s_exotic = 1; continue; }
+                            const int sl = dv_slot(col);
+                            atomicAdd(&s_acc[k][sl], 1ull | ((unsigned long long)(unsigned)(sc + p.score_bias) << 16) | ((unsigned long long)(unsigned)qu << 40));
+                            atomicMax(&s_tq[k][sl], (uint32_t)qu);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_exotic) continue;                                                    // nothing written yet: k_consensus_slow redoes the side
+        // ---- a lane per column decides
+        const uint32_t out = sp.out;
+        const gce_core ok = b.core[out];
+        const uint32_t *ocig = b.cigar + b.cigar_off[out];
+        uint8_t *oseq = b.seq + b.seq_off[out], *oqual = b.qual + b.qual_off[out];
+        int minc = 0;
+        for (int col = tid; col < len; col += DV_T) {
+            const int sl = dv_slot(col);
+            Tally5 t; t.total = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const unsigned long long a = s_acc[k][sl];
+                t.cnt[k] = (int)(a & 0xFFFFull); t.ss[k] = (int)((a >> 16) & 0xFFFFFFull) - t.cnt[k] * p.score_bias; t.qs[k] = (int)(a >> 40);
+                t.tq[k] = (int)s_tq[k][sl];
+                t.total += t.ss[k];
+            }
+            int ref4 = 0;
+            if (sp.ref) {
+                const int ro = d_ref_offset(ocig, ok.n_cigar, col);
+                if (ro >= 0 && (int64_t)ok.pos + ro < sp.ref_len) ref4 = d_ref_nib(sp.ref, (int64_t)ok.pos + ro);
+            }
+            const int ob = d_nib(oseq, col);
+            const ColOut r = decide_column(t, p, ob, ref4);
+            s_nb[col] = (uint8_t)r.base; s_nq[col] = (uint8_t)r.qual;
+            minc += r.minc;
+        }
+        if (minc) atomicAdd(&s_minc, minc);
+        __syncthreads();
+        minc = s_minc;
+        bool restore = false;
+        if (minc != 0) {                                                           // group.cpp:528-573
+            if (b.nm_type[out] == 0) { if (tid == 0) raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
+            else if (minc > 5) restore = true;
+            else if (tid == 0) { const int nn = b.nm[out] + minc; if (b.nm_type[out] == 'C' && nn >= 0 && nn <= 255) w.rp_nm[e] = nn; }
+        }
+        if (!restore) {
+            for (int bi = tid; bi < (len + 1) / 2; bi += DV_T) {
+                const int c0 = 2 * bi, c1 = c0 + 1;
+                const uint8_t old = oseq[bi];
+                oseq[bi] = (uint8_t)((s_nb[c0] << 4) | (c1 < len ? s_nb[c1] : (old & 0xF)));
+            }
+            for (int col = tid; col < len; col += DV_T) oqual[col] = s_nq[col];
+        }
+        if (tid == 0) { rp_out[gi] = out; w.gen_flag[e] = DV_DONE; }
+    }
+}
+
+// ===================================================================================================== deep clusters: pairing + UMI grouping
+// One BLOCK per cluster of 65..PD_MAX reads (the generic path ranks its reads by an O(n^2 / 64) scan on a few waves and counts
+// identical UMIs pair against pair: 15 ms of the 36 ms of configs[4]).  Everything lives in LDS:
+//   1. reads ordered by (qname, input index) -- std::map<string, Pair*> order plus arrival order (cluster.cpp:260-273): a bitonic
+//      sort of a u16 permutation; the comparator looks at 16 name bytes behind the cluster's common prefix (two big-endian words per
+//      read), equal windows (mates, as a rule) fall back to strcmp and the read index
+//   2. pairs: first read of a name run = left, last of the run (if any other) = right (pair.cpp:188-216), UMI agreement checked
+//   3. UMI grouping (cluster.cpp:57-100): pairs sorted by their UMI words -> runs = distinct UMIs with their counts (umiCount);
+//      the greedy loop (top count, lexicographically first on ties; absorb everything within the threshold) then runs over the
+//      DISTINCT UMIs on one wave -- a few hundred entries, not thousands of pairs; umiDiff (cluster.cpp:41-53) is the number of
+//      non-zero bytes of the XOR of the zero-padded words
+//   4. layout: pairs sorted by (group, qname order) -> gpl / gpr, grp_begin / grp_n
+// Clusters it cannot take (UMIs > 16 bytes, > PD_MAX reads) go to pq_list for the generic kernels.
+#define PD_T 1024
+#define PD_MAX 4096
+#define PD_NONE16 0xFFFFu
+
+// ascending bitonic sort of P (a power of two >= 128) entries.  Strides <= 64 stay inside one wave's 128-entry segment (thread t
+// handles the pair (i, i + j) with i = 2 * (t & ~(j - 1)) | (t & (j - 1))), so only the strides >= 128 need a block barrier.
+// strcmp of two strings of known lengths, 8 bytes at a time (big-endian words compare like the bytes)
+__device__ __forceinline__ int pd_rest_cmp(const char *a, int la, const char *c, int lc) {
+    for (int o = 0; o < la || o < lc; o += 8) {
+        uint64_t x[1], y[1];
+        load_be_words<1>(a + o, max(la - o, 0), x); load_be_words<1>(c + o, max(lc - o, 0), y);
+        if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    }
+    return 0;
+}
+template <typename T, typename Less>
+__device__ __forceinline__ void pd_bitonic(T *perm, int P, int tid, Less less) {
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += PD_T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                const bool up = (i & k) == 0;
+                const T a = perm[i], c = perm[l];
+                const bool swap = up ? less(c, a) : less(a, c);
+                if (swap) { perm[i] = c; perm[l] = a; }
+            }
+            if (j > 64 || j == 1 && (k << 1) > 128) __syncthreads(); else WAVE_SYNC();
+        }
+}
+// exclusive prefix over the block of one value per thread (+ total), s_w: 16 words of scratch
+__device__ __forceinline__ uint32_t pd_scan(uint32_t v, uint32_t *s_w, int tid, uint32_t &total) {
+    const int lane = tid & 63, wv = tid >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0; total = 0;
+    for (int k = 0; k < PD_T / 64; k++) { const uint32_t x = s_w[k]; if (k < wv) base += x; total += x; }
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, Work w) {
+    __shared__ uint64_t s_key[PD_MAX][2];        // name windows of the reads, then UMI words of the pairs, then (u32) layout keys
+    __shared__ uint16_t s_perm[PD_MAX];
+    __shared__ uint16_t s_pl[PD_MAX], s_pr[PD_MAX];       // member index of the left / right read of pair i (qname order)
+    __shared__ uint16_t s_pd[PD_MAX];            // pair -> distinct UMI, then pair -> group
+    __shared__ uint32_t s_x[2 * PD_MAX + PD_MAX / 2];   // steps 1-2: read index and name pointer offset of every member; step 3: the distinct-UMI tables
+    __shared__ uint32_t s_w[PD_T / 64];
+    __shared__ uint8_t s_rest[PD_MAX];           // name bytes behind the window
+    __shared__ int s_cp, s_flag, s_ngroups;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_list = w.si->n_slow_pair;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t c = w.slow_list[li];
+        const uint32_t start = w.cl_start[c], n = w.cl_n[c];
+        __syncthreads();
+        if (tid == 0) { s_cp = 0x7FFFFFFF; s_flag = 0; }
+        __syncthreads();
+        bool take = n > 64 && n <= PD_MAX;
+        if (take) {
+            int bad = 0;
+            const uint64_t q0 = b.qname_off[w.members[start]];
+            for (uint32_t i = tid; i < n; i += PD_T) {
+                const uint32_t m = w.members[start + i];
+                const int64_t dq = (int64_t)(b.qname_off[m] - q0);
+                if (w.umi_len[m] > 16 || dq > 0x7FFF0000ll || dq < -0x7FFF0000ll) bad = 1;
+            }
+            if (bad) s_flag = 1;
+        }
+        __syncthreads();
+        if (!take || s_flag) { if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }
+        const uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
+        if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } continue; }
+        const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
+        uint32_t *s_rd = s_x; uint32_t *s_qo = s_x + PD_MAX;
+        uint16_t *s_dfirst = reinterpret_cast<uint16_t *>(s_x), *s_dcnt = s_dfirst + PD_MAX, *s_dgrp = s_dcnt + PD_MAX;
+        // ---- 1. name windows + sort
+        {
+            const char *n0 = d_qname(b, w.members[start]);
+            const int l0 = (int)b.core[w.members[start]].l_qname - 1;
+            int cp = 0x7FFFFFFF;
+            for (uint32_t i = tid; i < n; i += PD_T) {
+                const uint32_t m = w.members[start + i];
+                const char *mq = d_qname(b, m);
+                const int lim = min(l0, (int)b.core[m].l_qname - 1);
+                int l = 0;
+                while (l + 8 <= lim) {                                               // 8 bytes at a time, then the first differing byte
+                    const uint64_t x = *(const u64_unaligned *)(n0 + l) ^ *(const u64_unaligned *)(mq + l);
+                    if (x) { l += (__ffsll((long long)x) - 1) >> 3; break; }
+                    l += 8;
+                }
+                if (l + 8 > lim) while (l < lim && n0[l] == mq[l]) l++;
+                cp = min(cp, l);
+            }
+            cp = wave_min(cp);
+            if (lane == 0) atomicMin(&s_cp, cp);
+        }
+        __syncthreads();
+        const int cp = s_cp;
+        const char *qbase = b.qname + b.qname_off[w.members[start]];                 // name pointers of a cluster as 32-bit distances from here
+        int P = 128; while (P < (int)n) P <<= 1;
+        for (int i = tid; i < P; i += PD_T) {
+            if (i < (int)n) {
+                const uint32_t my = w.members[start + i];
+                const int nl = (int)b.core[my].l_qname - 1;
+                uint64_t k2[2];
+                load_be_words<2>(d_qname(b, my) + cp, max(nl - cp, 0), k2);
+                s_key[i][0] = k2[0]; s_key[i][1] = k2[1];
+                s_perm[i] = (uint16_t)i;
+                s_rd[i] = my; s_rest[i] = (uint8_t)max(nl - cp - 16, 0); s_qo[i] = (uint32_t)(int32_t)((d_qname(b, my) + min(cp + 16, nl)) - qbase);      // where the window ends (checked above: fits)
+            } else s_perm[i] = PD_NONE16;
+        }
+        __syncthreads();
+        auto name_less = [&](uint16_t a, uint16_t c2) -> bool {
+            if (c2 == PD_NONE16) return a != PD_NONE16;
+            if (a == PD_NONE16) return false;
+            const uint64_t a0 = s_key[a][0], c0 = s_key[c2][0];
+            if (a0 != c0) return a0 < c0;
+            const uint64_t a1 = s_key[a][1], c1 = s_key[c2][1];
+            if (a1 != c1) return a1 < c1;
+            const int cmp = pd_rest_cmp(qbase + (int32_t)s_qo[a], (int)s_rest[a], qbase + (int32_t)s_qo[c2], (int)s_rest[c2]);        // the rest of the two names
+            return cmp < 0 || (cmp == 0 && s_rd[a] < s_rd[c2]);
+        };
+        pd_bitonic(s_perm, P, tid, name_less);
+        // ---- 2. pairs
+        const int per = (P + PD_T - 1) / PD_T;                                     // sorted positions per thread (contiguous)
+        uint32_t firsts = 0;
+        bool isf[PD_MAX / PD_T], isl[PD_MAX / PD_T];
+        int any_umi = 0;
+        for (int u = 0; u < per; u++) {
+            const int sidx = tid * per + u;
+            isf[u] = isl[u] = false;
+            if (sidx < (int)n) {
+                const uint16_t m = s_perm[sidx];
+                const uint32_t q = s_rd[m];
+                auto same = [&](uint16_t o) {
+                    if (s_key[o][0] != s_key[m][0] || s_key[o][1] != s_key[m][1]) return false;
+                    return pd_rest_cmp(qbase + (int32_t)s_qo[o], (int)s_rest[o], qbase + (int32_t)s_qo[m], (int)s_rest[m]) == 0;
+                };
+                isf[u] = sidx == 0 || !same(s_perm[sidx - 1]);
+                isl[u] = sidx == (int)n - 1 || !same(s_perm[sidx + 1]);
+                if (!isf[u]) {                                                     // setRight: UMI of the pair so far vs this read's (pair.cpp:201-212)
+                    const uint32_t pv = s_rd[s_perm[sidx - 1]];
+                    const int lp = w.umi_len[pv], lq = w.umi_len[q];
+                    if (lp != 0) {
+                        uint64_t x[2], y[2];
+                        load_be_words<2>(w.umi_ptr[pv], lp, x); load_be_words<2>(w.umi_ptr[q], lq, y);     // (<= 16 bytes: checked above)
+                        if (lp != lq || x[0] != y[0] || x[1] != y[1]) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
+                    }
+                }
+                if (isl[u] && w.umi_len[q]) any_umi = 1;
+                firsts += isf[u];
+            }
+        }
+        uint32_t npairs;
+        uint32_t pbase = pd_scan(firsts, s_w, tid, npairs);
+        if (any_umi) s_flag = 1;                                                   // (s_flag is 0 here)
+        {
+            uint32_t pi = pbase;
+            // a run may straddle threads: the pair index of a non-first read is (firsts up to and including it) - 1
+            for (int u = 0; u < per; u++) {
+                const int sidx = tid * per + u;
+                if (sidx < (int)n) {
+                    if (isf[u]) pi++;
+                    const uint32_t pidx = pi - 1;
+                    const uint16_t m = s_perm[sidx];
+                    if (isf[u]) { s_pl[pidx] = m; if (isl[u]) s_pr[pidx] = PD_NONE16; }
+                    if (isl[u] && !isf[u]) s_pr[pidx] = m;
+                }
+            }
+        }
+        __syncthreads();
+        any_umi = s_flag;
+        __syncthreads();
+        // ---- 3. UMI grouping
+        uint32_t ngroups = 1;
+        if (!any_umi) { for (uint32_t i = tid; i < npairs; i += PD_T) s_pd[i] = 0; }
+        else {
+            int P2 = 128; while (P2 < (int)npairs) P2 <<= 1;
+            for (int i = tid; i < P2; i += PD_T) {
+                if (i < (int)npairs) {
+                    const uint16_t m = s_pr[i] != PD_NONE16 ? s_pr[i] : s_pl[i];   // the pair's UMI is its last read's (pair.cpp:188-216)
+                    const uint32_t ui = w.members[start + m];
+                    uint64_t k2[2];
+                    load_be_words<2>(w.umi_ptr[ui], (int)w.umi_len[ui], k2);
+                    s_key[i][0] = k2[0]; s_key[i][1] = k2[1];
+                    s_perm[i] = (uint16_t)i;
+                } else s_perm[i] = PD_NONE16;
+            }
+            __syncthreads();
+            auto umi_less = [&](uint16_t a, uint16_t c2) -> bool {
+                if (c2 == PD_NONE16) return a != PD_NONE16;
+                if (a == PD_NONE16) return false;
+                const uint64_t a0 = s_key[a][0], c0 = s_key[c2][0];
+                if (a0 != c0) return a0 < c0;
+                const uint64_t a1 = s_key[a][1], c1 = s_key[c2][1];
+                if (a1 != c1) return a1 < c1;
+                return a < c2;
+            };
+            pd_bitonic(s_perm, P2, tid, umi_less);
+            const int per2 = (P2 + PD_T - 1) / PD_T;
+            uint32_t heads = 0;
+            for (int u = 0; u < per2; u++) {
+                const int sidx = tid * per2 + u;
+                if (sidx < (int)npairs) {
+                    const uint16_t m = s_perm[sidx];
+                    const bool head = sidx == 0 || s_key[s_perm[sidx - 1]][0] != s_key[m][0] || s_key[s_perm[sidx - 1]][1] != s_key[m][1];
+                    isf[u] = head; heads += head;
+                }
+            }
+            uint32_t D;
+            const uint32_t dbase = pd_scan(heads, s_w, tid, D);
+            {
+                uint32_t di = dbase;
+                for (int u = 0; u < per2; u++) {
+                    const int sidx = tid * per2 + u;
+                    if (sidx < (int)npairs) {
+                        if (isf[u]) { di++; s_dfirst[di - 1] = s_perm[sidx]; s_dcnt[di - 1] = (uint16_t)sidx; s_dgrp[di - 1] = PD_NONE16; }   // dcnt: start for now
+                        s_pd[s_perm[sidx]] = (uint16_t)(di - 1);
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t d = tid; d < D; d += PD_T) {                             // run length = next start - own start
+                const uint32_t nxt = d + 1 < D ? s_dcnt[d + 1] : npairs;
+                s_dgrp[d] = (uint16_t)(nxt - s_dcnt[d]);                          // (parked in dgrp until every start was read)
+            }
+            __syncthreads();
+            for (uint32_t d = tid; d < D; d += PD_T) { s_dcnt[d] = s_dgrp[d]; }
+            __syncthreads();
+            for (uint32_t d = tid; d < D; d += PD_T) s_dgrp[d] = PD_NONE16;
+            __syncthreads();
+            // the greedy loop over the DISTINCT UMIs.  Candidates in the order the reference would pick them if nothing were absorbed:
+            // count descending, then UMI ascending (= distinct index ascending) -- one more sort, of (0xFFFF - count) << 16 | index
+            uint32_t *ord = s_x + PD_MAX + PD_MAX / 2;                                       // behind the three u16 tables (3 x PD_MAX x 2 bytes); PD_MAX words
+            int P4 = 128; while (P4 < (int)D) P4 <<= 1;
+            for (int i = tid; i < P4; i += PD_T) ord[i] = i < (int)D ? ((0xFFFFu - (uint32_t)s_dcnt[i]) << 16 | (uint32_t)i) : 0xFFFFFFFFu;
+            __syncthreads();
+            pd_bitonic(ord, P4, tid, [](uint32_t x, uint32_t y) { return x < y; });
+            if (thr <= 0) {                                                        // nothing but the UMI itself is within 0: groups = candidates in order
+                for (uint32_t r = tid; r < D; r += PD_T) s_dgrp[ord[r] & 0xFFFFu] = (uint16_t)r;
+                if (tid == 0) s_ngroups = (int)D;
+            } else {
+                uint32_t ptr = 0, ng = 0;
+                for (;;) {
+                    while (ptr < D && s_dgrp[ord[ptr] & 0xFFFFu] != PD_NONE16) ptr++;      // (every thread walks the same way)
+                    if (ptr >= D) break;
+                    const uint32_t top = ord[ptr] & 0xFFFFu;
+                    const uint64_t t0 = s_key[s_dfirst[top]][0], t1 = s_key[s_dfirst[top]][1];
+                    __syncthreads();                                               // everybody has read the state of this round
+                    for (uint32_t d = tid; d < D; d += PD_T) {
+                        if (s_dgrp[d] != PD_NONE16) continue;
+                        const uint64_t a0 = s_key[s_dfirst[d]][0], a1 = s_key[s_dfirst[d]][1];
+                        if (popc_nonzero_bytes(a0 ^ t0) + popc_nonzero_bytes(a1 ^ t1) <= thr) s_dgrp[d] = (uint16_t)ng;
+                    }
+                    ng++;
+                    __syncthreads();
+                }
+                if (tid == 0) s_ngroups = (int)ng;
+            }
+            __syncthreads();
+            ngroups = (uint32_t)s_ngroups;
+            for (uint32_t i = tid; i < npairs; i += PD_T) s_pd[i] = s_dgrp[s_pd[i]];
+        }
+        __syncthreads();
+        // ---- 4. layout: group by group, qname order kept inside a group (Group::addPair, group.cpp:17-22)
+        {
+            int P3 = 128; while (P3 < (int)npairs) P3 <<= 1;
+            uint32_t *lk = reinterpret_cast<uint32_t *>(&s_key[0][0]);
+            for (int i = tid; i < P3; i += PD_T) { lk[i] = i < (int)npairs ? ((uint32_t)s_pd[i] << 16 | (uint32_t)i) : 0xFFFFFFFFu; }
+            __syncthreads();
+            pd_bitonic(lk, P3, tid, [](uint32_t a, uint32_t c2) { return a < c2; });
+            for (uint32_t sidx = tid; sidx < npairs; sidx += PD_T) {
+                const uint32_t key = lk[sidx], g = key >> 16, i = key & 0xFFFFu;
+                w.gpl[start + sidx] = w.members[start + s_pl[i]];
+                w.gpr[start + sidx] = s_pr[i] != PD_NONE16 ? w.members[start + s_pr[i]] : NONE32;
+                const bool head = sidx == 0 || (lk[sidx - 1] >> 16) != g;
+                if (head) {
+                    w.grp_begin[start + g] = start + sidx;
+                    uint32_t e2 = sidx + 1;                                       // group sizes: walk to the end of the run (heads are few)
+                    while (e2 < npairs && (lk[e2] >> 16) == g) e2++;
+                    w.grp_n[start + g] = e2 - sidx;
+                }
+            }
+        }
+        if (tid == 0) {
+            const bool cross = d_key(b.core[w.members[start]], p).right < 0;
+            w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0));
+        }
+    }
+}

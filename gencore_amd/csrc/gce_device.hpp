@@ -77,7 +77,9 @@ struct StreamInfo {
     int n_events;                        // E: flush events inside this slice
     int n_events_a;                      // E_A: events whose read index < U
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
+    unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
+    unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
     unsigned int pad0, pad1;
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     unsigned long long n_pairs_total;    // pairs over all processed clusters

@@ -51,6 +51,7 @@ struct Work {
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint8_t *pf_flag; uint32_t *pf_list;      // clusters the half-wave pairing kernel hands to the full-wave one (same scheme)
     uint8_t *pq_flag; uint32_t *pq_list;      // ... and the quarter-wave kernel to the half-wave one
+    void *deep_list;                       // DeepRec[] (gce_deep.hpp)
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
                                           // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
     uint8_t *slot_flag;                   // pair slots of the groups whose sides were handed on (k_score2 scores only those)
@@ -744,9 +745,9 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
 template <int PHASE>
 __global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, Work w) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t n_slow = w.si->n_slow_pair;
+    const uint32_t n_slow = w.si->n_slow_pair2;                                      // what k_pairing_deep (gce_deep.hpp) left over
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
-        pairing_generic<PHASE>(b, p, w, w.slow_list[idx], lane, blockIdx.y, gridDim.y);
+        pairing_generic<PHASE>(b, p, w, w.pq_list[idx], lane, blockIdx.y, gridDim.y);
         WAVE_SYNC();
     }
 }
@@ -1155,42 +1156,16 @@ __device__ inline ColResult vote_column(const VoteCtx &v, int col, int out_base,
     return res;
 }
 
-// Group::consensusMergeBam for one side (group.cpp:136-318).  Returns the template read or NONE32.
 // Scratch (cluster-local arrays that are dead after k_pairing): left side uses sorted/pl/pr, right side pg/pu/members
 // for containedBy / voters / lenDiff (the two sides of a group may run concurrently on different waves).
-__device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left,
-                                   uint32_t *tally, int lane, int32_t *nm_slot) {
+struct SidePrep {                       // what Group::consensusMergeBam hands to makeConsensus (group.cpp:268-315)
+    uint32_t out, nv; bool left_mode; int len; const uint8_t *ref; int64_t ref_len;
+    const uint32_t *voters, *vld;       // cluster-local scratch: voter reads (template first) and their lenDiff, at [begin, begin + nv)
+};
+// template pick + voter list of one group side (wave-level).  prep.out == NONE32: the side yields no read.
+__device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left, int lane) {
+    SidePrep sp; sp.out = NONE32; sp.nv = 0; sp.left_mode = is_left; sp.len = 0; sp.ref = nullptr; sp.ref_len = 0; sp.voters = nullptr; sp.vld = nullptr;
     const uint32_t *side = is_left ? w.gpl : w.gpr;
-    // ---- low-complexity skip for very deep groups (group.cpp:142-175)
-    if ((int)np > p.skip_low_complexity_thr) {
-        int distinct = 0; uint32_t first = NONE32;
-        for (uint32_t base = 0; base < np; base += 64) {
-            uint32_t k = base + lane;
-            bool uniq = false; uint32_t rd = NONE32;
-            if (k < np && (rd = side[begin + k]) != NONE32) {
-                uniq = true;
-                int nc = b.core[rd].n_cigar; const uint32_t *cg = b.cigar + b.cigar_off[rd];
-                for (uint32_t j = 0; j < k && uniq; j++) {
-                    uint32_t o = side[begin + j];
-                    if (o == NONE32 || b.core[o].n_cigar != nc) continue;
-                    const uint32_t *og = b.cigar + b.cigar_off[o];
-                    bool same = true;
-                    for (int x = 0; x < nc; x++) same &= (og[x] == cg[x]);
-                    if (same) uniq = false;
-                }
-            }
-            unsigned long long has = __ballot(rd != NONE32);
-            if (first == NONE32 && has) first = side[begin + base + (__ffsll((long long)has) - 1)];
-            distinct += __popcll(__ballot(uniq));
-        }
-        if ((double)distinct > (double)np * 0.1 && first != NONE32) {
-            int n = b.core[first].l_qseq, dn = 0;
-            const uint8_t *s = b.seq + b.seq_off[first];
-            for (int i = lane; i < n - 1; i += 64) dn += d_base_class(d_nib(s, i)) != d_base_class(d_nib(s, i + 1));
-            dn = wave_sum(dn);
-            if ((double)dn < (double)n * 0.5) return NONE32;
-        }
-    }
     // ---- leftReadMode (group.cpp:177-194)
     bool left_mode = is_left;
     if (!is_left) {
@@ -1206,7 +1181,8 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
     // isPartOf, so containedBy(read) = sum over classes of |class| x [read is part of the class] -- O(reads x classes) on
     // registers instead of O(reads^2) walks through memory.  One class per lane (<= 64), CIGARs of <= 4 ops; anything else
     // takes the pairwise loop below.
-    bool classed = false;
+    bool classed = false, lowc_done = false;
+    uint32_t first_read = NONE32;                  // firstRead of group.cpp:145-160: the side's first present read
     if (np > 64) {
         int c_n = 0, c_cnt = 0, c_rr = 0; uint32_t c_w0 = 0, c_w1 = 0, c_w2 = 0, c_w3 = 0;      // lane c = class c
         int nclass = 0; bool fail = false;
@@ -1230,6 +1206,7 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
             load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
             if (__any(has && n_ > 4)) { fail = true; break; }
             const unsigned long long hm = __ballot(has);
+            if (first_read == NONE32 && hm) first_read = side[begin + base + (__ffsll((long long)hm) - 1)];
             for (unsigned long long m = hm; m; m &= m - 1) {
                 const int t = __ffsll((long long)m) - 1;
                 const int r_n = rl32(n_, t), r_rr = rl32(rr_, t);
@@ -1241,6 +1218,25 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
                     if (lane == nclass) { c_n = r_n; c_rr = r_rr; c_w0 = r0; c_w1 = r1; c_w2 = r2; c_w3 = r3; c_cnt = 1; }
                     nclass++;
                 }
+            }
+        }
+        // ---- low-complexity skip for very deep groups (group.cpp:142-175), from the classes: distinct CIGAR strings = classes whose
+        //      words differ from every earlier class (a right side keys its classes by right end as well)
+        if (!fail && (int)np > p.skip_low_complexity_thr) {
+            bool dup = false;
+            for (int cc = 0; cc < nclass; cc++) {
+                const int q_n = rl32(c_n, cc);
+                const uint32_t q0 = (uint32_t)rl32((int)c_w0, cc), q1 = (uint32_t)rl32((int)c_w1, cc), q2 = (uint32_t)rl32((int)c_w2, cc), q3 = (uint32_t)rl32((int)c_w3, cc);
+                if (lane > cc && lane < nclass && c_n == q_n && c_w0 == q0 && c_w1 == q1 && c_w2 == q2 && c_w3 == q3) dup = true;
+            }
+            const int distinct = __popcll(__ballot(lane < nclass && !dup));
+            lowc_done = true;
+            if ((double)distinct > (double)np * 0.1 && first_read != NONE32) {
+                int n = b.core[first_read].l_qseq, dn = 0;
+                const uint8_t *s = b.seq + b.seq_off[first_read];
+                for (int i = lane; i < n - 1; i += 64) dn += d_base_class(d_nib(s, i)) != d_base_class(d_nib(s, i + 1));
+                dn = wave_sum(dn);
+                if ((double)dn < (double)n * 0.5) return sp;
             }
         }
         if (!fail) {
@@ -1273,6 +1269,36 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
                 if (base + lane < np) contained[begin + base + lane] = has ? cb : 0;
             }
             classed = true;
+        }
+    }
+    // ---- low-complexity skip for very deep groups (group.cpp:142-175)
+    if (!lowc_done && (int)np > p.skip_low_complexity_thr) {     // (> 64 classes or CIGARs of > 4 ops: pairwise)
+        int distinct = 0; uint32_t first = NONE32;
+        for (uint32_t base = 0; base < np; base += 64) {
+            uint32_t k = base + lane;
+            bool uniq = false; uint32_t rd = NONE32;
+            if (k < np && (rd = side[begin + k]) != NONE32) {
+                uniq = true;
+                int nc = b.core[rd].n_cigar; const uint32_t *cg = b.cigar + b.cigar_off[rd];
+                for (uint32_t j = 0; j < k && uniq; j++) {
+                    uint32_t o = side[begin + j];
+                    if (o == NONE32 || b.core[o].n_cigar != nc) continue;
+                    const uint32_t *og = b.cigar + b.cigar_off[o];
+                    bool same = true;
+                    for (int x = 0; x < nc; x++) same &= (og[x] == cg[x]);
+                    if (same) uniq = false;
+                }
+            }
+            unsigned long long has = __ballot(rd != NONE32);
+            if (first == NONE32 && has) first = side[begin + base + (__ffsll((long long)has) - 1)];
+            distinct += __popcll(__ballot(uniq));
+        }
+        if ((double)distinct > (double)np * 0.1 && first != NONE32) {
+            int n = b.core[first].l_qseq, dn = 0;
+            const uint8_t *s = b.seq + b.seq_off[first];
+            for (int i = lane; i < n - 1; i += 64) dn += d_base_class(d_nib(s, i)) != d_base_class(d_nib(s, i + 1));
+            dn = wave_sum(dn);
+            if ((double)dn < (double)n * 0.5) return sp;
         }
     }
     if (!classed)
@@ -1322,9 +1348,9 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         bool better = best == NONE32 || oc > bc || (oc == bc && (ol < blen || (ol == blen && ob < best)));
         if (better) { best = ob; bc = oc; blen = ol; }
     }
-    if ((double)bc < (double)np * 0.4 && np != 1) return NONE32;            // group.cpp:264-266
+    if ((double)bc < (double)np * 0.4 && np != 1) return sp;            // group.cpp:264-266
     uint32_t out = side[begin + best];
-    if (out == NONE32) return NONE32;                                        // group.cpp:283-285
+    if (out == NONE32) return sp;                                        // group.cpp:283-285
     gce_core ok = b.core[out];
     const uint32_t *ocig = b.cigar + b.cigar_off[out];
     // ---- voters: template + every read the template is part of (group.cpp:287-313); lenDiff (group.cpp:339-348)
@@ -1355,14 +1381,27 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
         for (uint32_t q = lane; q < nv; q += 64) mn = min(mn, b.core[voters[begin + q]].l_qseq);
         len = wave_min(mn);
     }
-    VoteCtx v;
-    v.b = &b; v.p = &p; v.w = &w; v.out = out; v.nv = nv; v.vbase = begin; v.left_mode = left_mode; v.len = len;
-    v.ref = nullptr; v.ref_len = 0; v.ocig = ocig; v.oncig = ok.n_cigar; v.opos = ok.pos; v.tally = tally; v.voters = voters; v.vld = vld;
+    sp.out = out; sp.nv = nv; sp.left_mode = left_mode; sp.len = len; sp.voters = voters; sp.vld = vld;
     if (ok.isize != 0 && ok.tid >= 0 && ok.tid < p.n_ref) {                  // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
         const uint8_t *rd = p.ref_data[ok.tid];
         int64_t need_len = (int64_t)d_ref_offset(ocig, ok.n_cigar, len - 1) + 1;
-        if (rd && (int64_t)ok.pos + need_len < p.ref_len[ok.tid]) { v.ref = rd; v.ref_len = p.ref_len[ok.tid]; }
+        if (rd && (int64_t)ok.pos + need_len < p.ref_len[ok.tid]) { sp.ref = rd; sp.ref_len = p.ref_len[ok.tid]; }
     }
+    return sp;
+}
+
+// Group::consensusMergeBam for one side (group.cpp:136-318), wave-level: side_prepare + the column votes.  Returns the template
+// read or NONE32.
+__device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const Work &w, uint32_t begin, uint32_t np, bool is_left,
+                                   uint32_t *tally, int lane, int32_t *nm_slot) {
+    const SidePrep sp = side_prepare(b, p, w, begin, np, is_left, lane);
+    if (sp.out == NONE32) return NONE32;
+    const uint32_t out = sp.out, nv = sp.nv; const int len = sp.len;
+    const gce_core ok = b.core[out];
+    const uint32_t *ocig = b.cigar + b.cigar_off[out];
+    VoteCtx v;
+    v.b = &b; v.p = &p; v.w = &w; v.out = out; v.nv = nv; v.vbase = begin; v.left_mode = sp.left_mode; v.len = len;
+    v.ref = sp.ref; v.ref_len = sp.ref_len; v.ocig = ocig; v.oncig = ok.n_cigar; v.opos = ok.pos; v.tally = tally; v.voters = sp.voters; v.vld = sp.vld;
     uint8_t *oseq = b.seq + b.seq_off[out], *oqual = b.qual + b.qual_off[out];
     const int nbytes = (len + 1) >> 1;
     int minc = 0;
@@ -1447,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p,
     const uint32_t n_slow = (uint32_t)w.si->n_slow;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
         uint32_t e = w.slow_list[idx], gi = e >> 1; bool is_left = !(e & 1);
+        if (w.gen_flag[e] == 2) continue;                                       // finished by k_vote_deep (gce_deep.hpp)
         uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
         uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
         uint32_t out = side_consensus(b, p, w, begin, np, is_left, s_tally[wv], lane, w.rp_nm + e);
