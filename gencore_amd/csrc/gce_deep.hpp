@@ -113,28 +113,49 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
                         if (!on[u]) continue;
                         const int q = q0 + u * (DV_T / 64);
                         const DVoter v = s_v[q];
+                        if (bytewise[u]) {
+                            for (int j = 0; j < 4; j++) {
+                                const int col = c0 + j, rp = rp0[u] + j;
+                                if (col >= len || rp < 0 || rp >= v.rl) continue;        // outside the voter: UB in the reference, skipped (as the oracle)
+                                const int nib = d_nib(b.seq + v.so, rp), qu = b.qual[v.qo + rp];
+                                const int sc = d_score_at(p, w.score + v.qo, v.patch, rp, qu);
+                                const int k = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : -1;
+                                if (k < 0 || qu >= 128) { s_exotic = 1; continue; }
+                                const int sl = dv_slot(col);
+                                atomicAdd(&s_acc[k][sl], 1ull | ((unsigned long long)(unsigned)(sc + p.score_bias) << 16) | ((unsigned long long)(unsigned)qu << 40));
+                                atomicMax(&s_tq[k][sl], (uint32_t)qu);
+                            }
+                            continue;
+                        }
+                        // four columns at once: valid ones are j < nval (rp0 >= 0 here)
+                        const int nval = min(min(4, len - c0), v.rl - rp0[u]);
+                        const uint32_t vm = nval >= 4 ? 0xFFFFFFFFu : (1u << (8 * nval)) - 1u;
+                        if (q4[u] & 0x80808080u & vm) { s_exotic = 1; continue; }
+                        uint32_t sw = ((s4[u] & 0x0F0F0F0Fu) << 4) | ((s4[u] & 0xF0F0F0F0u) >> 4);      // nibble i of the word now at bits 4i
+                        sw >>= 4 * (rp0[u] & 1);
+                        uint32_t sb4;                                                      // biased scores
+                        if (v.patch == GCE_PATCH_CONST) sb4 = 0x01010101u * (uint32_t)(p.s_moderate + p.score_bias);
+                        else {
+                            sb4 = d_q2s4_biased(p, q4[u] & 0x7F7F7F7Fu);
+                            const int ws = (int)(v.patch & 0xFFFF), wl = (int)(v.patch >> 16);
+                            if (v.patch != 0u && rp0[u] < ws + wl && rp0[u] + 4 > ws) {
+                                uint32_t m = 0;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) if ((unsigned)(rp0[u] + j - ws) < (unsigned)wl) m |= 0xFFu << (8 * j);
+                                sb4 = (sc4[u] & m) | (sb4 & ~m);
+                            }
+                        }
+                        const int slb = ((cb >> 2) + lane) & 127;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const int col = c0 + j, rp = rp0[u] + j;
-                            if (col >= len || rp < 0 || rp >= v.rl) continue;            // outside the voter: UB in the reference, skipped (as the oracle)
-                            int nib, qu, sc;
-                            if (bytewise[u]) {
-                                nib = d_nib(b.seq + v.so, rp); qu = b.qual[v.qo + rp];
-                                sc = d_score_at(p, w.score + v.qo, v.patch, rp, qu);
-                            } else {
-                                const int ni = (rp0[u] & 1) + j;                          // nibble index inside the loaded word (high nibble first)
-                                const uint32_t by = (s4[u] >> (8 * (ni >> 1))) & 0xFFu;
-                                nib = (ni & 1) ? (int)(by & 0xF) : (int)(by >> 4);
-                                qu = (int)((q4[u] >> (8 * j)) & 0xFFu);
-                                if (v.patch == GCE_PATCH_CONST) sc = p.s_moderate;
-                                else if ((unsigned)(rp - (int)(v.patch & 0xFFFF)) < (v.patch >> 16)) sc = (int)((sc4[u] >> (8 * j)) & 0xFFu) - p.score_bias;
-                                else sc = d_qual2score(p, qu);
-                            }
-                            const int k = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : -1;
-                            if (k < 0 || qu >= 128) { s_exotic = 1; continue; }
-                            const int sl = dv_slot(col);
-                            atomicAdd(&s_acc[k][sl], 1ull | ((unsigned long long)(unsigned)(sc + p.score_bias) << 16) | ((unsigned long long)(unsigned)qu << 40));
-                            atomicMax(&s_tq[k][sl], (uint32_t)qu);
+                            if (j >= nval) continue;
+                            const uint32_t nib = (sw >> (4 * j)) & 15u;
+                            const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;       // A,C,G,T,N -> 0..4, anything else 7
+                            if (k == 7u) { s_exotic = 1; continue; }
+                            const uint32_t qu = (q4[u] >> (8 * j)) & 0xFFu, sb = (sb4 >> (8 * j)) & 0xFFu;
+                            const int sl = (j << 7) | slb;
+                            atomicAdd(&s_acc[k][sl], (unsigned long long)(1u | (sb << 16)) | ((unsigned long long)(qu << 8) << 32));
+                            atomicMax(&s_tq[k][sl], qu);
                         }
                     }
                 }

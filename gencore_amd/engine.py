@@ -47,7 +47,9 @@ class Engine:
         self._check(self.lib.gce_set_reference(self._h, tid, ptr, n_bases))
 
     def set_reference_ascii(self, tid, bases):
-        """bases: bytes / numpy uint8 of upper-cased ASCII; packed to the 4-bit code on the GPU."""
+        """bases: str / bytes / numpy uint8 of upper-cased ASCII; packed to the 4-bit code on the GPU."""
+        if isinstance(bases, str):
+            bases = bases.encode()
         a = np.frombuffer(bases, np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, np.uint8)
         self._check(self.lib.gce_set_reference_ascii(self._h, tid, a.ctypes.data, int(a.size)))
 

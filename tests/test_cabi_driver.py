@@ -52,6 +52,20 @@ def read_table(path, batch):
     return status, rows, stats
 
 
+def ascii_of(reference):
+    """(FastaReader nibbles, length) per contig -> the ASCII bases gce_set_reference_ascii takes; None = contig absent."""
+    code = np.frombuffer(b"NATCG" + b"N" * 11, np.uint8)
+    out = []
+    for nib, ln in reference or []:
+        if nib is None:
+            out.append(None)
+            continue
+        both = np.empty(len(nib) * 2, np.uint8)
+        both[0::2] = nib & 0xF; both[1::2] = nib >> 4
+        out.append(code[both[:ln]].tobytes())
+    return out
+
+
 def small_case():
     import fuzzgen
     batch, over, reference, contig_len = fuzzgen.make_case(7, n_mol=80, umi_mode="prefix", period=50)
@@ -79,13 +93,7 @@ def test_c_caller_matches_oracle(built, tmp_path, case):
         batch, over, reference, contig_len = small_case()
         tl, contigs, csr, period, prefix = list(contig_len), [], over.get("cluster_size_req", 1), over.get("flush_period", 10000), over.get("umi_prefix", "")
         ref = reference
-        ascii_contigs = []
-        if reference:
-            code = np.frombuffer(b"NATCG" + b"N" * 11, np.uint8)
-            for nib, ln in reference:
-                both = np.empty(len(nib) * 2, np.uint8)
-                both[0::2] = nib & 0xF; both[1::2] = nib >> 4
-                ascii_contigs.append(code[both[:ln]].tobytes())
+        ascii_contigs = ascii_of(reference)
         contigs = ascii_contigs
     else:
         from gencore_amd import synth
@@ -93,12 +101,7 @@ def test_c_caller_matches_oracle(built, tmp_path, case):
         batch = d.to_batch()
         tl, csr, period, prefix = list(d.target_len), d.info["supporting_reads"], 10000, d.info["umi_prefix"]
         ref = d.reference_host()
-        code = np.frombuffer(b"NATCG" + b"N" * 11, np.uint8)
-        contigs = []
-        for nib, ln in ref:
-            both = np.empty(len(nib) * 2, np.uint8)
-            both[0::2] = nib & 0xF; both[1::2] = nib >> 4
-            contigs.append(code[both[:ln]].tobytes())
+        contigs = ascii_of(ref)
     tla = np.asarray(tl, np.uint32)
     prm = default_params(n_targets=len(tla), target_len=tla.ctypes.data, umi_prefix=prefix, cluster_size_req=csr, flush_period=period)
     want = oracle_py.run(batch, prm, ref)

@@ -76,6 +76,26 @@ def test_synthetic_configs(built, name, n_pairs):
     assert len(got.emitted()) > 0
 
 
+def test_cfg5_many_deep_clusters(built):
+    """BASELINE configs[4] at 72 molecules: 72 clusters of >= 500 pairs each go through the deep-cluster kernels (gce_deep.hpp:
+    block-per-cluster pairing, block-per-side votes), and one group has 1503 pairs at the DEFAULT
+    skipLowComplexityClusterThreshold of 1000 -- the low-complexity check and the early break of group.cpp:142-175,231-232
+    run on natural data."""
+    import collections
+    batch, prm, ref = synth_case("cfg5", 90000)
+    core = batch.core
+    left = np.where(core["isize"] < 0, core["mpos"], core["pos"])
+    groups, clusters = collections.Counter(), collections.Counter()
+    for i in np.nonzero(core["flag"] & 64)[0]:
+        q = batch.qname_of(int(i))
+        key = (int(core["tid"][i]), int(left[i]), abs(int(core["isize"][i])))
+        groups[key + (q[q.rfind("UMI_") + 4:],)] += 1
+        clusters[key] += 1
+    assert sum(1 for v in clusters.values() if v >= 500) >= 50 and max(groups.values()) > 1000
+    got, want = run_both(batch, prm, ref)
+    assert len(got.emitted()) > 1000
+
+
 def test_sharded_stream_context(built):
     """tick_offset / trailing_flush (coordinate-sharded multi-GPU runs): per-contig slices reproduce the whole stream."""
     from gencore_amd.shard import shard_by_contig
