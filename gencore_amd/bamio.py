@@ -1,0 +1,93 @@
+"""Host-side file formats around the hot path, thin ctypes wrappers over gencore_amd/csrc/bamio.cpp:
+BamFile (gce_bam_open / gce_bam_chunk: a sorted BAM -> ReadBatch), write_bam (gce_bam_write), load_fasta (gce_fasta_load) and
+run_bam (gce_run_bam: BAM in -> engine -> BAM out, with the wall time of every stage).  No htslib."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .batch import ReadBatch
+from .capi import CORE_DTYPE, GceBamInfo, GceBamRun, GceBatch, GceError
+
+
+class BamFile:
+    def __init__(self, path, threads=0):
+        self.lib = capi.load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.gce_bam_open(str(path).encode(), threads, C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.gce_bam_error(self._h).decode() if self._h else ""
+            self.close()
+            raise GceError(rc, msg)
+        self.info = GceBamInfo()
+        self.lib.gce_bam_get_info(self._h, C.byref(self.info))
+        n = self.info.n_targets
+        self.target_len = [int(self.info.target_len[i]) for i in range(n)]
+        self.target_name = [self.info.target_name[i].decode() for i in range(n)]
+        self.text = C.string_at(self.info.text, self.info.l_text).decode() if self.info.l_text else ""
+        self.n_records = int(self.info.n_records)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gce_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def chunk_struct(self, first, count, slot=0):
+        b = GceBatch()
+        rc = self.lib.gce_bam_chunk(self._h, first, count, slot, C.byref(b))
+        if rc != 0:
+            raise GceError(rc, "gce_bam_chunk")
+        return b
+
+    def batch(self, first=0, count=None):
+        """Records [first, first+count) as a ReadBatch (copies out of the reader's buffers)."""
+        count = self.n_records - first if count is None else count
+        b = self.chunk_struct(first, count)
+
+        def arr(ptr, dt, n):
+            if n == 0 or not ptr:
+                return np.zeros(0, dt)
+            return np.frombuffer(C.string_at(ptr, n * np.dtype(dt).itemsize), dt).copy()
+        n = count
+        mi = bool(b.mi)
+        return ReadBatch(core=arr(b.core, CORE_DTYPE, n), qname_off=arr(b.qname_off, np.uint64, n), qname=arr(b.qname, np.uint8, b.qname_bytes),
+                         cigar_off=arr(b.cigar_off, np.uint64, n), cigar=arr(b.cigar, np.uint32, b.cigar_words),
+                         seq_off=arr(b.seq_off, np.uint64, n), seq=arr(b.seq, np.uint8, b.seq_bytes),
+                         qual_off=arr(b.qual_off, np.uint64, n), qual=arr(b.qual, np.uint8, b.qual_bytes),
+                         nm=arr(b.nm, np.int32, n), nm_type=arr(b.nm_type, np.uint8, n),
+                         mi_off=arr(b.mi_off, np.uint64, n) if mi else None, mi=arr(b.mi, np.uint8, b.mi_bytes) if mi else None)
+
+
+def load_fasta(path):
+    """{contig id: ASCII bases (bytes)} in file order, with FastaReader's quirks (src/fastareader.cpp:57-104)."""
+    lib = capi.load_library()
+    h = C.c_void_p()
+    rc = lib.gce_fasta_load(str(path).encode(), C.byref(h))
+    if rc != 0:
+        raise GceError(rc, "gce_fasta_load")
+    n = C.c_int32()
+    ids, seqs, lens = C.POINTER(C.c_char_p)(), C.POINTER(C.c_void_p)(), C.POINTER(C.c_int64)()
+    lib.gce_fasta_get(h, C.byref(n), C.byref(ids), C.byref(seqs), C.byref(lens))
+    out = {}
+    for i in range(n.value):
+        out[ids[i].decode()] = C.string_at(seqs[i], lens[i])
+    lib.gce_fasta_free(h)
+    return out
+
+
+def run_bam(in_path, out_path, params, fasta=None, threads=0, chunk_reads=1 << 21, level=6):
+    """gce_run_bam: returns the GceBamRun record (stage times, Stats blocks)."""
+    lib = capi.load_library()
+    run = GceBamRun()
+    err = (C.c_char * 256)()
+    rc = lib.gce_run_bam(str(in_path).encode(), str(out_path).encode(), str(fasta).encode() if fasta else None, C.byref(params), threads,
+                         chunk_reads, level, C.byref(run), err)
+    if rc != 0:
+        raise GceError(rc, err.value.decode(errors="replace"))
+    return run

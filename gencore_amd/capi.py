@@ -100,7 +100,23 @@ STATUS_NAMES = {
 EXPORTED_SYMBOLS = [
     "gce_params_default", "gce_detect_umi_prefix", "gce_create", "gce_destroy", "gce_set_reference", "gce_set_reference_ascii",
     "gce_pack_reference", "gce_set_flush_events", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
-    "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version"]
+    "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
+    "gce_reserve", "gce_submit_async", "gce_submit_wait",
+    "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write",
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam"]
+
+
+class GceBamInfo(C.Structure):
+    _fields_ = [("n_targets", C.c_int32), ("target_len", C.POINTER(C.c_uint32)), ("target_name", C.POINTER(C.c_char_p)),
+                ("text", C.c_void_p), ("l_text", C.c_int64), ("n_records", C.c_int64),
+                ("qname_bytes", C.c_uint64), ("cigar_words", C.c_uint64), ("seq_bytes", C.c_uint64), ("qual_bytes", C.c_uint64),
+                ("mi_bytes", C.c_uint64), ("read_s", C.c_double), ("inflate_s", C.c_double), ("index_s", C.c_double)]
+
+
+class GceBamRun(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_out", C.c_int64), ("open_s", C.c_double), ("submit_s", C.c_double),
+                ("process_s", C.c_double), ("kernel_ms", C.c_double), ("drain_s", C.c_double), ("write_s", C.c_double),
+                ("total_s", C.c_double), ("pre", GceStats), ("post", GceStats)]
 
 
 class GceError(RuntimeError):
@@ -145,6 +161,22 @@ def load_library(path=None):
     lib.gce_status_message.argtypes = [C.c_int]
     lib.gce_status_message.restype = C.c_char_p
     lib.gce_abi_version.restype = C.c_int
+    lib.gce_reserve.argtypes = [C.c_void_p, C.c_int64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.gce_submit_async.argtypes = [C.c_void_p, C.POINTER(GceBatch), C.POINTER(C.c_int32)]
+    lib.gce_submit_wait.argtypes = [C.c_void_p, C.c_int32]
+    lib.gce_bam_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.gce_bam_close.argtypes = [C.c_void_p]
+    lib.gce_bam_close.restype = None
+    lib.gce_bam_error.argtypes = [C.c_void_p]
+    lib.gce_bam_error.restype = C.c_char_p
+    lib.gce_bam_get_info.argtypes = [C.c_void_p, C.POINTER(GceBamInfo)]
+    lib.gce_bam_chunk.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(GceBatch)]
+    lib.gce_bam_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(GceResult), C.c_int, C.c_int]
+    lib.gce_fasta_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.gce_fasta_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
+    lib.gce_fasta_free.argtypes = [C.c_void_p]
+    lib.gce_fasta_free.restype = None
+    lib.gce_run_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(GceParams), C.c_int, C.c_int64, C.c_int, C.POINTER(GceBamRun), C.c_char * 256]
     if path is None:
         _lib = lib
     return lib

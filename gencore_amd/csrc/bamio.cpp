@@ -1,0 +1,497 @@
+// bamio.cpp — BGZF/BAM reader and writer over zlib + FASTA loader behind the C-ABI (include/gencore_amd.h, "files" section).
+//
+// Replaces on the host what the reference does through htslib and FastaReader around the hot path:
+//   sam_open / sam_hdr_read / sam_read1        src/gencore.cpp:164-205      -> gce_bam_open (+ gce_bam_chunk: records -> gce_batch)
+//   sam_hdr_write / sam_write1 / sam_close     src/gencore.cpp:187-190,104  -> gce_bam_write (result rows -> records -> BGZF)
+//   FastaReader::readAll / readNext / to4bits  src/fastareader.cpp:57-104,139-152,157-168 -> gce_fasta_load
+// htslib itself is a pinned dependency that is absent from /root/reference; the formats are the published ones (SAMv1 section 4:
+// BGZF = concatenated gzip members with a "BC" extra field, BAM record layout), restated here.
+// Everything that scales with the file is spread over `threads` host threads: inflate per BGZF block, the struct-of-arrays fill
+// per record range, record rebuild + deflate per output block.  No GPU code in this file.
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/gencore_amd.h"
+
+namespace {
+
+struct Block { uint64_t coff; uint32_t csize, usize; uint64_t uoff; };
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline int32_t rdi32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+
+template <class F> void parallel_for(int threads, int64_t n, F f) {          // f(thread, begin, end) over contiguous ranges
+    threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
+    if (threads == 1) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back([=] { f(t, n * t / threads, n * (t + 1) / threads); });
+    for (auto &x : th) x.join();
+}
+
+bool read_file(const char *path, std::vector<uint8_t> &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)std::max(0l, sz));
+    const size_t got = sz > 0 ? fread(out.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return got == (size_t)std::max(0l, sz);
+}
+
+// one raw-deflate BGZF member -> dst (usize bytes); checks the CRC
+bool inflate_block(const uint8_t *src, const Block &b, uint8_t *dst) {
+    const uint16_t xlen = rd16(src + 10);
+    const uint8_t *cdata = src + 12 + xlen;
+    const uint32_t clen = b.csize - 12 - xlen - 8;
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = clen; zs.next_out = dst; zs.avail_out = b.usize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.total_out != b.usize) return false;
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.usize) == rd32(src + b.csize - 8);
+}
+
+// one BGZF member from `n` (<= 0xff00) bytes; returns its size
+size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* >= 0x10000 + 64 */) {
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(dst, head, 16);
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = n; zs.next_out = dst + 18; zs.avail_out = 0x10000 - 18 - 8;
+    int rc = deflate(&zs, Z_FINISH);
+    if (rc != Z_STREAM_END) {                                                 // incompressible: store
+        deflateEnd(&zs); memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = n; zs.next_out = dst + 18; zs.avail_out = 0x10000 - 18 - 8;
+        rc = deflate(&zs, Z_FINISH);
+    }
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const size_t total = 18 + clen + 8;
+    const uint16_t bsize = (uint16_t)(total - 1);
+    memcpy(dst + 16, &bsize, 2);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, n);
+    memcpy(dst + 18 + clen, &crc, 4); memcpy(dst + 18 + clen + 4, &n, 4);
+    return total;
+}
+
+struct Slot {                                     // struct-of-arrays buffers of one chunk
+    std::vector<gce_core> core; std::vector<uint64_t> qoff, coff, soff, loff, mioff;
+    std::vector<char> qname, mi; std::vector<uint32_t> cigar; std::vector<uint8_t> seq, qual, nmt; std::vector<int32_t> nm;
+};
+
+// aux walk of one record: NM (type + value as bam_aux2i gives it) and MI:Z
+struct AuxInfo { uint8_t nm_type; int32_t nm; const char *mi; };
+inline size_t aux_size(uint8_t type, const uint8_t *p, const uint8_t *end) {   // bytes of the value behind the type byte, or SIZE_MAX
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    case 'Z': case 'H': { const uint8_t *q = p; while (q < end && *q) q++; return q < end ? (size_t)(q - p) + 1 : SIZE_MAX; }
+    case 'B': {
+        if (p + 5 > end) return SIZE_MAX;
+        const size_t es = aux_size(p[0], nullptr, nullptr);
+        return es == SIZE_MAX ? SIZE_MAX : 5 + es * (size_t)rd32(p + 1);
+    }
+    default: return SIZE_MAX;
+    }
+}
+inline AuxInfo scan_aux(const uint8_t *p, const uint8_t *end) {
+    AuxInfo a{0, 0, nullptr};
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], type = p[2];
+        const uint8_t *v = p + 3;
+        const size_t sz = aux_size(type, v, end);
+        if (sz == SIZE_MAX || v + sz > end) break;
+        if (t0 == 'N' && t1 == 'M' && a.nm_type == 0) {                      // bam_aux_get returns the first match
+            a.nm_type = type;
+            switch (type) {                                                   // bam_aux2i
+            case 'c': a.nm = (int8_t)v[0]; break;   case 'C': a.nm = v[0]; break;
+            case 's': a.nm = (int16_t)rd16(v); break; case 'S': a.nm = rd16(v); break;
+            case 'i': a.nm = rdi32(v); break;        case 'I': a.nm = (int32_t)rd32(v); break;
+            default: a.nm = 0; break;
+            }
+        } else if (t0 == 'M' && t1 == 'I' && type == 'Z' && !a.mi) a.mi = (const char *)v;
+        p = v + sz;
+    }
+    return a;
+}
+
+}  // namespace
+
+struct gce_bam {
+    std::vector<uint8_t> u;                       // the inflated stream
+    std::string text;
+    std::vector<std::string> names; std::vector<const char *> name_ptr; std::vector<uint32_t> lens;
+    std::vector<uint64_t> rec;                    // offset of every record's block_size
+    uint64_t tot_q = 0, tot_c = 0, tot_s = 0, tot_l = 0, tot_mi = 0;
+    int threads = 1;
+    Slot slot[2];
+    std::string err;
+    double t_read = 0, t_inflate = 0, t_index = 0;
+};
+
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+extern "C" {
+
+int gce_bam_open(const char *path, int threads, gce_bam **out) {
+    if (!path || !out) return GCE_ERR_INVALID;
+    gce_bam *f = new gce_bam();
+    f->threads = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    *out = f;
+    double t0 = now_s();
+    std::vector<uint8_t> z;
+    if (!read_file(path, z)) { f->err = std::string("cannot read ") + path; return GCE_ERR_INVALID; }
+    f->t_read = now_s() - t0; t0 = now_s();
+    // ---- BGZF members
+    std::vector<Block> blocks;
+    uint64_t off = 0, uoff = 0;
+    while (off + 18 <= z.size()) {
+        const uint8_t *p = z.data() + off;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { f->err = "not a BGZF file"; return GCE_ERR_INVALID; }
+        const uint16_t xlen = rd16(p + 10);
+        uint32_t bsize = 0; bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen; ) {
+            const uint8_t *s = p + 12 + x; const uint16_t sl = rd16(s + 2);
+            if (s[0] == 'B' && s[1] == 'C' && sl == 2) { bsize = (uint32_t)rd16(s + 4) + 1; found = true; }
+            x += 4 + sl;
+        }
+        if (!found || off + bsize > z.size() || bsize < 12u + xlen + 8u) { f->err = "bad BGZF block"; return GCE_ERR_INVALID; }
+        Block b; b.coff = off; b.csize = bsize; b.usize = rd32(p + bsize - 4); b.uoff = uoff;
+        blocks.push_back(b);
+        off += bsize; uoff += b.usize;
+    }
+    if (off != z.size()) { f->err = "trailing bytes after the last BGZF block"; return GCE_ERR_INVALID; }
+    f->u.resize(uoff + 64);
+    std::atomic<int> bad{0};
+    parallel_for(f->threads, (int64_t)blocks.size(), [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) if (blocks[k].usize && !inflate_block(z.data() + blocks[k].coff, blocks[k], f->u.data() + blocks[k].uoff)) bad = 1;
+    });
+    if (bad) { f->err = "inflate / CRC failure"; return GCE_ERR_INVALID; }
+    f->t_inflate = now_s() - t0; t0 = now_s();
+    z.clear(); z.shrink_to_fit();
+    // ---- header (SAMv1 4.2)
+    const uint8_t *u = f->u.data(); const uint64_t n = uoff;
+    if (n < 12 || memcmp(u, "BAM\1", 4) != 0) { f->err = "not a BAM stream"; return GCE_ERR_INVALID; }
+    uint64_t p = 4;
+    const uint32_t l_text = rd32(u + p); p += 4;
+    if (p + l_text + 4 > n) { f->err = "truncated header"; return GCE_ERR_INVALID; }
+    f->text.assign((const char *)u + p, l_text); p += l_text;
+    const uint32_t n_ref = rd32(u + p); p += 4;
+    for (uint32_t r = 0; r < n_ref; r++) {
+        if (p + 4 > n) { f->err = "truncated header"; return GCE_ERR_INVALID; }
+        const uint32_t ln = rd32(u + p); p += 4;
+        if (p + ln + 4 > n || ln == 0) { f->err = "truncated header"; return GCE_ERR_INVALID; }
+        f->names.emplace_back((const char *)u + p, ln - 1); p += ln;
+        f->lens.push_back(rd32(u + p)); p += 4;
+    }
+    for (auto &s : f->names) f->name_ptr.push_back(s.c_str());
+    // ---- record index + blob totals
+    while (p + 4 <= n) {
+        const uint32_t bs = rd32(u + p);
+        if (bs < 32 || p + 4 + bs > n) { f->err = "truncated record"; return GCE_ERR_INVALID; }
+        f->rec.push_back(p);
+        p += 4 + bs;
+    }
+    if (p != n) { f->err = "trailing bytes after the last record"; return GCE_ERR_INVALID; }
+    const int64_t nr = (int64_t)f->rec.size();
+    std::vector<uint64_t> tq(f->threads + 1, 0), tc(f->threads + 1, 0), ts(f->threads + 1, 0), tl(f->threads + 1, 0), tm(f->threads + 1, 0);
+    std::atomic<int> badrec{0};
+    parallel_for(f->threads, nr, [&](int t, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint8_t *r = u + f->rec[k] + 4; const uint32_t bs = rd32(u + f->rec[k]);
+            const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
+            if (lq == 0 || ls < 0 || 32ull + lq + 4ull * nc + (uint64_t)(ls + 1) / 2 + (uint64_t)ls > bs) { badrec = 1; continue; }
+            tq[t] += lq; tc[t] += nc; ts[t] += (uint64_t)(ls + 1) / 2; tl[t] += (uint64_t)ls;
+            const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs);
+            if (ai.mi) tm[t] += strlen(ai.mi) + 1;
+        }
+    });
+    if (badrec) { f->err = "inconsistent record lengths"; return GCE_ERR_INVALID; }
+    for (int t = 0; t < f->threads; t++) { f->tot_q += tq[t]; f->tot_c += tc[t]; f->tot_s += ts[t]; f->tot_l += tl[t]; f->tot_mi += tm[t]; }
+    f->t_index = now_s() - t0;
+    return GCE_OK;
+}
+
+void gce_bam_close(gce_bam *f) { delete f; }
+const char *gce_bam_error(const gce_bam *f) { return f ? f->err.c_str() : "null"; }
+
+int gce_bam_get_info(const gce_bam *f, gce_bam_info *o) {
+    if (!f || !o) return GCE_ERR_INVALID;
+    o->n_targets = (int32_t)f->lens.size(); o->target_len = f->lens.data(); o->target_name = f->name_ptr.data();
+    o->text = f->text.data(); o->l_text = (int64_t)f->text.size();
+    o->n_records = (int64_t)f->rec.size();
+    o->qname_bytes = f->tot_q; o->cigar_words = f->tot_c; o->seq_bytes = f->tot_s; o->qual_bytes = f->tot_l; o->mi_bytes = f->tot_mi;
+    o->read_s = f->t_read; o->inflate_s = f->t_inflate; o->index_s = f->t_index;
+    return GCE_OK;
+}
+
+// records [first, first + count) as a gce_batch in one of the two chunk slots (offsets relative to the slot's blobs)
+int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_batch *out) {
+    if (!f || !out || first < 0 || count < 0 || first + count > (int64_t)f->rec.size() || (slot_id != 0 && slot_id != 1)) return GCE_ERR_INVALID;
+    Slot &s = f->slot[slot_id];
+    const uint8_t *u = f->u.data();
+    const int T = f->threads;
+    std::vector<uint64_t> tq(T + 1, 0), tc(T + 1, 0), ts(T + 1, 0), tl(T + 1, 0), tm(T + 1, 0);
+    std::vector<uint8_t> has_mi(T, 0);
+    parallel_for(T, count, [&](int t, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint8_t *r = u + f->rec[first + k] + 4; const uint32_t bs = rd32(u + f->rec[first + k]);
+            const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
+            tq[t + 1] += lq; tc[t + 1] += nc; ts[t + 1] += (uint64_t)(ls + 1) / 2; tl[t + 1] += (uint64_t)ls;
+            if (f->tot_mi) { const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs); if (ai.mi) { tm[t + 1] += strlen(ai.mi) + 1; has_mi[t] = 1; } }
+        }
+    });
+    for (int t = 0; t < T; t++) { tq[t + 1] += tq[t]; tc[t + 1] += tc[t]; ts[t + 1] += ts[t]; tl[t + 1] += tl[t]; tm[t + 1] += tm[t]; }
+    const bool mi = f->tot_mi != 0;
+    s.core.resize(count); s.qoff.resize(count); s.coff.resize(count); s.soff.resize(count); s.loff.resize(count); s.nm.resize(count); s.nmt.resize(count);
+    s.qname.resize(tq[T] + 64); s.cigar.resize(tc[T] + 16); s.seq.resize(ts[T] + 64); s.qual.resize(tl[T] + 64);
+    if (mi) { s.mioff.resize(count); s.mi.resize(tm[T] + 64); }
+    const int nthreads_used = (int)std::max<int64_t>(1, std::min<int64_t>(T, count));
+    parallel_for(T, count, [&](int t, int64_t a, int64_t e) {
+        // parallel_for hands thread t the same range as in the counting pass, so the prefix sums are this range's start offsets
+        uint64_t q = tq[t], c = tc[t], sq = ts[t], l = tl[t], m = tm[t];
+        for (int64_t k = a; k < e; k++) {
+            const uint8_t *r = u + f->rec[first + k] + 4; const uint32_t bs = rd32(u + f->rec[first + k]);
+            memcpy(&s.core[k], r, 32);                                        // gce_core IS the 32-byte BAM core block
+            const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
+            const uint8_t *pq = r + 32, *pc = pq + lq, *ps = pc + 4 * nc, *pl = ps + (ls + 1) / 2, *pa = pl + ls;
+            s.qoff[k] = q; memcpy(s.qname.data() + q, pq, lq); q += lq;
+            s.coff[k] = c; memcpy(s.cigar.data() + c, pc, 4 * nc); c += nc;
+            s.soff[k] = sq; memcpy(s.seq.data() + sq, ps, (ls + 1) / 2); sq += (uint64_t)(ls + 1) / 2;
+            s.loff[k] = l; memcpy(s.qual.data() + l, pl, ls); l += (uint64_t)ls;
+            const AuxInfo ai = scan_aux(pa, r + bs);
+            s.nmt[k] = ai.nm_type; s.nm[k] = ai.nm;
+            if (mi) {
+                if (ai.mi) { const size_t n = strlen(ai.mi) + 1; s.mioff[k] = m; memcpy(s.mi.data() + m, ai.mi, n); m += n; }
+                else s.mioff[k] = UINT64_MAX;
+            }
+        }
+    });
+    (void)nthreads_used;
+    memset(out, 0, sizeof *out);
+    out->n_reads = count; out->core = s.core.data();
+    out->qname_off = s.qoff.data(); out->qname = s.qname.data(); out->cigar_off = s.coff.data(); out->cigar = s.cigar.data();
+    out->seq_off = s.soff.data(); out->seq = s.seq.data(); out->qual_off = s.loff.data(); out->qual = s.qual.data();
+    out->nm = s.nm.data(); out->nm_type = s.nmt.data();
+    if (mi) { out->mi_off = s.mioff.data(); out->mi = s.mi.data(); out->mi_bytes = tm[T]; }
+    out->qname_bytes = tq[T]; out->cigar_words = tc[T]; out->seq_bytes = ts[T]; out->qual_bytes = tl[T];
+    return GCE_OK;
+}
+
+// Gencore::writeBam for every row of the result (src/gencore.cpp:85-111): the input record res->src[k] with the row's bases,
+// qualities, name (BamUtil::copyQName, src/bamutil.cpp:338-364), NM byte (src/group.cpp:570) and FR / RR aux (src/pair.cpp:57-67).
+int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, int threads, int level) {
+    if (!path || !in || !res) return GCE_ERR_INVALID;
+    const int T = threads > 0 ? threads : in->threads;
+    const uint8_t *u = in->u.data();
+    const int64_t n = res->n_out;
+    for (int64_t k = 0; k < n; k++) if (res->src[k] >= in->rec.size() || res->qname_src[k] >= in->rec.size()) return GCE_ERR_INVALID;
+    // ---- header bytes
+    std::vector<uint8_t> hdr;
+    auto put32 = [&](std::vector<uint8_t> &v, uint32_t x) { const uint8_t *p = (const uint8_t *)&x; v.insert(v.end(), p, p + 4); };
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32(hdr, (uint32_t)in->text.size()); hdr.insert(hdr.end(), in->text.begin(), in->text.end());
+    put32(hdr, (uint32_t)in->lens.size());
+    for (size_t r = 0; r < in->lens.size(); r++) {
+        put32(hdr, (uint32_t)in->names[r].size() + 1);
+        hdr.insert(hdr.end(), in->names[r].begin(), in->names[r].end()); hdr.push_back(0);
+        put32(hdr, in->lens[r]);
+    }
+    // ---- record sizes, then the records
+    std::vector<uint64_t> roff((size_t)n + 1, 0);
+    parallel_for(T, n, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint64_t ro = in->rec[res->src[k]]; const uint32_t bs = rd32(u + ro);
+            const uint32_t lq_old = u[ro + 4 + 8], lq_new = u[in->rec[res->qname_src[k]] + 4 + 8];
+            roff[k + 1] = 4ull + bs - lq_old + lq_new + (res->fr[k] >= 0 ? 4 : 0) + (res->rr[k] >= 0 ? 4 : 0);
+        }
+    });
+    for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
+    std::vector<uint8_t> body(hdr.size() + roff[n]);
+    memcpy(body.data(), hdr.data(), hdr.size());
+    uint8_t *rb = body.data() + hdr.size();
+    parallel_for(T, n, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint8_t *r = u + in->rec[res->src[k]] + 4; const uint32_t bs = rd32(r - 4);
+            const uint8_t *nr = u + in->rec[res->qname_src[k]] + 4;
+            const uint32_t lq_old = r[8], lq_new = nr[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
+            uint8_t *o = rb + roff[k];
+            const uint32_t nbs = (uint32_t)(roff[k + 1] - roff[k] - 4);
+            memcpy(o, &nbs, 4); memcpy(o + 4, r, 32);
+            o[4 + 8] = (uint8_t)lq_new;
+            uint8_t *w = o + 36;
+            memcpy(w, nr + 32, lq_new); w += lq_new;
+            memcpy(w, r + 32 + lq_old, 4 * nc); w += 4 * nc;
+            memcpy(w, res->seq + res->seq_off[k], (ls + 1) / 2); w += (ls + 1) / 2;
+            memcpy(w, res->qual + res->qual_off[k], ls); w += ls;
+            const uint8_t *aux = r + 32 + lq_old + 4 * nc + (ls + 1) / 2 + ls; const size_t al = (size_t)(r + bs - aux);
+            memcpy(w, aux, al);
+            if (res->nm_new[k] >= 0) {                                       // dataNM[1] = newValNM (type 'C' only, checked by the engine)
+                uint8_t *p = w, *end = w + al;
+                while (p + 3 <= end) {
+                    const size_t sz = aux_size(p[2], p + 3, end);
+                    if (sz == SIZE_MAX) break;
+                    if (p[0] == 'N' && p[1] == 'M') { p[3] = (uint8_t)res->nm_new[k]; break; }
+                    p += 3 + sz;
+                }
+            }
+            w += al;
+            if (res->fr[k] >= 0) { w[0] = 'F'; w[1] = 'R'; w[2] = 'C'; w[3] = (uint8_t)res->fr[k]; w += 4; }
+            if (res->rr[k] >= 0) { w[0] = 'R'; w[1] = 'R'; w[2] = 'C'; w[3] = (uint8_t)res->rr[k]; w += 4; }
+        }
+    });
+    // ---- BGZF
+    const uint64_t BS = 0xff00;
+    const int64_t nb = (int64_t)((body.size() + BS - 1) / BS);
+    std::vector<uint8_t> z((size_t)nb * 0x10000 + 64);
+    std::vector<uint32_t> zs((size_t)nb, 0);
+    parallel_for(T, nb, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint64_t o = (uint64_t)k * BS; const uint32_t len = (uint32_t)std::min<uint64_t>(BS, body.size() - o);
+            zs[k] = (uint32_t)deflate_block(body.data() + o, len, level, z.data() + (size_t)k * 0x10000);
+        }
+    });
+    FILE *f = fopen(path, "wb");
+    if (!f) return GCE_ERR_INVALID;
+    for (int64_t k = 0; k < nb; k++) if (fwrite(z.data() + (size_t)k * 0x10000, 1, zs[k], f) != zs[k]) { fclose(f); return GCE_ERR_INVALID; }
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof_block, 1, 28, f);
+    fclose(f);
+    return GCE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------ FASTA
+// FastaReader(file) + readAll (src/fastareader.cpp:7-41,57-104,157-168) with its quirks: the FIRST character of every line is
+// taken by get(c) and appended without the validity filter of str_keep_valid_sequence (util.h:194-210) -- an empty line inside a
+// contig therefore contributes its '\n' as one base (code 0) and the line after it is taken whole; lower case is folded
+// (forceUpperCase = true, fastareader.h:21); the contig ID is the header up to the first blank.  Later contigs of the same name
+// replace earlier ones (std::map assignment).  Returns the contigs as upper-cased ASCII, ready for gce_set_reference_ascii.
+struct gce_fasta { std::vector<std::string> ids, seqs; std::vector<const char *> idp, seqp; std::vector<int64_t> len; };
+
+int gce_fasta_load(const char *path, gce_fasta **out) {
+    if (!path || !out) return GCE_ERR_INVALID;
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) return GCE_ERR_INVALID;
+    gce_fasta *fa = new gce_fasta();
+    *out = fa;
+    size_t p = 0; const size_t n = d.size();
+    while (p < n && d[p] != '>') p++;                                         // seek to the first contig
+    if (p < n) p++;
+    bool eof = p >= n;
+    // ifstream semantics: eof() turns true only when a read hits the end; get() past the end fails and sets it
+    auto upper = [](char c) { return (c >= 'a' && c <= 'z') ? (char)(c - ('a' - 'A')) : c; };
+    while (!eof) {                                                            // readAll: while(!eof) readNext()
+        std::string header, seq;
+        bool found_header = false;
+        for (;;) {
+            if (p >= n) { eof = true; break; }                                // get(c) fails at the end
+            const char c = (char)d[p++];
+            if (c == '>') break;
+            if (found_header) seq.push_back(upper(c)); else header.push_back(c);
+            std::string line;                                                 // getline(stream, line, '\n')
+            if (p >= n) eof = true;                                           //   (an empty rest sets eof and yields "")
+            else {
+                size_t e = p;
+                while (e < n && d[e] != '\n') e++;
+                line.assign((const char *)d.data() + p, e - p);
+                if (e >= n) { eof = true; p = n; } else p = e + 1;
+            }
+            if (!found_header) { header += line; found_header = true; }
+            else for (char ch : line) { ch = upper(ch); if (isalpha((unsigned char)ch) || ch == '-' || ch == '*') seq.push_back(ch); }
+            if (eof) break;
+        }
+        const size_t sp = header.find(' ');
+        const std::string id = header.substr(0, sp);
+        size_t at = fa->ids.size();
+        for (size_t k = 0; k < fa->ids.size(); k++) if (fa->ids[k] == id) at = k;
+        if (at == fa->ids.size()) { fa->ids.push_back(id); fa->seqs.push_back(seq); } else fa->seqs[at] = seq;
+    }
+    for (size_t k = 0; k < fa->ids.size(); k++) { fa->idp.push_back(fa->ids[k].c_str()); fa->seqp.push_back(fa->seqs[k].data()); fa->len.push_back((int64_t)fa->seqs[k].size()); }
+    return GCE_OK;
+}
+int gce_fasta_get(const gce_fasta *fa, int32_t *n, const char *const **ids, const char *const **seqs, const int64_t **lens) {
+    if (!fa || !n) return GCE_ERR_INVALID;
+    *n = (int32_t)fa->ids.size();
+    if (ids) *ids = fa->idp.data();
+    if (seqs) *seqs = fa->seqp.data();
+    if (lens) *lens = fa->len.data();
+    return GCE_OK;
+}
+void gce_fasta_free(gce_fasta *fa) { delete fa; }
+
+// Gencore::consensus() for a sorted BAM (src/gencore.cpp:162-293) through the C-ABI.
+int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {
+    auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
+    seterr("");
+    if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    const double t_start = now_s();
+    gce_bam *f = nullptr; gce_engine *e = nullptr; gce_fasta *fa = nullptr;
+    int rc = gce_bam_open(in_path, threads, &f);
+    auto done = [&](int code, const char *m) { seterr(m); if (e) gce_destroy(e); if (f) gce_bam_close(f); if (fa) gce_fasta_free(fa); return code; };
+    if (rc != GCE_OK) return done(rc, f ? gce_bam_error(f) : "open failed");
+    out->open_s = now_s() - t_start;
+    gce_bam_info bi; gce_bam_get_info(f, &bi);
+    gce_params prm = *params;
+    prm.n_targets = bi.n_targets; prm.target_len = bi.target_len;
+    if (strcmp(prm.umi_prefix, "auto") == 0) {                                   // src/gencore.cpp:207-220
+        memset(prm.umi_prefix, 0, sizeof prm.umi_prefix);
+        if (bi.n_records > 0) { gce_batch one; if (gce_bam_chunk(f, 0, 1, 0, &one) == GCE_OK) gce_detect_umi_prefix(one.qname, prm.umi_prefix); }
+    }
+    if ((rc = gce_create(&prm, &e)) != GCE_OK) return done(rc, gce_status_message(rc));
+    if (fasta_path && *fasta_path) {
+        if ((rc = gce_fasta_load(fasta_path, &fa)) != GCE_OK) return done(rc, "cannot read the FASTA file");
+        int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *lens;
+        gce_fasta_get(fa, &nc, &ids, &seqs, &lens);
+        for (int32_t t = 0; t < bi.n_targets; t++)                               // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+            for (int32_t c = 0; c < nc; c++)
+                if (strcmp(ids[c], bi.target_name[t]) == 0 && (rc = gce_set_reference_ascii(e, t, seqs[c], lens[c])) != GCE_OK) return done(rc, gce_last_error(e));
+    }
+    double t0 = now_s();
+    if (bi.mi_bytes == 0) { if ((rc = gce_reserve(e, bi.n_records, bi.qname_bytes, bi.cigar_words, bi.seq_bytes, bi.qual_bytes)) != GCE_OK) return done(rc, gce_last_error(e)); }
+    if (chunk_reads <= 0) chunk_reads = 1 << 21;
+    int32_t tickets[2] = {-1, -1};
+    int64_t k = 0;
+    for (int64_t first = 0; first < bi.n_records; first += chunk_reads, k++) {
+        const int sl = (int)(k & 1);
+        if (tickets[sl] >= 0 && (rc = gce_submit_wait(e, tickets[sl])) != GCE_OK) return done(rc, gce_last_error(e));   // the slot's previous copy
+        gce_batch b;
+        if ((rc = gce_bam_chunk(f, first, std::min(chunk_reads, bi.n_records - first), sl, &b)) != GCE_OK) return done(rc, "chunk");
+        if (bi.mi_bytes == 0) rc = gce_submit_async(e, &b, &tickets[sl]); else rc = gce_submit(e, &b);
+        if (rc != GCE_OK) return done(rc, gce_last_error(e));
+    }
+    out->submit_s = now_s() - t0; t0 = now_s();
+    if (bi.n_records > 0) {
+        if ((rc = gce_process(e)) != GCE_OK) return done(rc, gce_last_error(e)[0] ? gce_last_error(e) : gce_status_message(rc));
+        out->process_s = now_s() - t0; t0 = now_s();
+        gce_timing tm; if (gce_get_timing(e, &tm) == GCE_OK) out->kernel_ms = tm.total_ms;
+        gce_result res;
+        if ((rc = gce_drain(e, &res)) != GCE_OK) return done(rc, gce_last_error(e));
+        out->drain_s = now_s() - t0; t0 = now_s();
+        out->n_reads = res.n_reads; out->n_out = res.n_out; out->pre = res.pre; out->post = res.post;
+        if ((rc = gce_bam_write(out_path, f, &res, threads, level)) != GCE_OK) return done(rc, "cannot write the output BAM");
+    } else {
+        gce_result res; memset(&res, 0, sizeof res);
+        if ((rc = gce_bam_write(out_path, f, &res, threads, level)) != GCE_OK) return done(rc, "cannot write the output BAM");
+    }
+    out->write_s = now_s() - t0;
+    out->total_s = now_s() - t_start;
+    return done(GCE_OK, "");
+}
+
+}  // extern "C"

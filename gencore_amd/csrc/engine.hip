@@ -50,6 +50,9 @@ struct gce_engine {
     std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm; std::vector<uint64_t> h_tick;
     std::vector<int32_t> h_ev_tid, h_ev_pos;   // gce_set_flush_events
     bool have_mi = false, have_tick = false, have_events = false, host_mode = false, device_mode = false, processed = false;
+    // streamed submission (gce_reserve): batches go straight to HBM on their own stream while the caller prepares the next one
+    bool reserved = false; hipStream_t up_stream = nullptr; std::vector<hipEvent_t> up_events;
+    size_t rs_n = 0, rs_q = 0, rs_c = 0, rs_s = 0, rs_l = 0, st_n = 0, st_q = 0, st_c = 0, st_s = 0, st_l = 0;
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
@@ -194,6 +197,7 @@ int gce_reset(gce_engine *e) {
     e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear(); e->h_tick.clear();
     e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
     e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = false; e->n = 0; e->n_out = 0;
+    e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = 0;                     // a reservation (gce_reserve) stays
     return GCE_OK;
 }
 
@@ -205,10 +209,81 @@ int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid,
     return GCE_OK;
 }
 
+__global__ void k_add_u64(uint64_t *a, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += base;
+}
+
+// Pre-size the HBM copy of a stream whose totals are known (a BAM file that was indexed, gce_bam_get_info): from then on
+// gce_submit / gce_submit_async copy every batch straight into place -- no host staging, and the copy of batch k overlaps whatever
+// the caller does to prepare batch k + 1.  MI tags and gce_batch.tick are not supported on this path (use plain gce_submit).
+int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar_words, size_t seq_bytes, size_t qual_bytes) {
+    if (!e || n_reads < 0) return GCE_ERR_INVALID;
+    if (e->host_mode || e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_reserve after a submit");
+    (void)hipSetDevice(e->prm.device);
+    const size_t n = (size_t)n_reads;
+    HIPCHK(e->b_core.ensure(n * sizeof(gce_core) + 64)); HIPCHK(e->b_qoff.ensure(n * 8 + 64)); HIPCHK(e->b_coff.ensure(n * 8 + 64));
+    HIPCHK(e->b_soff.ensure(n * 8 + 64)); HIPCHK(e->b_loff.ensure(n * 8 + 64)); HIPCHK(e->b_nm.ensure(n * 4 + 64)); HIPCHK(e->b_nmt.ensure(n + 64));
+    HIPCHK(e->b_qname.ensure(qname_bytes + 64)); HIPCHK(e->b_cigar.ensure(cigar_words * 4 + 64)); HIPCHK(e->b_seq.ensure(seq_bytes + 64)); HIPCHK(e->b_qual.ensure(qual_bytes + 64));
+    if (!e->up_stream) HIPCHK(hipStreamCreate(&e->up_stream));
+    e->reserved = true; e->rs_n = n; e->rs_q = qname_bytes; e->rs_c = cigar_words; e->rs_s = seq_bytes; e->rs_l = qual_bytes;
+    e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = 0;
+    return GCE_OK;
+}
+
+// One batch of a reserved stream, asynchronously: the caller's buffers must stay untouched until gce_submit_wait(ticket) (or
+// gce_process) returns.  *ticket may be NULL.
+int gce_submit_async(gce_engine *e, const gce_batch *b, int32_t *ticket) {
+    if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
+    if (!e->reserved) return fail(e, GCE_ERR_INVALID, "gce_submit_async needs gce_reserve");
+    if (e->device_mode && !e->processed) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
+    if (e->processed) gce_reset(e);
+    if (b->mi || b->tick) return fail(e, GCE_ERR_INVALID, "MI tags / ticks are not supported on the reserved path");
+    const size_t n = (size_t)b->n_reads;
+    if (e->st_n + n > e->rs_n || e->st_q + b->qname_bytes > e->rs_q || e->st_c + b->cigar_words > e->rs_c || e->st_s + b->seq_bytes > e->rs_s || e->st_l + b->qual_bytes > e->rs_l)
+        return fail(e, GCE_ERR_INVALID, "batch exceeds the reservation");
+    (void)hipSetDevice(e->prm.device);
+    e->host_mode = true;
+    hipStream_t s = e->up_stream;
+    if (n) {
+        if (!b->core || !b->qname_off || !b->qname || !b->cigar_off || !b->seq_off || !b->seq || !b->qual_off || !b->qual || !b->nm || !b->nm_type)
+            return fail(e, GCE_ERR_INVALID, "null array in gce_batch");
+        auto cp = [&](DevBuf &d, size_t at, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync((char *)d.p + at, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
+        HIPCHK(cp(e->b_core, e->st_n * sizeof(gce_core), b->core, n * sizeof(gce_core)));
+        HIPCHK(cp(e->b_nm, e->st_n * 4, b->nm, n * 4)); HIPCHK(cp(e->b_nmt, e->st_n, b->nm_type, n));
+        HIPCHK(cp(e->b_qoff, e->st_n * 8, b->qname_off, n * 8)); HIPCHK(cp(e->b_coff, e->st_n * 8, b->cigar_off, n * 8));
+        HIPCHK(cp(e->b_soff, e->st_n * 8, b->seq_off, n * 8)); HIPCHK(cp(e->b_loff, e->st_n * 8, b->qual_off, n * 8));
+        HIPCHK(cp(e->b_qname, e->st_q, b->qname, b->qname_bytes)); HIPCHK(cp(e->b_cigar, e->st_c * 4, b->cigar, b->cigar_words * 4));
+        HIPCHK(cp(e->b_seq, e->st_s, b->seq, b->seq_bytes)); HIPCHK(cp(e->b_qual, e->st_l, b->qual, b->qual_bytes));
+        const unsigned nb = (unsigned)((n + 255) / 256);                            // offsets of the batch -> offsets of the stream
+        if (e->st_q) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_qoff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_q);
+        if (e->st_c) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_coff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_c);
+        if (e->st_s) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_soff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_s);
+        if (e->st_l) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_loff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_l);
+        e->st_n += n; e->st_q += b->qname_bytes; e->st_c += b->cigar_words; e->st_s += b->seq_bytes; e->st_l += b->qual_bytes;
+    }
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, s));
+    e->up_events.push_back(ev);
+    if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    return GCE_OK;
+}
+
+int gce_submit_wait(gce_engine *e, int32_t ticket) {
+    if (!e || ticket < 0 || (size_t)ticket >= e->up_events.size()) return GCE_ERR_INVALID;
+    HIPCHK(hipEventSynchronize(e->up_events[ticket]));
+    return GCE_OK;
+}
+
 // Gencore::addToCluster for a whole batch (src/gencore.cpp:272,469): host buffers are staged, then uploaded by gce_process.
 int gce_submit(gce_engine *e, const gce_batch *b) {
     if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
     if (e->device_mode && !e->processed) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
+    if (e->reserved) {                                                             // straight to HBM; the caller's buffers are free again on return
+        int32_t t; int rc = gce_submit_async(e, b, &t);
+        return rc != GCE_OK ? rc : gce_submit_wait(e, t);
+    }
     if (e->processed) gce_reset(e);
     e->host_mode = true;
     const int64_t n = b->n_reads;
@@ -249,6 +324,18 @@ int gce_submit_device(gce_engine *e, const gce_batch *b) {
 }
 
 static int upload(gce_engine *e) {
+    if (e->reserved) {                                                             // already in place (gce_submit_async): wait for the copies, publish the views
+        HIPCHK(hipStreamSynchronize(e->up_stream));
+        for (auto ev : e->up_events) (void)hipEventDestroy(ev);
+        e->up_events.clear();
+        gce_batch &d = e->dev_batch; memset(&d, 0, sizeof d);
+        d.n_reads = (int64_t)e->st_n; d.core = e->b_core.as<gce_core>();
+        d.qname_off = e->b_qoff.as<uint64_t>(); d.qname = e->b_qname.as<char>(); d.cigar_off = e->b_coff.as<uint64_t>(); d.cigar = e->b_cigar.as<uint32_t>();
+        d.seq_off = e->b_soff.as<uint64_t>(); d.seq = e->b_seq.as<uint8_t>(); d.qual_off = e->b_loff.as<uint64_t>(); d.qual = e->b_qual.as<uint8_t>();
+        d.nm = e->b_nm.as<int32_t>(); d.nm_type = e->b_nmt.as<uint8_t>();
+        d.qname_bytes = e->st_q; d.cigar_words = e->st_c; d.seq_bytes = e->st_s; d.qual_bytes = e->st_l;
+        return GCE_OK;
+    }
     struct { DevBuf *d; const void *src; size_t bytes; const void **dst; } items[] = {
         {&e->b_core, e->h_core.data(), e->h_core.size() * sizeof(gce_core), (const void **)&e->dev_batch.core},
         {&e->b_qoff, e->h_qoff.data(), e->h_qoff.size() * 8, (const void **)&e->dev_batch.qname_off},

@@ -246,6 +246,15 @@ int gce_drain(gce_engine *e, gce_result *out);
 /* Device-side view of the same table (device pointers). */
 int gce_result_device(gce_engine *e, gce_result *out);
 
+/* Streamed submission for a stream whose totals are known up front (a BAM file indexed by gce_bam_open): gce_reserve sizes the
+ * HBM copy once, then every gce_submit / gce_submit_async copies its batch straight into place on a separate HIP stream -- the
+ * copy of batch k overlaps the caller's preparation of batch k+1 (src/gencore.cpp:205-274 interleaves sam_read1 and
+ * addToCluster the same way).  With gce_submit_async the caller's buffers must stay untouched until gce_submit_wait(ticket)
+ * or gce_process returns.  MI tags and gce_batch.tick are not supported on this path. */
+int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar_words, size_t seq_bytes, size_t qual_bytes);
+int gce_submit_async(gce_engine *e, const gce_batch *batch, int32_t *ticket);
+int gce_submit_wait(gce_engine *e, int32_t ticket);
+
 int gce_get_timing(gce_engine *e, gce_timing *out);
 /* Drop all submitted reads/results but keep params, reference and allocations (for repeated bench steps). */
 int gce_reset(gce_engine *e);
@@ -253,6 +262,63 @@ int gce_reset(gce_engine *e);
 const char *gce_last_error(const gce_engine *e);   /* human-readable detail of the last failure */
 const char *gce_status_message(int status);        /* the reference's message for a status code */
 int gce_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Files: the callers and data formats on either side of the path.  Host code over zlib
+ * (gencore_amd/csrc/bamio.cpp); htslib is not used.
+ * ------------------------------------------------------------------------------------------------------------------------ */
+typedef struct gce_bam gce_bam;       /* a BAM file held in memory: inflated stream + record index */
+typedef struct gce_fasta gce_fasta;
+
+typedef struct gce_bam_info {
+    int32_t             n_targets;    /* bam_hdr_t.n_targets / target_len / target_name (src/gencore.cpp:171,311) */
+    const uint32_t     *target_len;
+    const char *const  *target_name;
+    const char         *text;         /* SAM header text, l_text bytes */
+    int64_t             l_text;
+    int64_t             n_records;
+    uint64_t            qname_bytes, cigar_words, seq_bytes, qual_bytes, mi_bytes;   /* blob totals over all records (gce_reserve) */
+    double              read_s, inflate_s, index_s;                                  /* wall time of gce_bam_open's stages */
+} gce_bam_info;
+
+/* Replaces: sam_open + sam_hdr_read + the sam_read1 loop (src/gencore.cpp:164-205): reads the file, inflates its BGZF blocks on
+ * `threads` host threads (0 = all), parses the header and indexes the records. */
+int gce_bam_open(const char *path, int threads, gce_bam **out);
+void gce_bam_close(gce_bam *f);
+const char *gce_bam_error(const gce_bam *f);
+int gce_bam_get_info(const gce_bam *f, gce_bam_info *out);
+/* Records [first, first+count) as a gce_batch (host pointers into one of two internal buffer sets, slot = 0 / 1, valid until that
+ * slot is filled again): the 32-byte core block verbatim, name / CIGAR / bases / qualities blobs, NM (type + value, bam_aux2i)
+ * and MI:Z (src/bamutil.cpp:23-38) from the aux area. */
+int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot, gce_batch *out);
+/* Replaces: sam_hdr_write + Gencore::writeBam / sam_write1 for every output record (src/gencore.cpp:85-111,187-190): row k of
+ * `res` (HOST pointers: gce_drain) becomes input record src[k] with the row's bases / qualities, the name of record qname_src[k]
+ * (BamUtil::copyQName, src/bamutil.cpp:338-364), the NM byte (src/group.cpp:570) and FR / RR appended as aux type 'C'
+ * (src/pair.cpp:57-67); BGZF blocks of 0xff00 bytes deflated at `level` on `threads` threads, EOF marker block at the end. */
+int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, int threads, int level);
+
+/* Replaces: Reference::Reference -> FastaReader(file) + readAll (src/reference.cpp:13-24, src/fastareader.cpp:7-41,57-104,157-168),
+ * including its quirks (first character of every line unfiltered, lower case folded, ID = header up to the first blank, a later
+ * contig of the same name wins).  Contigs come back as ASCII for gce_set_reference_ascii. */
+int gce_fasta_load(const char *path, gce_fasta **out);
+int gce_fasta_get(const gce_fasta *fa, int32_t *n_contigs, const char *const **ids, const char *const **bases, const int64_t **lengths);
+void gce_fasta_free(gce_fasta *fa);
+
+typedef struct gce_bam_run {
+    int64_t n_reads, n_out;
+    double  open_s;          /* gce_bam_open: read + inflate + index */
+    double  submit_s;        /* struct-of-arrays fill of every chunk + gce_submit_async (copies overlap the next fill) */
+    double  process_s;       /* gce_process wall time (waits for the last copy) */
+    double  kernel_ms;       /* gce_timing.total_ms */
+    double  drain_s, write_s, total_s;
+    gce_stats pre, post;
+} gce_bam_run;
+/* Replaces: Gencore::consensus() end to end for a coordinate-sorted BAM (src/gencore.cpp:162-293): open, (optional) reference,
+ * chunks of `chunk_reads` records through gce_reserve / gce_submit_async, gce_process, gce_drain, gce_bam_write.
+ * params->n_targets / target_len are taken from the BAM header; params->umi_prefix "auto" is resolved on the first read
+ * (src/gencore.cpp:207-220).  fasta_path may be NULL. */
+int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                int64_t chunk_reads, int level, gce_bam_run *out, char err[256]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,208 @@
+"""BGZF/BAM reader and writer + FASTA loader (gencore_amd/csrc/bamio.cpp) against an independent pure-Python
+implementation of the formats (tests/pybam.py) and hand-derived FASTA cases; GPU: a BAM file end to end through gce_run_bam."""
+import numpy as np
+import pytest
+
+import fuzzgen
+import pybam
+from gencore_amd.batch import ReadBatch
+from gencore_amd.capi import default_params
+
+
+def records_of(batch):
+    """python records (dicts) of a ReadBatch, for pybam.write_bam"""
+    out = []
+    for i in range(batch.n):
+        c = batch.core[i]
+        d = dict(qname=batch.qname_of(i), flag=int(c["flag"]), tid=int(c["tid"]), pos=int(c["pos"]), cigar=batch.cigar_of(i), mtid=int(c["mtid"]),
+                 mpos=int(c["mpos"]), isize=int(c["isize"]), seq=batch.seq_of(i), qual=batch.qual_of(i).tolist(), mapq=int(c["mapq"]), bin=int(c["bin"]),
+                 nm=(int(batch.nm[i]) if batch.nm_type[i] else None), nm_type=(chr(batch.nm_type[i]) if batch.nm_type[i] else "C"))
+        if i % 3 == 0:
+            d["aux_pre"] = [("AS", "i", 77 + i), ("XZ", "Z", "before")]
+        if i % 5 == 0:
+            d["aux_post"] = [("RG", "Z", "grp%d" % (i % 4)), ("XS", "s", -3)]
+        out.append(d)
+    return out
+
+
+def same_batch(a, b):
+    assert a.n == b.n
+    for f in ("tid", "pos", "l_qname", "mapq", "bin", "n_cigar", "flag", "l_qseq", "mtid", "mpos", "isize"):
+        assert np.array_equal(a.core[f], b.core[f]), f
+    for i in range(a.n):
+        assert a.qname_of(i) == b.qname_of(i) and a.cigar_of(i) == b.cigar_of(i) and a.seq_of(i) == b.seq_of(i) and a.qual_of(i).tolist() == b.qual_of(i).tolist()
+    assert np.array_equal(a.nm_type, b.nm_type) and np.array_equal(np.where(a.nm_type != 0, a.nm, 0), np.where(b.nm_type != 0, b.nm, 0))
+
+
+@pytest.mark.parametrize("seed,block", [(5, 0xff00), (9, 700), (31, 65280)])
+def test_reader_against_python_writer(built, tmp_path, seed, block):
+    """pybam writes the file (odd BGZF block sizes cut records across blocks), the C++ reader must hand back the same batch."""
+    from gencore_amd.bamio import BamFile
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=40)
+    recs = records_of(batch)
+    targets = [("ctg%d" % i, int(l)) for i, l in enumerate(contig_len)]
+    path = str(tmp_path / "in.bam")
+    pybam.write_bam(path, recs, targets, block=block)
+    f = BamFile(path, threads=3)
+    assert f.target_name == [t[0] for t in targets] and f.target_len == [t[1] for t in targets] and f.n_records == batch.n
+    same_batch(f.batch(), batch)
+    half = batch.n // 2                                         # chunks are relative to their own blobs
+    a, b2 = f.batch(0, half), f.batch(half, batch.n - half)
+    assert a.n == half and b2.qname_of(0) == batch.qname_of(half) and int(b2.seq_off[0]) == 0
+    info = f.info
+    assert info.seq_bytes == batch.seq.size and info.qual_bytes == batch.qual.size and info.cigar_words == batch.cigar.size
+    f.close()
+
+
+def test_reader_mi_tag_and_nm_types(built, tmp_path):
+    from gencore_amd.bamio import BamFile
+    recs = []
+    for k, (typ, val) in enumerate([("C", 7), ("c", -2), ("S", 300), ("s", -300), ("i", -70000), ("I", 70000)]):
+        recs.append(dict(qname="r%d" % k, flag=99, tid=0, pos=10 + k, cigar="4M", mtid=0, mpos=100, isize=94, seq="ACGT", qual=[30] * 4, nm=val, nm_type=typ,
+                         mi=("AAC_GGT" if k % 2 else None), aux_pre=[("XB", "C", 1)]))
+    recs.append(dict(qname="nonm", flag=99, tid=0, pos=30, cigar="4M", mtid=0, mpos=100, isize=74, seq="ACGT", qual=[30] * 4, nm=None))
+    path = str(tmp_path / "mi.bam")
+    pybam.write_bam(path, recs, [("c", 1000)])
+    f = BamFile(path)
+    b = f.batch()
+    assert b.nm.tolist()[:6] == [7, -2, 300, -300, -70000, 70000] and [chr(x) for x in b.nm_type[:6]] == list("CcSsiI") and b.nm_type[6] == 0
+    mi = [None if int(o) == 0xFFFFFFFFFFFFFFFF else bytes(b.mi[int(o):]).split(b"\0")[0].decode() for o in b.mi_off]
+    assert mi == [None, "AAC_GGT", None, "AAC_GGT", None, "AAC_GGT", None]
+    f.close()
+
+
+def test_bad_files_are_rejected(built, tmp_path):
+    from gencore_amd.bamio import BamFile
+    from gencore_amd.capi import GceError
+    p = tmp_path / "x.bam"
+    p.write_bytes(b"not a bam at all, not even gzip")
+    with pytest.raises(GceError):
+        BamFile(str(p))
+    good = tmp_path / "g.bam"
+    pybam.write_bam(str(good), [dict(qname="a", flag=4, tid=-1, pos=-1, cigar="*", mtid=-1, mpos=-1, isize=0, seq="ACGT", qual=[1] * 4, nm=None)], [("c", 10)])
+    raw = bytearray(good.read_bytes())
+    raw[30] ^= 0xFF                                             # corrupt the deflate stream / CRC
+    bad = tmp_path / "b.bam"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(GceError):
+        BamFile(str(bad))
+
+
+@pytest.mark.parametrize("seed", [4, 22])
+def test_writer_against_python_reader(built, oracle, tmp_path, seed):
+    """gce_bam_write fed with the ORACLE's result table (as gce_result rows): the file, parsed by pybam, holds exactly the records
+    the oracle emits -- name copies, NM patches, FR / RR appended behind the untouched aux fields."""
+    import ctypes as C
+    from gencore_amd import capi
+    from gencore_amd.bamio import BamFile
+    from test_host_logic import rows_from_table
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=60, umi_mode="duplex")
+    for k in list(over):
+        if k not in ("umi_prefix", "flush_period", "cluster_size_req"):
+            over.pop(k)
+    want = oracle.run(batch, fuzzgen.make_params(over, contig_len), reference)
+    assert want.status == 0
+    recs = records_of(batch)
+    targets = [("ctg%d" % i, int(l)) for i, l in enumerate(contig_len)]
+    src = str(tmp_path / "in.bam")
+    pybam.write_bam(src, recs, targets, text="@HD\tVN:1.6\n@CO\tkeep me\n")
+    f = BamFile(src, threads=2)
+    rows = rows_from_table(batch, want)
+    r = capi.GceResult()
+    keep = {k: np.ascontiguousarray(v) for k, v in rows.items()}
+    keep["fr"] = keep["fr"].astype(np.int16); keep["rr"] = keep["rr"].astype(np.int16); keep["nm_new"] = keep["nm_new"].astype(np.int32)
+    keep["kind"] = keep["kind"].astype(np.uint8); keep["qname_src"] = keep["qname_src"].astype(np.uint32)
+    r.n_reads, r.n_out = batch.n, len(rows["src"])
+    for name in ("src", "kind", "qname_src", "nm_new", "fr", "rr", "mate", "seq_off", "qual_off", "seq", "qual"):
+        setattr(r, name, keep[name].ctypes.data)
+    r.seq_bytes, r.qual_bytes = keep["seq"].size, keep["qual"].size
+    out = str(tmp_path / "out.bam")
+    assert f.lib.gce_bam_write(out.encode(), f._h, C.byref(r), 3, 6) == 0
+    text, tg, got = pybam.read_bam(out)
+    assert text == "@HD\tVN:1.6\n@CO\tkeep me\n" and tg == targets
+    exp = {x["src"]: x for x in want.records(batch)}
+    assert len(got) == len(rows["src"])
+    for k, g in enumerate(got):
+        i = int(rows["src"][k]); e = exp[i]; o = recs[i]
+        assert (g["qname"], g["flag"], g["tid"], g["pos"], g["mtid"], g["mpos"], g["isize"], g["seq"], g["qual"]) == \
+               (e["qname"].rstrip("\0"), e["flag"], e["tid"], e["pos"], e["mtid"], e["mpos"], e["isize"], e["seq"], e["qual"]), (k, g, e)
+        assert g["mapq"] == o["mapq"] and g["bin"] == o["bin"] and pybam.parse_cigar(o["cigar"]) == g["cigar"]
+        if e["nm"] is not None:
+            assert g["aux"]["NM"][1] == e["nm"] and g["aux"]["NM"][0] == o["nm_type"]
+        assert ("FR" in g["aux"]) == (e["fr"] >= 0) and ("RR" in g["aux"]) == (e["rr"] >= 0)
+        if e["fr"] >= 0:
+            assert g["aux"]["FR"] == ("C", e["fr"])
+        if e["rr"] >= 0:
+            assert g["aux"]["RR"] == ("C", e["rr"]) and g["aux_order"][-2:] == ["FR", "RR"]
+        for tag, typ, val in o.get("aux_pre", []) + o.get("aux_post", []):      # everything else untouched, in place
+            assert g["aux"][tag] == (typ, val)
+    f.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------ FASTA
+FASTA_CASES = [
+    # (file text, expected {id: bases}) -- worked out by hand from src/fastareader.cpp:7-41,57-104 and util.h:194-210
+    (">c1 first contig\nACGT\nacgt\n>c2\nGG\n", {"c1": "ACGTACGT", "c2": "GG"}),
+    # an empty line: get(c) takes the '\n' itself as a base, the next line is then consumed whole by getline
+    (">c1\nACGT\n\nTTTT\n", {"c1": "ACGT\nTTTT"}),
+    # the first character of a line escapes str_keep_valid_sequence (digits / blanks survive there and only there)
+    (">c1\n1ACGT\nAC GT9\n", {"c1": "1ACGTACGT"}),
+    # no trailing newline; junk before the first '>' is skipped; '-' and '*' are kept
+    ("junk\n>c1\nAC-G*\nTT", {"c1": "AC-G*TT"}),
+    # CRLF: '\r' is dropped from sequence lines but stays in an ID without a blank
+    (">c1 x\r\nACGT\r\n>c2\r\nGG\r\n", {"c1": "ACGT", "c2\r": "GG"}),
+    # a later contig of the same name replaces the earlier one; an empty contig is a contig
+    (">c1\nAAAA\n>c1\nCC\n>e\n>z\nG\n", {"c1": "CC", "e": "", "z": "G"}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FASTA_CASES)))
+def test_fasta_loader_quirks(built, tmp_path, case):
+    from gencore_amd.bamio import load_fasta
+    text, want = FASTA_CASES[case]
+    p = tmp_path / "ref.fa"
+    p.write_bytes(text.encode())
+    got = {k: v.decode() for k, v in load_fasta(str(p)).items()}
+    assert got == want
+
+
+# ------------------------------------------------------------------------------------------------------------------ end to end
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n_pairs,chunk", [("cfg3", 30000, 7000), ("cfg2", 20000, 1 << 21), ("cfg5", 3000, 1000)])
+def test_bam_end_to_end(built, oracle, tmp_path, workload, n_pairs, chunk):
+    """A sorted BAM + FASTA on disk -> gce_run_bam (reader, chunked gce_submit_async, engine, writer) -> a BAM whose records,
+    parsed independently, are the oracle's; Stats blocks equal."""
+    from gencore_amd import synth
+    from gencore_amd.bamio import run_bam
+    from test_cabi_driver import ascii_of
+    d = synth.generate(workload, n_pairs=n_pairs)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"], cluster_size_req=d.info["supporting_reads"])
+    ref = d.reference_host()
+    want = oracle.run(batch, prm, ref)
+    assert want.status == 0
+    targets = [("chr%d" % (i + 1), int(l)) for i, l in enumerate(tl)]
+    src, out, fa = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "ref.fa")
+    pybam.write_bam(src, records_of(batch), targets)
+    with open(fa, "wb") as f:
+        for (nm, _), bases in zip(targets, ascii_of(ref)):
+            if bases is None:
+                continue
+            f.write(b">" + nm.encode() + b" synthetic\n")
+            for o in range(0, len(bases), 60):
+                f.write(bases[o:o + 60] + b"\n")
+    prm2 = default_params(umi_prefix="auto", cluster_size_req=d.info["supporting_reads"])
+    run = run_bam(src, out, prm2, fasta=fa, threads=4, chunk_reads=chunk)
+    assert run.n_reads == batch.n and run.n_out == len(want.emitted())
+    assert bytes(run.pre) == bytes(want.pre) and bytes(run.post) == bytes(want.post)
+    _, tg, got = pybam.read_bam(out)
+    assert tg == targets
+    key = lambda r: (r["tid"], r["pos"], r["qname"], r["flag"], r["seq"])
+    exp = sorted(({**r, "qname": r["qname"].rstrip("\0")} for r in want.records(batch)), key=key)
+    got_sorted = sorted(got, key=key)
+    assert [(g["tid"], g["pos"]) for g in got] == sorted((g["tid"], g["pos"]) for g in got)      # the file is coordinate sorted
+    for g, e in zip(got_sorted, exp):
+        assert (g["qname"], g["flag"], g["tid"], g["pos"], g["seq"], g["qual"]) == (e["qname"], e["flag"], e["tid"], e["pos"], e["seq"], e["qual"])
+        assert g["aux"].get("FR", (None, -1))[1] == e["fr"] and g["aux"].get("RR", (None, -1))[1] == e["rr"]
+        assert e["nm"] is None or g["aux"]["NM"][1] == e["nm"]
