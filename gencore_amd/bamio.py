@@ -91,3 +91,16 @@ def run_bam(in_path, out_path, params, fasta=None, threads=0, chunk_reads=1 << 2
     if rc != 0:
         raise GceError(rc, err.value.decode(errors="replace"))
     return run
+
+
+def write_batch_as_bam(path, batch, target_len, target_name=None, text="@HD\tVN:1.6\tSO:coordinate\n", threads=0, level=1):
+    """gce_bam_from_batch: a ReadBatch as a BAM file (synthetic inputs for the end-to-end runs)."""
+    lib = capi.load_library()
+    st = batch.as_struct()
+    tl = np.ascontiguousarray(target_len, np.uint32)
+    names = None
+    if target_name is not None:
+        names = (C.c_char_p * len(tl))(*[n.encode() for n in target_name])
+    rc = lib.gce_bam_from_batch(str(path).encode(), C.byref(st), len(tl), tl.ctypes.data, names, text.encode(), threads, level)
+    if rc != 0:
+        raise GceError(rc, "gce_bam_from_batch")

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "gce_pack_reference", "gce_set_flush_events", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
-    "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write",
+    "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch",
     "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam"]
 
 
@@ -114,7 +114,7 @@ class GceBamInfo(C.Structure):
 
 
 class GceBamRun(C.Structure):
-    _fields_ = [("n_reads", C.c_int64), ("n_out", C.c_int64), ("open_s", C.c_double), ("submit_s", C.c_double),
+    _fields_ = [("n_reads", C.c_int64), ("n_out", C.c_int64), ("open_s", C.c_double), ("read_s", C.c_double), ("inflate_s", C.c_double), ("index_s", C.c_double), ("submit_s", C.c_double),
                 ("process_s", C.c_double), ("kernel_ms", C.c_double), ("drain_s", C.c_double), ("write_s", C.c_double),
                 ("total_s", C.c_double), ("pre", GceStats), ("post", GceStats)]
 
@@ -172,6 +172,7 @@ def load_library(path=None):
     lib.gce_bam_get_info.argtypes = [C.c_void_p, C.POINTER(GceBamInfo)]
     lib.gce_bam_chunk.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(GceBatch)]
     lib.gce_bam_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(GceResult), C.c_int, C.c_int]
+    lib.gce_bam_from_batch.argtypes = [C.c_char_p, C.POINTER(GceBatch), C.c_int32, C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.c_int]
     lib.gce_fasta_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.gce_fasta_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
     lib.gce_fasta_free.argtypes = [C.c_void_p]

@@ -9,6 +9,7 @@
 // Everything that scales with the file is spread over `threads` host threads: inflate per BGZF block, the struct-of-arrays fill
 // per record range, record rebuild + deflate per output block.  No GPU code in this file.
 #include <zlib.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -19,6 +20,8 @@
 #include <thread>
 #include <vector>
 #include "../../include/gencore_amd.h"
+
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 namespace {
 
@@ -36,7 +39,7 @@ template <class F> void parallel_for(int threads, int64_t n, F f) {          // 
     for (auto &x : th) x.join();
 }
 
-bool read_file(const char *path, std::vector<uint8_t> &out) {
+template <class V> bool read_file(const char *path, V &out) {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
@@ -86,9 +89,33 @@ size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* 
     return total;
 }
 
+// a growable buffer that is NOT value-initialised (std::vector::resize would write gigabytes of zeros on one thread)
+template <class T> struct Raw {
+    T *p = nullptr; size_t cap = 0, n = 0;
+    ~Raw() { free(p); }
+    void release() { free(p); p = nullptr; cap = n = 0; }
+    void resize(size_t k) {
+        if (k > cap) {
+            free(p);
+            const size_t bytes = std::max<size_t>(k, 1) * sizeof(T);
+            if (bytes >= (8u << 20)) {                                           // big buffers: 2 MB pages where the kernel offers them (first touch
+                const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);    // of 4 KB pages is what the host path mostly waits for)
+                p = (T *)aligned_alloc(2u << 20, rounded);
+                if (p) madvise(p, rounded, MADV_HUGEPAGE);
+            } else p = (T *)malloc(bytes);
+            cap = k;
+        }
+        n = k;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
 struct Slot {                                     // struct-of-arrays buffers of one chunk
-    std::vector<gce_core> core; std::vector<uint64_t> qoff, coff, soff, loff, mioff;
-    std::vector<char> qname, mi; std::vector<uint32_t> cigar; std::vector<uint8_t> seq, qual, nmt; std::vector<int32_t> nm;
+    Raw<gce_core> core; Raw<uint64_t> qoff, coff, soff, loff, mioff;
+    Raw<char> qname, mi; Raw<uint32_t> cigar; Raw<uint8_t> seq, qual, nmt; Raw<int32_t> nm;
 };
 
 // aux walk of one record: NM (type + value as bam_aux2i gives it) and MI:Z
@@ -129,10 +156,31 @@ inline AuxInfo scan_aux(const uint8_t *p, const uint8_t *end) {
     return a;
 }
 
+// body -> BGZF blocks of 0xff00 bytes + the EOF marker block
+int write_bgzf(const char *path, const std::vector<uint8_t> &body, int T, int level) {
+    const uint64_t BS = 0xff00;
+    const int64_t nb = (int64_t)((body.size() + BS - 1) / BS);
+    std::vector<uint8_t> z((size_t)nb * 0x10000 + 64);
+    std::vector<uint32_t> zs((size_t)nb, 0);
+    parallel_for(T, nb, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const uint64_t o = (uint64_t)k * BS; const uint32_t len = (uint32_t)std::min<uint64_t>(BS, body.size() - o);
+            zs[k] = (uint32_t)deflate_block(body.data() + o, len, level, z.data() + (size_t)k * 0x10000);
+        }
+    });
+    FILE *f = fopen(path, "wb");
+    if (!f) return GCE_ERR_INVALID;
+    for (int64_t k = 0; k < nb; k++) if (fwrite(z.data() + (size_t)k * 0x10000, 1, zs[k], f) != zs[k]) { fclose(f); return GCE_ERR_INVALID; }
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof_block, 1, 28, f);
+    fclose(f);
+    return GCE_OK;
+}
+
 }  // namespace
 
 struct gce_bam {
-    std::vector<uint8_t> u;                       // the inflated stream
+    Raw<uint8_t> u;                               // the inflated stream
     std::string text;
     std::vector<std::string> names; std::vector<const char *> name_ptr; std::vector<uint32_t> lens;
     std::vector<uint64_t> rec;                    // offset of every record's block_size
@@ -143,7 +191,6 @@ struct gce_bam {
     double t_read = 0, t_inflate = 0, t_index = 0;
 };
 
-static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 extern "C" {
 
@@ -153,7 +200,7 @@ int gce_bam_open(const char *path, int threads, gce_bam **out) {
     f->threads = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
     *out = f;
     double t0 = now_s();
-    std::vector<uint8_t> z;
+    Raw<uint8_t> z;
     if (!read_file(path, z)) { f->err = std::string("cannot read ") + path; return GCE_ERR_INVALID; }
     f->t_read = now_s() - t0; t0 = now_s();
     // ---- BGZF members
@@ -182,7 +229,7 @@ int gce_bam_open(const char *path, int threads, gce_bam **out) {
     });
     if (bad) { f->err = "inflate / CRC failure"; return GCE_ERR_INVALID; }
     f->t_inflate = now_s() - t0; t0 = now_s();
-    z.clear(); z.shrink_to_fit();
+    z.release();
     // ---- header (SAMv1 4.2)
     const uint8_t *u = f->u.data(); const uint64_t n = uoff;
     if (n < 12 || memcmp(u, "BAM\1", 4) != 0) { f->err = "not a BAM stream"; return GCE_ERR_INVALID; }
@@ -199,26 +246,88 @@ int gce_bam_open(const char *path, int threads, gce_bam **out) {
         f->lens.push_back(rd32(u + p)); p += 4;
     }
     for (auto &s : f->names) f->name_ptr.push_back(s.c_str());
-    // ---- record index + blob totals
-    while (p + 4 <= n) {
-        const uint32_t bs = rd32(u + p);
-        if (bs < 32 || p + 4 + bs > n) { f->err = "truncated record"; return GCE_ERR_INVALID; }
-        f->rec.push_back(p);
-        p += 4 + bs;
+    // ---- record index.  The records form a chain (every block_size leads to the next record): one dependent cache miss per record
+    //      when walked by one thread.  The stream is cut into segments instead; every segment is walked from a GUESSED record start
+    //      (a position where two records in a row look sane), and the pieces are then joined: segment s is accepted from the exact
+    //      offset at which the verified chain of segment s - 1 leaves that segment.  A guess that never meets the true chain costs a
+    //      sequential re-walk of its segment, never a wrong index.
+    {
+        const uint64_t first = p;
+        const int32_t nref = (int32_t)n_ref;
+        auto plausible = [&](uint64_t o) -> bool {                                   // does a record start at o?
+            if (o + 36 > n) return false;
+            const uint32_t bs = rd32(u + o);
+            if (bs < 32 || bs > (1u << 24) || o + 4 + bs > n) return false;
+            const uint8_t *r = u + o + 4;
+            const int32_t tid = rdi32(r), mtid = rdi32(r + 20); const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
+            if (tid < -1 || tid >= nref || mtid < -1 || mtid >= nref || lq == 0 || ls < 0) return false;
+            if (32ull + lq + 4ull * nc + (uint64_t)(ls + 1) / 2 + (uint64_t)ls > bs) return false;
+            return r[32 + lq - 1] == 0;
+        };
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(f->threads, (int64_t)((n - first) >> 22)));       // >= 4 MB per segment
+        std::vector<std::vector<uint64_t>> part(S);
+        std::vector<uint64_t> seg_lo(S + 1);
+        for (int sg = 0; sg <= S; sg++) seg_lo[sg] = first + (n - first) * (uint64_t)sg / (uint64_t)S;
+        auto walk = [&](uint64_t o, uint64_t hi, std::vector<uint64_t> &out) -> uint64_t {    // records starting in [o, hi); returns where the chain leaves
+            while (o < hi && o + 4 <= n) {
+                const uint32_t bs = rd32(u + o);
+                if (bs < 32 || o + 4 + bs > n) return UINT64_MAX;                        // broken chain
+                out.push_back(o);
+                o += 4 + bs;
+            }
+            return o;
+        };
+        std::vector<uint64_t> leave(S, 0);
+        parallel_for(S, S, [&](int, int64_t a, int64_t e) {
+            for (int64_t sg = a; sg < e; sg++) {
+                uint64_t o = seg_lo[sg];
+                if (sg > 0) {                                                            // guess: first position where two records in a row look sane
+                    const uint64_t lim = std::min<uint64_t>(seg_lo[sg + 1], o + (1u << 20));
+                    while (o < lim && !(plausible(o) && (o + 4 + rd32(u + o) >= n - 3 || plausible(o + 4 + rd32(u + o))))) o++;
+                    if (o >= lim) { leave[sg] = UINT64_MAX; continue; }
+                }
+                part[sg].reserve((size_t)((seg_lo[sg + 1] - seg_lo[sg]) / 200));
+                leave[sg] = walk(o, seg_lo[sg + 1], part[sg]);
+            }
+        });
+        const double t_walk = now_s();
+        int rewalks = 0;
+        uint64_t at = first;                                                             // where the verified chain enters the next segment
+        for (int sg = 0; sg < S; sg++) {
+            std::vector<uint64_t> &v = part[sg];
+            size_t from = 0; bool ok = leave[sg] != UINT64_MAX;
+            if (ok && at < seg_lo[sg + 1]) {                                             // (a record longer than a segment skips it entirely)
+                const auto it = std::lower_bound(v.begin(), v.end(), at);
+                ok = it != v.end() && *it == at; from = (size_t)(it - v.begin());
+            } else if (ok) from = v.size();
+            if (!ok) {                                                                   // the guess never met the chain: walk the segment for real
+                rewalks++;
+                v.clear(); from = 0;
+                leave[sg] = at < seg_lo[sg + 1] ? walk(at, seg_lo[sg + 1], v) : at;
+                if (leave[sg] == UINT64_MAX) { f->err = "truncated record"; return GCE_ERR_INVALID; }
+            }
+            f->rec.insert(f->rec.end(), v.begin() + from, v.end());
+            if (at < seg_lo[sg + 1]) at = leave[sg];
+            std::vector<uint64_t>().swap(v);
+        }
+        p = at;
+        if (getenv("GCE_BAM_VERBOSE")) fprintf(stderr, "index: %d segments, walk %.3f s, join %.3f s, %d re-walked\n", S, t_walk - t0, now_s() - t_walk, rewalks);
     }
     if (p != n) { f->err = "trailing bytes after the last record"; return GCE_ERR_INVALID; }
     const int64_t nr = (int64_t)f->rec.size();
     std::vector<uint64_t> tq(f->threads + 1, 0), tc(f->threads + 1, 0), ts(f->threads + 1, 0), tl(f->threads + 1, 0), tm(f->threads + 1, 0);
     std::atomic<int> badrec{0};
     parallel_for(f->threads, nr, [&](int t, int64_t a, int64_t e) {
+        uint64_t q = 0, c = 0, sq = 0, l = 0, m = 0;                              // (thread-local: the shared arrays would bounce between cores)
         for (int64_t k = a; k < e; k++) {
             const uint8_t *r = u + f->rec[k] + 4; const uint32_t bs = rd32(u + f->rec[k]);
             const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
             if (lq == 0 || ls < 0 || 32ull + lq + 4ull * nc + (uint64_t)(ls + 1) / 2 + (uint64_t)ls > bs) { badrec = 1; continue; }
-            tq[t] += lq; tc[t] += nc; ts[t] += (uint64_t)(ls + 1) / 2; tl[t] += (uint64_t)ls;
+            q += lq; c += nc; sq += (uint64_t)(ls + 1) / 2; l += (uint64_t)ls;
             const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs);
-            if (ai.mi) tm[t] += strlen(ai.mi) + 1;
+            if (ai.mi) m += strlen(ai.mi) + 1;
         }
+        tq[t] = q; tc[t] = c; ts[t] = sq; tl[t] = l; tm[t] = m;
     });
     if (badrec) { f->err = "inconsistent record lengths"; return GCE_ERR_INVALID; }
     for (int t = 0; t < f->threads; t++) { f->tot_q += tq[t]; f->tot_c += tc[t]; f->tot_s += ts[t]; f->tot_l += tl[t]; f->tot_mi += tm[t]; }
@@ -246,14 +355,15 @@ int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_bat
     const uint8_t *u = f->u.data();
     const int T = f->threads;
     std::vector<uint64_t> tq(T + 1, 0), tc(T + 1, 0), ts(T + 1, 0), tl(T + 1, 0), tm(T + 1, 0);
-    std::vector<uint8_t> has_mi(T, 0);
     parallel_for(T, count, [&](int t, int64_t a, int64_t e) {
+        uint64_t q = 0, c = 0, sq = 0, l = 0, m = 0;
         for (int64_t k = a; k < e; k++) {
             const uint8_t *r = u + f->rec[first + k] + 4; const uint32_t bs = rd32(u + f->rec[first + k]);
             const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
-            tq[t + 1] += lq; tc[t + 1] += nc; ts[t + 1] += (uint64_t)(ls + 1) / 2; tl[t + 1] += (uint64_t)ls;
-            if (f->tot_mi) { const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs); if (ai.mi) { tm[t + 1] += strlen(ai.mi) + 1; has_mi[t] = 1; } }
+            q += lq; c += nc; sq += (uint64_t)(ls + 1) / 2; l += (uint64_t)ls;
+            if (f->tot_mi) { const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs); if (ai.mi) m += strlen(ai.mi) + 1; }
         }
+        tq[t + 1] = q; tc[t + 1] = c; ts[t + 1] = sq; tl[t + 1] = l; tm[t + 1] = m;
     });
     for (int t = 0; t < T; t++) { tq[t + 1] += tq[t]; tc[t + 1] += tc[t]; ts[t + 1] += ts[t]; tl[t + 1] += tl[t]; tm[t + 1] += tm[t]; }
     const bool mi = f->tot_mi != 0;
@@ -354,24 +464,67 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
             if (res->rr[k] >= 0) { w[0] = 'R'; w[1] = 'R'; w[2] = 'C'; w[3] = (uint8_t)res->rr[k]; w += 4; }
         }
     });
-    // ---- BGZF
-    const uint64_t BS = 0xff00;
-    const int64_t nb = (int64_t)((body.size() + BS - 1) / BS);
-    std::vector<uint8_t> z((size_t)nb * 0x10000 + 64);
-    std::vector<uint32_t> zs((size_t)nb, 0);
-    parallel_for(T, nb, [&](int, int64_t a, int64_t e) {
+    return write_bgzf(path, body, T, level);
+}
+
+// The inverse of gce_bam_chunk: a gce_batch (host pointers) as a BAM file -- header, one record per read with its NM tag (type and
+// value as given) and MI:Z tag.  Used to materialise synthetic streams as files (tools/bam_bench.py, tests).
+int gce_bam_from_batch(const char *path, const gce_batch *b, int32_t n_targets, const uint32_t *target_len, const char *const *target_name,
+                       const char *text, int threads, int level) {
+    if (!path || !b || n_targets < 0) return GCE_ERR_INVALID;
+    const int T = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<uint8_t> hdr;
+    auto put32 = [&](std::vector<uint8_t> &v, uint32_t x) { const uint8_t *p = (const uint8_t *)&x; v.insert(v.end(), p, p + 4); };
+    const std::string tx = text ? text : "";
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32(hdr, (uint32_t)tx.size()); hdr.insert(hdr.end(), tx.begin(), tx.end());
+    put32(hdr, (uint32_t)n_targets);
+    for (int32_t r = 0; r < n_targets; r++) {
+        const std::string nm = target_name && target_name[r] ? target_name[r] : ("contig" + std::to_string(r));
+        put32(hdr, (uint32_t)nm.size() + 1); hdr.insert(hdr.end(), nm.begin(), nm.end()); hdr.push_back(0);
+        put32(hdr, target_len[r]);
+    }
+    const int64_t n = b->n_reads;
+    auto nm_bytes = [](uint8_t t) -> size_t { return t == 0 ? 0 : 3 + ((t == 'c' || t == 'C') ? 1 : (t == 's' || t == 'S') ? 2 : 4); };
+    std::vector<uint64_t> roff((size_t)n + 1, 0);
+    parallel_for(T, n, [&](int, int64_t a, int64_t e) {
         for (int64_t k = a; k < e; k++) {
-            const uint64_t o = (uint64_t)k * BS; const uint32_t len = (uint32_t)std::min<uint64_t>(BS, body.size() - o);
-            zs[k] = (uint32_t)deflate_block(body.data() + o, len, level, z.data() + (size_t)k * 0x10000);
+            const gce_core &c = b->core[k];
+            size_t mi = 0;
+            if (b->mi && b->mi_off && b->mi_off[k] != UINT64_MAX) mi = 3 + strlen(b->mi + b->mi_off[k]) + 1;
+            roff[k + 1] = 4ull + 32 + c.l_qname + 4ull * c.n_cigar + (uint64_t)(c.l_qseq + 1) / 2 + (uint64_t)c.l_qseq + nm_bytes(b->nm_type[k]) + mi;
         }
     });
-    FILE *f = fopen(path, "wb");
-    if (!f) return GCE_ERR_INVALID;
-    for (int64_t k = 0; k < nb; k++) if (fwrite(z.data() + (size_t)k * 0x10000, 1, zs[k], f) != zs[k]) { fclose(f); return GCE_ERR_INVALID; }
-    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    fwrite(eof_block, 1, 28, f);
-    fclose(f);
-    return GCE_OK;
+    for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
+    std::vector<uint8_t> body(hdr.size() + roff[n]);
+    memcpy(body.data(), hdr.data(), hdr.size());
+    uint8_t *rb = body.data() + hdr.size();
+    parallel_for(T, n, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            const gce_core &c = b->core[k];
+            uint8_t *o = rb + roff[k];
+            const uint32_t bs = (uint32_t)(roff[k + 1] - roff[k] - 4);
+            memcpy(o, &bs, 4); memcpy(o + 4, &c, 32);
+            uint8_t *w = o + 36;
+            memcpy(w, b->qname + b->qname_off[k], c.l_qname); w += c.l_qname;
+            memcpy(w, b->cigar + b->cigar_off[k], 4ull * c.n_cigar); w += 4ull * c.n_cigar;
+            memcpy(w, b->seq + b->seq_off[k], (c.l_qseq + 1) / 2); w += (c.l_qseq + 1) / 2;
+            memcpy(w, b->qual + b->qual_off[k], c.l_qseq); w += c.l_qseq;
+            const uint8_t t = b->nm_type[k];
+            if (t) {
+                w[0] = 'N'; w[1] = 'M'; w[2] = t;
+                const int32_t v = b->nm[k];
+                const size_t sz = nm_bytes(t) - 3;
+                memcpy(w + 3, &v, sz);                                           // little endian: the low bytes are the value
+                w += 3 + sz;
+            }
+            if (b->mi && b->mi_off && b->mi_off[k] != UINT64_MAX) {
+                const char *m = b->mi + b->mi_off[k]; const size_t ml = strlen(m) + 1;
+                w[0] = 'M'; w[1] = 'I'; w[2] = 'Z'; memcpy(w + 3, m, ml); w += 3 + ml;
+            }
+        }
+    });
+    return write_bgzf(path, body, T, level);
 }
 
 // ------------------------------------------------------------------------------------------------------------ FASTA
@@ -447,6 +600,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     if (rc != GCE_OK) return done(rc, f ? gce_bam_error(f) : "open failed");
     out->open_s = now_s() - t_start;
     gce_bam_info bi; gce_bam_get_info(f, &bi);
+    out->read_s = bi.read_s; out->inflate_s = bi.inflate_s; out->index_s = bi.index_s;
     gce_params prm = *params;
     prm.n_targets = bi.n_targets; prm.target_len = bi.target_len;
     if (strcmp(prm.umi_prefix, "auto") == 0) {                                   // src/gencore.cpp:207-220

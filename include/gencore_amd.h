@@ -297,6 +297,11 @@ int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot, gce_batch 
  * (src/pair.cpp:57-67); BGZF blocks of 0xff00 bytes deflated at `level` on `threads` threads, EOF marker block at the end. */
 int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, int threads, int level);
 
+/* The inverse of gce_bam_chunk: a gce_batch (host pointers) as a BAM file, one record per read with its NM and MI tags.  Not a
+ * reference call site: it materialises synthetic streams as files for the end-to-end measurement (tools/bam_bench.py) and tests. */
+int gce_bam_from_batch(const char *path, const gce_batch *batch, int32_t n_targets, const uint32_t *target_len,
+                       const char *const *target_name, const char *text, int threads, int level);
+
 /* Replaces: Reference::Reference -> FastaReader(file) + readAll (src/reference.cpp:13-24, src/fastareader.cpp:7-41,57-104,157-168),
  * including its quirks (first character of every line unfiltered, lower case folded, ID = header up to the first blank, a later
  * contig of the same name wins).  Contigs come back as ASCII for gce_set_reference_ascii. */
@@ -307,6 +312,7 @@ void gce_fasta_free(gce_fasta *fa);
 typedef struct gce_bam_run {
     int64_t n_reads, n_out;
     double  open_s;          /* gce_bam_open: read + inflate + index */
+    double  read_s, inflate_s, index_s;
     double  submit_s;        /* struct-of-arrays fill of every chunk + gce_submit_async (copies overlap the next fill) */
     double  process_s;       /* gce_process wall time (waits for the last copy) */
     double  kernel_ms;       /* gce_timing.total_ms */

@@ -54,6 +54,26 @@ def test_reader_against_python_writer(built, tmp_path, seed, block):
     f.close()
 
 
+def test_reader_parallel_index_on_a_large_file(built, tmp_path):
+    """> 4 MB per host thread: the record index is built from speculative per-segment walks joined against the verified chain
+    (bamio.cpp); the batch must equal the one the file was written from, whatever the thread count."""
+    from gencore_amd import synth
+    from gencore_amd.bamio import BamFile, write_batch_as_bam
+    d = synth.generate("cfg3", n_pairs=60000)
+    batch = d.to_batch()
+    path = str(tmp_path / "big.bam")
+    write_batch_as_bam(path, batch, np.asarray(d.target_len, np.uint32), threads=4)
+    for th in (1, 5, 8):
+        f = BamFile(path, threads=th)
+        b = f.batch()
+        assert b.n == batch.n and np.array_equal(b.core, batch.core)
+        for name in ("qname_off", "seq_off", "qual_off", "cigar_off", "nm", "nm_type"):
+            assert np.array_equal(getattr(b, name), getattr(batch, name)), name
+        assert np.array_equal(b.seq, batch.seq[:b.seq.size]) and np.array_equal(b.qual, batch.qual[:b.qual.size])
+        assert np.array_equal(b.qname, batch.qname[:b.qname.size]) and np.array_equal(b.cigar, batch.cigar[:b.cigar.size])
+        f.close()
+
+
 def test_reader_mi_tag_and_nm_types(built, tmp_path):
     from gencore_amd.bamio import BamFile
     recs = []
