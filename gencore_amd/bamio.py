@@ -104,3 +104,17 @@ def write_batch_as_bam(path, batch, target_len, target_name=None, text="@HD\tVN:
     rc = lib.gce_bam_from_batch(str(path).encode(), C.byref(st), len(tl), tl.ctypes.data, names, text.encode(), threads, level)
     if rc != 0:
         raise GceError(rc, "gce_bam_from_batch")
+
+
+def load_bed(path, target_names):
+    """Bed::loadFromFile (src/bed.cpp:111-168): list of (tid, start, end, name) in file order; tid -1 = contig not in the header."""
+    lib = capi.load_library()
+    names = (C.c_char_p * max(len(target_names), 1))(*[n.encode() for n in target_names])
+    n = C.c_int32()
+    tid, st, en, nm = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_char_p)()
+    rc = lib.gce_bed_load(str(path).encode(), len(target_names), names, C.byref(n), C.byref(tid), C.byref(st), C.byref(en), C.byref(nm))
+    if rc != 0:
+        raise GceError(rc, "gce_bed_load")
+    out = [(tid[k], st[k], en[k], nm[k].decode()) for k in range(n.value)]
+    lib.gce_bed_free(n, tid, st, en, nm)
+    return out

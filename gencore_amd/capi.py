@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
     "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch",
-    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam"]
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_depth_stats", "gce_bed_load", "gce_bed_free"]
 
 
 class GceBamInfo(C.Structure):
@@ -111,6 +111,11 @@ class GceBamInfo(C.Structure):
                 ("text", C.c_void_p), ("l_text", C.c_int64), ("n_records", C.c_int64),
                 ("qname_bytes", C.c_uint64), ("cigar_words", C.c_uint64), ("seq_bytes", C.c_uint64), ("qual_bytes", C.c_uint64),
                 ("mi_bytes", C.c_uint64), ("read_s", C.c_double), ("inflate_s", C.c_double), ("index_s", C.c_double)]
+
+
+class GceDepth(C.Structure):
+    _fields_ = [("n_targets", C.c_int32), ("bin_off", C.POINTER(C.c_int64)), ("pre_depth", C.POINTER(C.c_int64)), ("post_depth", C.POINTER(C.c_int64)),
+                ("n_regions", C.c_int32), ("pre_bed", C.POINTER(C.c_int64)), ("post_bed", C.POINTER(C.c_int64))]
 
 
 class GceBamRun(C.Structure):
@@ -177,6 +182,11 @@ def load_library(path=None):
     lib.gce_fasta_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
     lib.gce_fasta_free.argtypes = [C.c_void_p]
     lib.gce_fasta_free.restype = None
+    lib.gce_depth_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GceDepth)]
+    lib.gce_bed_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
+                                 C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_char_p))]
+    lib.gce_bed_free.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gce_bed_free.restype = None
     lib.gce_run_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(GceParams), C.c_int, C.c_int64, C.c_int, C.POINTER(GceBamRun), C.c_char * 256]
     if path is None:
         _lib = lib

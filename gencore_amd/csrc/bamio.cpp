@@ -586,6 +586,65 @@ int gce_fasta_get(const gce_fasta *fa, int32_t *n, const char *const **ids, cons
 }
 void gce_fasta_free(gce_fasta *fa) { delete fa; }
 
+// ------------------------------------------------------------------------------------------------------------ BED
+// Bed::loadFromFile (src/bed.cpp:111-168) with util.h's trim / split (util.h:44-85).  An empty (or blank-only) line indexes an
+// empty vector in the reference (undefined behaviour); it is skipped here.
+int gce_bed_load(const char *path, int32_t n_targets, const char *const *target_name, int32_t *n_regions, int32_t **tid_out, int32_t **start_out,
+                 int32_t **end_out, char ***name_out) {
+    if (!path || !n_regions || !tid_out || !start_out || !end_out) return GCE_ERR_INVALID;
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) return GCE_ERR_INVALID;
+    auto trim = [](const std::string &x) -> std::string {                          // spaces only (util.h:44-57)
+        const size_t a = x.find_first_not_of(' ');
+        if (a == std::string::npos) return "";
+        const size_t b = x.find_last_not_of(' ');
+        return x.substr(a, b - a + 1);
+    };
+    std::vector<int32_t> tids, starts, ends; std::vector<std::string> names;
+    size_t p = 0; const size_t n = d.size();
+    while (p < n) {                                                                // file.getline(line, 4096)
+        size_t e = p;
+        while (e < n && d[e] != '\n') e++;
+        if (e - p > 4095) break;                                                   // the line does not fit the buffer: failbit, the loop ends
+        std::string line((const char *)d.data() + p, e - p);
+        const size_t nul = line.find('\0');                                        // strlen(line)
+        if (nul != std::string::npos) line.resize(nul);
+        p = e < n ? e + 1 : n;
+        if (line.size() >= 2 && line.back() == '\r') { line.pop_back(); if (line.back() == '\r') line.pop_back(); }      // bed.cpp:126-133
+        line = trim(line);
+        std::vector<std::string> tok;                                              // split(linestr, "\t") (util.h:59-85)
+        if (!line.empty()) {
+            size_t b = line.find_first_not_of('\t');
+            while (b != std::string::npos) {
+                const size_t c = line.find('\t', b);
+                if (c != std::string::npos) { tok.push_back(line.substr(b, c - b)); b = c + 1; }
+                else { tok.push_back(line.substr(b)); b = c; }
+            }
+        }
+        if (tok.empty()) continue;
+        if (tok[0].compare(0, 1, "#") == 0) continue;                              // bed.cpp:139-140
+        if (tok.size() < 3) continue;                                              // :142-143
+        const std::string chr = trim(tok[0]);
+        int tid = -1;
+        for (int32_t t = 0; t < n_targets; t++) if (target_name && target_name[t] && chr == target_name[t]) tid = t;   // :154-162 (the last match wins)
+        tids.push_back(tid); starts.push_back(atoi(trim(tok[1]).c_str())); ends.push_back(atoi(trim(tok[2]).c_str()));
+        names.push_back(tok.size() > 3 ? trim(tok[3]) : "");
+    }
+    const size_t m = tids.size();
+    *n_regions = (int32_t)m;
+    *tid_out = (int32_t *)malloc(std::max<size_t>(m, 1) * 4); *start_out = (int32_t *)malloc(std::max<size_t>(m, 1) * 4); *end_out = (int32_t *)malloc(std::max<size_t>(m, 1) * 4);
+    memcpy(*tid_out, tids.data(), m * 4); memcpy(*start_out, starts.data(), m * 4); memcpy(*end_out, ends.data(), m * 4);
+    if (name_out) {
+        *name_out = (char **)malloc(std::max<size_t>(m, 1) * sizeof(char *));
+        for (size_t k = 0; k < m; k++) (*name_out)[k] = strdup(names[k].c_str());
+    }
+    return GCE_OK;
+}
+void gce_bed_free(int32_t n_regions, int32_t *tid, int32_t *start, int32_t *end, char **name) {
+    free(tid); free(start); free(end);
+    if (name) { for (int32_t k = 0; k < n_regions; k++) free(name[k]); free(name); }
+}
+
 // Gencore::consensus() for a sorted BAM (src/gencore.cpp:162-293) through the C-ABI.
 int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
                 int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {

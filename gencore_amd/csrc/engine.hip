@@ -14,6 +14,7 @@
 #include "gce_vote.hpp"
 #include "gce_deep.hpp"
 #include "gce_output.hpp"
+#include "gce_depth.hpp"
 
 namespace {
 
@@ -67,6 +68,9 @@ struct gce_engine {
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
+    // depth statistics (gce_depth_stats)
+    DevBuf dp_binoff, dp_regoff, dp_rs, dp_re, dp_pmax, dp_sorted, dp_depth, dp_bed;
+    std::vector<int64_t> h_binoff, h_depth_pre, h_depth_post, h_bed_pre, h_bed_post;
     // host result copies
     std::vector<uint8_t> r_kind, r_seq, r_qual; std::vector<uint32_t> r_src, r_qsrc, r_mate; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
     std::vector<uint64_t> r_soff, r_qoff;
@@ -680,6 +684,55 @@ int gce_drain(gce_engine *e, gce_result *out) {
     out->seq_off = e->r_soff.data(); out->qual_off = e->r_qoff.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
     out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
+    return GCE_OK;
+}
+
+// Stats::statDepth / Bed::statDepth for the processed stream: see gce_depth.hpp and include/gencore_amd.h.
+int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_t *r_tid, const int32_t *r_start, const int32_t *r_end, gce_depth *out) {
+    if (!e || !out || step <= 0 || n_regions < 0 || (n_regions > 0 && (!r_tid || !r_start || !r_end))) return GCE_ERR_INVALID;
+    if (!e->processed) return fail(e, GCE_ERR_INVALID, "gce_depth_stats before gce_process");
+    (void)hipSetDevice(e->prm.device);
+    hipStream_t s = e->stream;
+    const int nt = (int)e->target_len.size();
+    e->h_binoff.assign(nt + 1, 0);
+    for (int t = 0; t < nt; t++) e->h_binoff[t + 1] = e->h_binoff[t] + 1 + (int64_t)e->target_len[t] / step;           // stats.cpp:41-47
+    const int64_t nbins = e->h_binoff[nt];
+    // regions grouped by contig, file order kept (Bed::loadFromFile pushes them per contig, bed.cpp:165-166)
+    std::vector<int32_t> off(nt + 1, 0), rs(n_regions), re(n_regions), pm(n_regions), where(n_regions);
+    for (int k = 0; k < n_regions; k++) if (r_tid[k] >= 0 && r_tid[k] < nt) off[r_tid[k] + 1]++;
+    for (int t = 0; t < nt; t++) off[t + 1] += off[t];
+    std::vector<int32_t> fill(off.begin(), off.end() - 1);
+    std::vector<uint8_t> sorted(std::max(nt, 1), 1);
+    std::fill(where.begin(), where.end(), -1);
+    for (int k = 0; k < n_regions; k++) {
+        if (r_tid[k] < 0 || r_tid[k] >= nt) continue;                                                                  // contig not in the BAM header: dropped (bed.cpp:151-166)
+        const int t = r_tid[k], at = fill[t]++;
+        rs[at] = r_start[k]; re[at] = r_end[k]; where[k] = at;
+        pm[at] = at > off[t] ? std::max(pm[at - 1], r_end[k]) : r_end[k];
+        if (at > off[t] && rs[at] < rs[at - 1]) sorted[t] = 0;
+    }
+    const int nreg = off[nt];
+    auto up = [&](DevBuf &d, const void *src, size_t bytes) -> int { HIPCHK(d.ensure(bytes + 64)); if (bytes) HIPCHK(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s)); return GCE_OK; };
+    int rc;
+    if ((rc = up(e->dp_binoff, e->h_binoff.data(), (nt + 1) * 8)) || (rc = up(e->dp_regoff, off.data(), (nt + 1) * 4)) || (rc = up(e->dp_rs, rs.data(), (size_t)nreg * 4)) ||
+        (rc = up(e->dp_re, re.data(), (size_t)nreg * 4)) || (rc = up(e->dp_pmax, pm.data(), (size_t)nreg * 4)) || (rc = up(e->dp_sorted, sorted.data(), sorted.size()))) return rc;
+    HIPCHK(e->dp_depth.ensure((size_t)nbins * 16 + 64)); HIPCHK(e->dp_bed.ensure((size_t)nreg * 16 + 64));
+    HIPCHK(hipMemsetAsync(e->dp_depth.p, 0, (size_t)nbins * 16, s)); HIPCHK(hipMemsetAsync(e->dp_bed.p, 0, (size_t)nreg * 16 + 16, s));
+    DepthCtx c; c.bin_off = e->dp_binoff.as<int64_t>(); c.n_targets = nt; c.step = step; c.reg_off = e->dp_regoff.as<int32_t>();
+    c.r_start = e->dp_rs.as<int32_t>(); c.r_end = e->dp_re.as<int32_t>(); c.r_pmax = e->dp_pmax.as<int32_t>(); c.contig_sorted = e->dp_sorted.as<uint8_t>();
+    unsigned long long *dpre = e->dp_depth.as<unsigned long long>(), *dpost = dpre + nbins, *bpre = e->dp_bed.as<unsigned long long>(), *bpost = bpre + nreg;
+    const uint64_t n = (uint64_t)e->n, no = (uint64_t)e->n_out;
+    if (n) hipLaunchKernelGGL(k_depth, dim3(cdiv(n, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)nullptr, n, c, dpre, bpre);
+    if (no) hipLaunchKernelGGL(k_depth, dim3(cdiv(no, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)e->o_src.p, no, c, dpost, bpost);
+    e->h_depth_pre.resize(nbins); e->h_depth_post.resize(nbins);
+    std::vector<int64_t> bp(nreg), bq(nreg);
+    if (nbins) { HIPCHK(hipMemcpyAsync(e->h_depth_pre.data(), dpre, nbins * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(e->h_depth_post.data(), dpost, nbins * 8, hipMemcpyDeviceToHost, s)); }
+    if (nreg) { HIPCHK(hipMemcpyAsync(bp.data(), bpre, (size_t)nreg * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(bq.data(), bpost, (size_t)nreg * 8, hipMemcpyDeviceToHost, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+    e->h_bed_pre.assign(n_regions, 0); e->h_bed_post.assign(n_regions, 0);
+    for (int k = 0; k < n_regions; k++) if (where[k] >= 0) { e->h_bed_pre[k] = bp[where[k]]; e->h_bed_post[k] = bq[where[k]]; }
+    out->n_targets = nt; out->bin_off = e->h_binoff.data(); out->pre_depth = e->h_depth_pre.data(); out->post_depth = e->h_depth_post.data();
+    out->n_regions = n_regions; out->pre_bed = e->h_bed_pre.data(); out->post_bed = e->h_bed_post.data();
     return GCE_OK;
 }
 

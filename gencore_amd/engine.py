@@ -105,6 +105,20 @@ class Engine:
         t.out_index = np.sort(rows["src"])
         return t
 
+    def depth_stats(self, step, regions):
+        """Stats::statDepth / Bed::statDepth of the processed stream on the GPU (gce_depth_stats).  regions: [(tid, start, end), ...] in
+        BED file order.  Returns (bin_off, pre_depth, post_depth, pre_bed, post_bed) as numpy int64."""
+        from .capi import GceDepth
+        reg = np.asarray([r[:3] for r in regions], np.int32).reshape(-1, 3)
+        t, a, b = (np.ascontiguousarray(reg[:, k]) for k in range(3))
+        d = GceDepth()
+        self._check(self.lib.gce_depth_stats(self._h, int(step), len(reg), t.ctypes.data, a.ctypes.data, b.ctypes.data, C.byref(d)))
+        nt = d.n_targets
+        off = np.ctypeslib.as_array(d.bin_off, shape=(nt + 1,)).copy()
+        nb = int(off[-1])
+        get = lambda ptr, n: np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.int64)
+        return off, get(d.pre_depth, nb), get(d.post_depth, nb), get(d.pre_bed, len(reg)), get(d.post_bed, len(reg))
+
     def run(self, batch, reference=None):
         """Convenience: one whole stream -> ResultTable (the host batch is NOT mutated)."""
         for tid, (nib, ln) in enumerate(reference or []):

@@ -255,6 +255,24 @@ int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar
 int gce_submit_async(gce_engine *e, const gce_batch *batch, int32_t *ticket);
 int gce_submit_wait(gce_engine *e, int32_t ticket);
 
+/* Replaces: Stats::statDepth + Bed::statDepth over the stream (src/stats.cpp:57-84, src/bed.cpp:66-81), i.e. the per-base part of
+ * mPreStats->addRead (src/gencore.cpp:222, mapped reads only: src/stats.cpp:118-120) and of mPostStats->addRead in writeBam
+ * (src/gencore.cpp:110), computed on the GPU from the batch that is resident after gce_process.  coverage_step = Options::coverageStep
+ * (src/options.cpp:36).  Regions: the BED file's (tid, start, end) in FILE order (gce_bed_load); a region whose tid is outside the header
+ * is ignored, as Bed::loadFromFile drops it (src/bed.cpp:151-166).  Results (host arrays owned by the engine until the next call):
+ * depth bins per contig, 1 + target_len / step each (src/stats.cpp:41-47), and base counts per region (BedRegion::mCount). */
+typedef struct gce_depth {
+    int32_t        n_targets;
+    const int64_t *bin_off;       /* [n_targets + 1] first bin of every contig */
+    const int64_t *pre_depth;     /* [bin_off[n_targets]]  mPreStats->mGenomeDepth */
+    const int64_t *post_depth;    /*                       mPostStats->mGenomeDepth */
+    int32_t        n_regions;
+    const int64_t *pre_bed;       /* [n_regions] in the order the regions were given */
+    const int64_t *post_bed;
+} gce_depth;
+int gce_depth_stats(gce_engine *e, int32_t coverage_step, int32_t n_regions, const int32_t *region_tid, const int32_t *region_start,
+                    const int32_t *region_end, gce_depth *out);
+
 int gce_get_timing(gce_engine *e, gce_timing *out);
 /* Drop all submitted reads/results but keep params, reference and allocations (for repeated bench steps). */
 int gce_reset(gce_engine *e);
@@ -308,6 +326,13 @@ int gce_bam_from_batch(const char *path, const gce_batch *batch, int32_t n_targe
 int gce_fasta_load(const char *path, gce_fasta **out);
 int gce_fasta_get(const gce_fasta *fa, int32_t *n_contigs, const char *const **ids, const char *const **bases, const int64_t **lengths);
 void gce_fasta_free(gce_fasta *fa);
+
+/* Replaces: Bed::loadFromFile (src/bed.cpp:111-168): tab-separated chr / start / end / [name], '#' comment lines skipped, contig names
+ * resolved against the BAM header (regions of unknown contigs get tid -1), reading stops at the first line of >= 4095 characters
+ * (ifstream::getline into a 4096-byte buffer).  Arrays are malloc'ed; free them with gce_bed_free. */
+int gce_bed_load(const char *path, int32_t n_targets, const char *const *target_name, int32_t *n_regions, int32_t **tid, int32_t **start,
+                 int32_t **end, char ***name);
+void gce_bed_free(int32_t n_regions, int32_t *tid, int32_t *start, int32_t *end, char **name);
 
 typedef struct gce_bam_run {
     int64_t n_reads, n_out;

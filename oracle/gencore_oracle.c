@@ -1007,4 +1007,27 @@ void orc_free_result(orc_result *r) {
     memset(r, 0, sizeof *r);
 }
 
+/* Stats::statDepth, the genome part                                                          stats.cpp:57-84 */
+void orc_stat_depth(int64_t *depth, int64_t n_bins, int32_t step, int32_t start, int32_t len) {
+    int end = start + len;
+    int left_pos = start / step, right_pos = end / step;                 /* :66-67 (C division truncates toward zero) */
+    if (right_pos >= n_bins || left_pos < 0) return;                     /* :69-70 */
+    if (left_pos == right_pos) depth[left_pos] += len;                   /* :72-73 */
+    else {
+        depth[left_pos] += (left_pos + 1) * step - start;                /* :75-78 */
+        depth[right_pos] += end - right_pos * step;
+        for (int p = left_pos + 1; p < right_pos; p++) depth[p] += step; /* :80-82 */
+    }
+}
+/* Bed::statDepth                                                                             bed.cpp:66-81 */
+void orc_bed_depth(const int32_t *r_start, const int32_t *r_end, int64_t *r_count, int32_t n_regions, int32_t start, int32_t len) {
+    int end = start + len;
+    for (int p = 0; p < n_regions; p++) {
+        if (r_end[p] < start) continue;                                  /* :73-74 */
+        if (r_start[p] > end) break;                                     /* :75-76: assumes sorted regions */
+        int l = (r_end[p] < end ? r_end[p] : end) - (r_start[p] > start ? r_start[p] : start);   /* :78 */
+        r_count[p] += l;
+    }
+}
+
 int orc_abi_version(void) { return GCE_ABI_VERSION; }

@@ -61,6 +61,10 @@ int  orc_cigar_rlen(const uint32_t *cigar, int n_cigar);
 void orc_pack_reference(const char *bases, int64_t n, uint8_t *out);
 char orc_reference_base(const uint8_t *data, int64_t pos);
 /* one group side in isolation: reads[0] is the template.  Used by kernel-level parity tests. */
+/* Stats::statDepth + Bed::statDepth (src/stats.cpp:57-84, src/bed.cpp:66-81) for one read: depth[] is the contig's bin array
+ * (1 + target_len / step entries), regions are the contig's BED regions in FILE order. */
+void orc_stat_depth(int64_t *depth, int64_t n_bins, int32_t step, int32_t start, int32_t len);
+void orc_bed_depth(const int32_t *r_start, const int32_t *r_end, int64_t *r_count, int32_t n_regions, int32_t start, int32_t len);
 int  orc_abi_version(void);
 
 #ifdef __cplusplus

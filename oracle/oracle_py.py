@@ -54,6 +54,10 @@ def lib():
         L.orc_m_offset_len.restype = None
         L.orc_cigar_rlen.argtypes = [C.c_void_p, C.c_int]
         L.orc_pack_reference.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+        L.orc_stat_depth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_stat_depth.restype = None
+        L.orc_bed_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_bed_depth.restype = None
         L.orc_pack_reference.restype = None
         L.orc_reference_base.argtypes = [C.c_void_p, C.c_int64]
         L.orc_reference_base.restype = C.c_char
@@ -142,3 +146,31 @@ def run(batch, params, contigs=None, events=None):
     lib().orc_free_result(C.byref(res))
     del keep
     return table
+
+
+def depth_stats(batch, table, target_len, step, regions):
+    """Stats::statDepth over every mapped input read (pre: Stats::addRead, stats.cpp:101-121 called from gencore.cpp:222) and over
+    every emitted record (post: writeBam, gencore.cpp:110).  regions: list of (tid, start, end) in BED file order.
+    Returns (bin_off, pre_depth, post_depth, pre_bed, post_bed)."""
+    L = lib()
+    tl = np.asarray(target_len, np.int64)
+    nb = 1 + tl // step
+    off = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+    reg = np.asarray(regions, np.int32).reshape(-1, 3)
+    by_tid = [np.nonzero(reg[:, 0] == t)[0] for t in range(len(tl))]          # stable: file order inside a contig
+    out = []
+    for sel in (np.nonzero(batch.core["tid"] >= 0)[0], np.nonzero(table.out_flag)[0]):
+        depth = np.zeros(int(off[-1]), np.int64)
+        bed = np.zeros(len(reg), np.int64)
+        for t in range(len(tl)):
+            rs, re_ = np.ascontiguousarray(reg[by_tid[t], 1]), np.ascontiguousarray(reg[by_tid[t], 2])
+            rc = np.zeros(len(rs), np.int64)
+            dd = depth[off[t]:off[t + 1]]
+            for i in sel[batch.core["tid"][sel] == t]:
+                c = batch.core[int(i)]
+                L.orc_stat_depth(dd.ctypes.data, int(nb[t]), step, int(c["pos"]), int(c["l_qseq"]))
+                if len(rs):
+                    L.orc_bed_depth(rs.ctypes.data, re_.ctypes.data, rc.ctypes.data, len(rs), int(c["pos"]), int(c["l_qseq"]))
+            bed[by_tid[t]] = rc
+        out += [depth, bed]
+    return off, out[0], out[2], out[1], out[3]
