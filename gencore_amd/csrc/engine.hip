@@ -541,7 +541,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
         compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
         hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
-        hipLaunchKernelGGL(k_pairing_deep, dim3(1024), dim3(PD_T), 0, s, b, p, w);             // deep clusters in LDS; the rest -> pq_list
+        hipLaunchKernelGGL(k_pairing_deep, dim3(256), dim3(PD_T), 0, s, b, p, w);             // deep clusters in LDS; the rest -> pq_list
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
         hipLaunchKernelGGL(k_pairing_slow<2>, dim3(1024), dim3(256), 0, s, b, p, w);
