@@ -109,7 +109,8 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
     __shared__ uint16_t s_tid[2][VB_MAXP];
     __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index inside the group), ascending
-    __shared__ __attribute__((aligned(16))) uint32_t s_tal[VB_CCAP][5][4];         // pass B: per contested column and bin {count, score sum, qual sum, top qual}
+    __shared__ __attribute__((aligned(8))) uint32_t s_tal[VB_CCAP][5][2];          // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
+                                                                                   // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
     __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
     __shared__ uint16_t s_jpre[VB_SIDES + 1];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         int s1 = s0;
         while (s1 < VB_SIDES && (int)s_cpre[s1 + 1] - (int)s_cpre[s0] <= VB_CCAP) s1++;          // sides [s0, s1) : a side has <= VB_SMAX columns
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
-        for (int k = tid; k < ncol * 5; k += VB_T) *(uint4 *)(&s_tal[0][0][0] + 4 * k) = make_uint4(0, 0, 0, 0);
+        for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
         // (c) one lane per (side, voter, contested column), columns fastest
         for (int it = j0 + tid; it < j0 + njob; it += VB_T) {
@@ -435,8 +436,8 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
             if (bin < 0 || (q & 0x80)) s_gflag[sd->grp] = 2;
             else {
-                uint32_t *t4 = &s_tal[ci - c0][bin][0];
-                atomicAdd(t4, 1u); atomicAdd(t4 + 1, (uint32_t)sc); atomicAdd(t4 + 2, (uint32_t)q); atomicMax(t4 + 3, (uint32_t)q);
+                uint32_t *t2 = &s_tal[ci - c0][bin][0];
+                atomicAdd(t2, 1u | ((uint32_t)(sc + p.score_bias) << 6) | ((uint32_t)q << 20)); atomicMax(t2 + 1, (uint32_t)q);
             }
         }
         __syncthreads();
@@ -453,8 +454,9 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             Tally5 t; t.total = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const uint4 v4 = *(const uint4 *)(&s_tal[ci - c0][k][0]);
-                t.cnt[k] = (int)v4.x; t.ss[k] = (int)v4.y; t.qs[k] = (int)v4.z; t.tq[k] = (int)v4.w; t.total += (int)v4.y;
+                const uint2 v2 = *(const uint2 *)(&s_tal[ci - c0][k][0]);
+                t.cnt[k] = (int)(v2.x & 63u); t.ss[k] = (int)((v2.x >> 6) & 0x3FFFu) - t.cnt[k] * p.score_bias; t.qs[k] = (int)(v2.x >> 20); t.tq[k] = (int)v2.y;
+                t.total += t.ss[k];
             }
             const ColOut r = decide_column_packed(t, p, out_base, ref4);
             s_cq[ci] = (uint8_t)r.qual; s_cb[ci] = (uint8_t)r.base;
