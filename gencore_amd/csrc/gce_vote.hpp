@@ -36,7 +36,7 @@
 #define VB_MAXP 96
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
-#define VB_CCAP 192        // contested columns voted per round (LDS tallies)
+#define VB_CCAP 144        // contested columns voted per round (LDS tallies)
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #define VB_RCAP (VB_SIDES * VB_SMAX)
 
@@ -102,7 +102,7 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
     return lo;
 }
 
-__global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+__global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
@@ -402,43 +402,59 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
-        // (c) one lane per (side, voter, contested column), columns fastest
-        for (int it = j0 + tid; it < j0 + njob; it += VB_T) {
-            const int s = s0 + vb_find(s_jpre + s0, s1 - s0, it), side = s & 1;
+        // (c) one lane per (side, voter, contested column), columns fastest.  Two items per trip: the byte loads of both are issued
+        //     before either is used (an item is two dependent round trips otherwise: LDS lookups -> its bytes)
+        struct Item { int ci, side, grp, q, sb, mb, mq, mc, col; bool on, inov, cst; };
+        auto prep = [&](int it) -> Item {
+            Item x; x.on = it < j0 + njob; x.ci = 0; x.side = 0; x.grp = 0; x.q = 0; x.sb = 0; x.mb = 0; x.mq = 0; x.mc = 0; x.col = 0; x.inov = false; x.cst = false;
+            if (!x.on) return x;
+            const int s = s0 + vb_find(s_jpre + s0, s1 - s0, it);
+            x.side = s & 1;
             const int ncs = (int)s_cpre[s + 1] - (int)s_cpre[s], local = it - (int)s_jpre[s];
             const int kv = (int)(((uint32_t)local * ((65536u + (uint32_t)ncs - 1u) / (uint32_t)ncs)) >> 16), c = local - kv * ncs;
-            const int ci = (int)s_cpre[s] + c, col = s_ccol[ci];
+            x.ci = (int)s_cpre[s] + c; x.col = s_ccol[x.ci];
             const VSide *sd = &s_side[s];
+            x.grp = sd->grp;
             const int lp = s_glp0[sd->grp] + s_vlist[s][kv];
-            const VRead *r = &s_rd[side][lp];
+            const VRead *r = &s_rd[x.side][lp];
             const VOv ov = s_ov[lp];
-            const int mystart = side ? ov.rs : ov.ls;
-            const bool inov = (ov.fl & 2) && (unsigned)(col - mystart) < (unsigned)ov.cmp;
-            const int sb = b.seq[r->so + (col >> 1)];
-            int q = b.qual[r->qo + col], sc, mb = 0, mq = 0, mc = 0;
-            if (inov) {                                                                 // pair.cpp:132-168: the mate's base and quality on the same reference position
-                const VRead *mt = &s_rd[side ^ 1][lp];
-                mc = col - mystart + (side ? ov.ls : ov.rs);
-                mb = b.seq[mt->so + (mc >> 1)]; mq = b.qual[mt->qo + mc];
+            const int mystart = x.side ? ov.rs : ov.ls;
+            x.cst = ov.fl & 1;
+            x.inov = (ov.fl & 2) && (unsigned)(x.col - mystart) < (unsigned)ov.cmp;
+            x.sb = b.seq[r->so + (x.col >> 1)];
+            x.q = b.qual[r->qo + x.col];
+            if (x.inov) {                                                               // pair.cpp:132-168: the mate's base and quality on the same reference position
+                const VRead *mt = &s_rd[x.side ^ 1][lp];
+                x.mc = x.col - mystart + (x.side ? ov.ls : ov.rs);
+                x.mb = b.seq[mt->so + (x.mc >> 1)]; x.mq = b.qual[mt->qo + x.mc];
             }
-            const int nb = (col & 1) ? (sb & 0xF) : (sb >> 4);
-            if (ov.fl & 1) sc = p.s_moderate;                                           // pair.cpp:89-105
-            else if (inov) {
-                const int mn = (mc & 1) ? (mb & 0xF) : (mb >> 4);
-                if (nb == mn) sc = d_qual2score(p, ((q + mq) / 2) & 0xFF) + 4;
+            return x;
+        };
+        auto vote = [&](const Item &x) {
+            if (!x.on) return;
+            int q = x.q, sc;
+            const int nb = (x.col & 1) ? (x.sb & 0xF) : (x.sb >> 4);
+            if (x.cst) sc = p.s_moderate;                                               // pair.cpp:89-105
+            else if (x.inov) {
+                const int mn = (x.mc & 1) ? (x.mb & 0xF) : (x.mb >> 4);
+                if (nb == mn) sc = d_qual2score(p, ((q + x.mq) / 2) & 0xFF) + 4;
                 else {
-                    const bool left_wins = side ? (mq >= q) : (q >= mq);              // `if(lq >= rq)`: the left read keeps a score
-                    const int dq = max(0, q - mq);
-                    sc = (side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
+                    const bool left_wins = x.side ? (x.mq >= q) : (q >= x.mq);        // `if(lq >= rq)`: the left read keeps a score
+                    const int dq = max(0, q - x.mq);
+                    sc = (x.side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
                     q = dq;                                                             // the rewritten quality is what the vote sees
                 }
             } else sc = d_qual2score(p, q);
             const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
-            if (bin < 0 || (q & 0x80)) s_gflag[sd->grp] = 2;
+            if (bin < 0 || (q & 0x80)) s_gflag[x.grp] = 2;
             else {
-                uint32_t *t2 = &s_tal[ci - c0][bin][0];
+                uint32_t *t2 = &s_tal[x.ci - c0][bin][0];
                 atomicAdd(t2, 1u | ((uint32_t)(sc + p.score_bias) << 6) | ((uint32_t)q << 20)); atomicMax(t2 + 1, (uint32_t)q);
             }
+        };
+        for (int it = j0 + tid; it < j0 + njob; it += 2 * VB_T) {
+            const Item x0 = prep(it), x1 = prep(it + VB_T);
+            vote(x0); vote(x1);
         }
         __syncthreads();
         // (d) one lane per column of the round: rule cascade + reference arbitration (group.cpp:394-501)
