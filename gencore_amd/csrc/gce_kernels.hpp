@@ -79,7 +79,7 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
 }
 
 // ===================================================================================================== prescan
-__global__ __launch_bounds__(CHUNK) void k_prescan(DevBatch b, DevParams p, Work w, int chunks_per_block) {
+__global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, Work w, int chunks_per_block) {
     __shared__ unsigned int s_cnt[WAVES_PER_BLOCK];
     __shared__ long long s_stat[WAVES_PER_BLOCK][6];
     __shared__ unsigned int s_unm[WAVES_PER_BLOCK];
@@ -261,9 +261,9 @@ __device__ __forceinline__ unsigned long long d_tab_key(const ClusterKey &k, uin
 // memory round trips: the scan is bound by latency x occupancy, not by issue.
 #define CL_U 2
 #define CL_LDS_SLOTS 1024          // LDS hash slots for the <= 512 distinct keys of a block
-__global__ __launch_bounds__(CHUNK) void k_cluster(DevBatch b, DevParams p, Work w) {
-    __shared__ unsigned int s_wcnt[CL_U][WAVES_PER_BLOCK];
+__global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, Work w) {
     __shared__ uint32_t s_slot[CL_LDS_SLOTS], s_cnt[CL_U * CHUNK], s_ik[CL_U * CHUNK], s_h[CL_U * CHUNK], s_base[CL_U * CHUNK];
+    unsigned int (*s_wcnt)[WAVES_PER_BLOCK] = reinterpret_cast<unsigned int (*)[WAVES_PER_BLOCK]>(s_h);      // (s_h is written long after the last read of s_wcnt; 20 KB of LDS = 8 blocks per CU)
     __shared__ int4 s_key[CL_U * CHUNK];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const StreamInfo *si = w.si;
