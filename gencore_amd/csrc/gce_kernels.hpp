@@ -2160,26 +2160,30 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
     if (threadIdx.x == 0) s_np = 0;
     __syncthreads();
     const uint64_t tid0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    // indices into gce_stats: 6 clusters, 7 multi, 8 molecules, 9 se, 10 pe, 11 sscs, 12 dcs, 13 uncounted, 14.. hist
+    // indices into gce_stats: 0 reads, 1 bases, 2 reads_unmapped, 3 bases_unmapped, 4 mismatches, 5 reads_with_mismatches,
+    // 6 clusters, 7 multi, 8 molecules, 9 se, 10 pe, 11 sscs, 12 dcs, 13 uncounted, 14.. hist.
+    // The scalar counters are summed in registers and reduced per wave at the end (64 lanes adding to one LDS word serialise);
+    // only the histogram goes through LDS atomics.
+    long long pre[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, post[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, np = 0, post_h1 = 0;
     for (uint64_t c = tid0; c < n_clusters; c += stride) {
         uint32_t G = w.cl_ngroups[c];
         if (G == 0) continue;
-        atomicAdd(&s_pre[6], 1ull); if (G > 1) atomicAdd(&s_pre[7], 1ull);              // cluster.cpp:102
-        atomicAdd(&s_np, (unsigned long long)w.cl_npairs[c]);
+        pre[6] += 1; if (G > 1) pre[7] += 1;                                             // cluster.cpp:102
+        np += w.cl_npairs[c];
         uint32_t nr = 0; { const uint32_t g0 = w.cl_gbase[c]; for (uint32_t g = 0; g < G; g++) { uint8_t st = w.rp_state[g0 + g]; nr += (st == RP_OUT_SSCS || st == RP_OUT_DCS); } }
-        if (nr > 0) { atomicAdd(&s_post[6], 1ull); if (nr > 1) atomicAdd(&s_post[7], 1ull); }   // cluster.cpp:185-187
+        if (nr > 0) { post[6] += 1; if (nr > 1) post[7] += 1; }                         // cluster.cpp:185-187
     }
     for (uint64_t g = tid0; g < n_groups; g += stride) {
         int supp = w.rp_supp[g];
         if (supp < 0) continue;                                                          // consumed as the reverse strand: no event
         bool pe = w.rp_left[g] != NONE32 && w.rp_right[g] != NONE32;
-        atomicAdd(&s_pre[8], 1ull);                                                      // Stats::addMolecule, stats.cpp:123-133
-        if (supp < GCE_MAX_SUPPORTING_READS) atomicAdd(&s_pre[14 + supp], 1ull); else atomicAdd(&s_pre[13], 1ull);
-        atomicAdd(&s_pre[pe ? 10 : 9], 1ull);
+        pre[8] += 1;                                                                     // Stats::addMolecule, stats.cpp:123-133
+        if (supp < GCE_MAX_SUPPORTING_READS) atomicAdd(&s_pre[14 + supp], 1ull); else pre[13] += 1;
+        pre[pe ? 10 : 9] += 1;
         uint8_t st = w.rp_state[g];
         if (st == RP_OUT_SSCS || st == RP_OUT_DCS) {
-            atomicAdd(&s_post[st == RP_OUT_DCS ? 12 : 11], 1ull);                        // addSSCS / addDCS
-            atomicAdd(&s_post[8], 1ull); atomicAdd(&s_post[14 + 1], 1ull); atomicAdd(&s_post[pe ? 10 : 9], 1ull);   // outputPair: addMolecule(1, PE)
+            post[st == RP_OUT_DCS ? 12 : 11] += 1;                                       // addSSCS / addDCS
+            post[8] += 1; post_h1 += 1; post[pe ? 10 : 9] += 1;                          // outputPair: addMolecule(1, PE)
         }
     }
     for (uint64_t i = tid0; i < (uint64_t)b.n; i += stride) {                             // writeBam -> mPostStats->addRead
@@ -2189,11 +2193,18 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
         const int nmn = w.out_flag[i] == 1 ? (int)w.orec[i].nm_new : -1;
         int nm = nmn >= 0 ? nmn : b.nm[i];
         int mism = (mapped && b.nm_type[i]) ? nm : 0;
-        atomicAdd(&s_post[0], 1ull); atomicAdd(&s_post[1], (unsigned long long)k.l_qseq);
-        if (mism) { atomicAdd(&s_post[4], (unsigned long long)(long long)mism); }
-        if (!mapped) { atomicAdd(&s_post[2], 1ull); atomicAdd(&s_post[3], (unsigned long long)k.l_qseq); }
-        if (mism > 0) atomicAdd(&s_post[5], 1ull);
+        post[0] += 1; post[1] += k.l_qseq;
+        post[4] += mism;
+        if (!mapped) { post[2] += 1; post[3] += k.l_qseq; }
+        if (mism > 0) post[5] += 1;
     }
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const long long a = wave_sum64(pre[k]), c2 = wave_sum64(post[k]);
+        if (lane == 0) { if (a) atomicAdd(&s_pre[k], (unsigned long long)a); if (c2) atomicAdd(&s_post[k], (unsigned long long)c2); }
+    }
+    { const long long a = wave_sum64(np), c2 = wave_sum64(post_h1); if (lane == 0) { if (a) atomicAdd(&s_np, (unsigned long long)a); if (c2) atomicAdd(&s_post[14 + 1], (unsigned long long)c2); } }
     __syncthreads();
     for (int k = threadIdx.x; k < GCE_STATS_WORDS; k += blockDim.x) {
         if (s_pre[k]) atomicAdd((unsigned long long *)&w.si->pre[k], s_pre[k]);
