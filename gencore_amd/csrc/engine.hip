@@ -597,6 +597,16 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
         hipLaunchKernelGGL(k_finish, dim3(cdiv(C, 64 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
     } else { HIPCHK(hipEventRecord(e->ev[EV_SCORE], s)); HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s)); }
+#ifdef VB_PROF
+    if (NG > 0) {
+        StreamInfo hs; (void)hipStreamSynchronize(s); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
+        static const char *nm[11] = {"P0 groups", "P1 pairs", "P2 classes", "P3 overlap", "P4 pass A", "P5 lists", "P5 items", "P5 decide", "P5 tail", "P6 results", "P7 write"};
+        const double blocks = (double)hs.prof[15];
+        fprintf(stderr, "k_vote phases, mean per block (100 MHz ticks -> us), %.0f blocks:", blocks);
+        for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (N > 0 && e->dev_error == 0) hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);
     HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
     // ---- the output set: emitted reads in bamComp order (gencore.h:19-47) as one compact table.  Capacities are worst case

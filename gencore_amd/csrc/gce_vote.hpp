@@ -102,6 +102,11 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
     return lo;
 }
 
+#ifdef VB_PROF
+#define VB_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define VB_TICK(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
@@ -122,6 +127,10 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
     const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
     const uint32_t g0 = w.vb_start[blockIdx.x];
     if (g0 == NONE32) return;
+#ifdef VB_PROF
+    unsigned long long t_prev_ = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&w.si->prof[15], 1ull);
+#endif
     // ---------------------------------------------------------------- P0: the groups of this batch
     if (tid < 64) {
         const uint32_t gi = g0 + (uint32_t)lane;
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
     for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
     __syncthreads();
     const int ng = s_ng, npairs = s_glp0[ng];
+    VB_TICK(0);
     // ---------------------------------------------------------------- P1: pairs -> read descriptors, overlap window
     if (tid < npairs) {
         int j = 0;
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         s_ov[tid] = ov;
     }
     __syncthreads();
+    VB_TICK(1);
     // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
     if (tid < 64) {
         const int j = lane >> 1, side = lane & 1;
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         if (lane == VB_SIDES - 1) s_ipre[VB_SIDES] = (uint16_t)pre;
     }
     __syncthreads();
+    VB_TICK(2);
     // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
     //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten)
     if (tid < npairs) {
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         }
     }
     __syncthreads();
+    VB_TICK(3);
     // ---------------------------------------------------------------- P4: pass A, one lane per (side, 16 columns); the 16 top qualities stay
     //      in registers until the write-back (an item keeps its lane: it = tid + VB_T k, k < VB_IPL)
 #define VB_IPL (VB_SIDES * (VB_COLS / 16) / VB_T)
@@ -359,6 +372,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         }
     }
     __syncthreads();
+    VB_TICK(4);
     // ---------------------------------------------------------------- P5: pass B
     // (a) contested columns per side (forced columns behind the template's end do not exist); a side with too many hands its group on;
     //     prefixes over the sides: of the columns, and of the (voter, column) items
@@ -402,6 +416,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
+        VB_TICK(5);
         // (c) one lane per (side, voter, contested column), columns fastest.  Two items per trip: the byte loads of both are issued
         //     before either is used (an item is two dependent round trips otherwise: LDS lookups -> its bytes)
         struct Item { int ci, side, grp, q, sb, mb, mq, mc, col; bool on, inov, cst; };
@@ -457,6 +472,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
             vote(x0); vote(x1);
         }
         __syncthreads();
+        VB_TICK(6);
         // (d) one lane per column of the round: rule cascade + reference arbitration (group.cpp:394-501)
         for (int ci = c0 + tid; ci < c0 + ncol; ci += VB_T) {
             const int s = s0 + vb_find(s_cpre + s0, s1 - s0, ci), col = s_ccol[ci];
@@ -479,9 +495,11 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
             if (r.minc) atomicAdd(&s_side[s].minc, r.minc);
         }
         __syncthreads();
+        VB_TICK(7);
         s0 = s1;
         if (s_cpre[s0] >= n_cont) break;
     }
+    VB_TICK(8);
     // ---------------------------------------------------------------- P6: results per (group, side); NM patch or restore (group.cpp:528-573)
     if (tid < 2 * ng) {
         const int j = tid >> 1, side = tid & 1;
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
         }
     }
     __syncthreads();
+    VB_TICK(9);
     // ---------------------------------------------------------------- P7: the templates go back (the only writes to the reads)
     // (a) a restored template (mismatchInc > 5, group.cpp:528-558): seq and qual come back from the backup taken AFTER computeScore
     //     (group.cpp:327-333): the bases stay, the quals are the original ones except where the overlap check rewrote them (pair.cpp:158-159,
@@ -577,4 +596,5 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
             if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
         }
     }
+    VB_TICK(10);
 }
