@@ -196,10 +196,10 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
             if (np == 1 && s_rd[1][lp0].rd == NONE32) {                                 // group.cpp:73-77: returned untouched
                 sd.result = side == 0 ? s_rd[0][lp0].rd : NONE32;
             } else {
-                uint32_t hm = 0, single = 0;
+                uint32_t hm = 0, single = 0; int pmin = 0x7FFFFFFF, pmax = -0x7FFFFFFF;
                 for (int k = 0; k < np; k++) {
                     const VRead r = rds[k];
-                    if (r.rd != NONE32) { hm |= 1u << k; if (r.nc == 1 && cig_op(r.c0) == 0) single |= 1u << k; }
+                    if (r.rd != NONE32) { hm |= 1u << k; if (r.nc == 1 && cig_op(r.c0) == 0) single |= 1u << k; pmin = min(pmin, r.pos); pmax = max(pmax, r.pos); }
                 }
                 if (hm != 0) {
                     // The side's majority class = CIGAR and length of its first single-M read (see gce_lean2.hpp for the argument):
@@ -218,8 +218,7 @@ __global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work 
                     // class of identical reads (same CIGAR, length AND position) nothing changes, as long as every other read is unrelated
                     // to it from the end as well: >= 2 ops and a LAST op that is not an M block of >= len bases (a leading soft clip,
                     // typically) -- such a read neither votes (group.cpp:287-313) nor contains or is contained.
-                    bool ralign = false;
-                    if (side == 1) for (int k = 0; k < np; k++) if (((hm >> k) & 1u) && rds[k].pos != t.pos) ralign = true;
+                    const bool ralign = side == 1 && pmin != pmax;                     // (some read off the template's position <=> not all positions equal)
                     uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1 || (ralign && multi);
                     for (int k = 0; k < np; k++) {
                         if (!((hm >> k) & 1u)) continue;
