@@ -595,7 +595,14 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
-        hipLaunchKernelGGL(k_finish, dim3(cdiv(C, 64 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C);
+        if (!p.disable_duplex) {                                                                  // duplex stage: flagged clusters, compacted, a wave each
+            const unsigned nbc = cdiv(C, SCAN_TILE);
+            hipLaunchKernelGGL(k_finish_screen, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, w.pf_flag);
+            hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)w.pf_flag, (uint64_t)C, w.scan_part);
+            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, &w.si->n_pf_items, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)w.pf_flag, (uint64_t)C, (const uint64_t *)w.scan_part, w.pf_list);
+            hipLaunchKernelGGL(k_finish, dim3(4096), dim3(256), 0, s, b, p, w, (const uint32_t *)w.pf_list, (const unsigned long long *)&w.si->n_pf_items);
+        }
     } else { HIPCHK(hipEventRecord(e->ev[EV_SCORE], s)); HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s)); }
 #ifdef VB_PROF
     if (NG > 0) {

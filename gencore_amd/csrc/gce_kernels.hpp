@@ -2139,15 +2139,18 @@ __device__ void finish_cluster(const DevBatch &b, const DevParams &p, const Work
         WAVE_SYNC();
     }
 }
-// Few clusters need the duplex stage (UMIs and >= 2 groups): a wave screens 64 clusters with one coalesced load each and works
-// through the ones that qualify, instead of one (mostly idle) wave per cluster.
-__global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, uint32_t n_clusters) {
+// Few clusters need the duplex stage (UMIs and >= 2 groups): they are flagged, compacted, and then get a wave each -- a deep amplicon
+// cluster with a hundred UMI groups keeps its wave busy for a long time, and 64 neighbouring clusters behind one wave (the first
+// version) serialised exactly those.
+__global__ __launch_bounds__(256) void k_finish_screen(Work w, uint32_t n_clusters, uint8_t *flag) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_clusters) flag[c] = w.cl_ngroups[c] >= 2 && (w.cl_hasumi[c] & 1);
+}
+__global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w, const uint32_t *list, const unsigned long long *list_n) {
     const int lane = lane_id();
-    const uint32_t c0 = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64, c = c0 + (uint32_t)lane;
-    if (c0 >= n_clusters || p.disable_duplex) return;
-    const bool need = c < n_clusters && w.cl_ngroups[c] >= 2 && (w.cl_hasumi[c] & 1);
-    for (unsigned long long m = __ballot(need); m; m &= m - 1) {
-        finish_cluster(b, p, w, c0 + (uint32_t)(__ffsll((long long)m) - 1), lane);
+    const uint32_t n = (uint32_t)*list_n;
+    for (uint32_t k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); k < n; k += gridDim.x * WAVES_PER_BLOCK) {
+        finish_cluster(b, p, w, list[k], lane);
         WAVE_SYNC();
     }
 }
