@@ -36,7 +36,7 @@
 #define VB_MAXP 96
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
-#define VB_CCAP 144        // contested columns voted per round (LDS tallies)
+#define VB_CCAP 192        // contested columns voted per round (LDS tallies)
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #define VB_RCAP (VB_SIDES * VB_SMAX)
 
@@ -107,7 +107,7 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
 #else
 #define VB_TICK(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(VB_T, 8) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+__global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
