@@ -145,6 +145,9 @@ void gce_destroy(gce_engine *e) {
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
+    for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
+    for (auto ev : e->up_events) (void)hipEventDestroy(ev);
+    if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }
     for (auto &b : e->ref_buf) b.release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -3,16 +3,19 @@
 //
 // The per-group kernels of round 1 (one wave per group, k_score2 in front) were bound by their own instruction stream: ~1800 wave
 // instructions per group, most of them bookkeeping executed with 6-19 of 64 lanes busy.  Here a workgroup of 256 threads takes a
-// batch of ~14 groups (<= 16 groups, <= 95 pairs) through a few FLAT phases, every phase with one lane per independent item:
+// batch of ~9 groups (<= 16 groups, <= 95 pairs, weight 64) through a few FLAT phases, every phase with one lane per independent item:
 //   P1  lane = pair            the two reads' descriptors into LDS; the pair's mate-overlap window (pair.cpp:108-120)
 //   P2  lane = (group, side)   consensusMergeBam for the sides this kernel covers: one class of reads with the same CIGAR and length
+//                              -- and position, when the right reads start at different positions (right-aligned mode) --
 //                              (+ a provably unrelated minority), template = first read of the class, voters = the class
 //   P3  lane = pair            mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
 //   P4  lane = (side, 16 columns)  "pass A": OR / AND of the voters' packed bases (unanimity), packed max of their quals; a column
 //                              all voters agree on with top quality >= moderate takes group.cpp:421-428 (base kept, qual = max qual)
 //   P5  lane = (side, voter, contested column)  "pass B": the voter's base, quality and exact score (pair.cpp:132-169 computed on the fly,
 //                              the qualities of mismatching overlap bases rewritten to max(0, own - mate)) go into the column's 5-bin tally
-//                              in LDS; consecutive lanes = consecutive contested columns of ONE voter, so a wave's 64 byte loads fall
+//                              in LDS (count | biased score sum | quality sum packed into ONE atomic add, one atomic max for the top
+//                              quality: 7.7 KB of tallies instead of 15 KB took the kernel from 5 to 7 waves per SIMD, -1.2 ms, after no
+//                              change of the instruction stream had moved it); consecutive lanes = consecutive contested columns of ONE voter, so a wave's 64 byte loads fall
 //                              into a dozen cache lines (column-major items made every lane touch a line of its own: the texture
 //                              addresser, not HBM, was the limit).  Then lane = contested column: rule cascade + reference arbitration
 //                              (group.cpp:394-501)
@@ -22,7 +25,7 @@
 // for the vote and persists exactly where the reference's persists in an emitted record (the template's columns are either voted
 // columns, or — after a restore — rewritten here).  Scores are never materialised: no k_score2 launch, no score array traffic.
 //
-// A group with a side outside that scope (unrelated reads, right reads on different positions, > 32 pairs, IUPAC codes, quals >= 128,
+// A group with a side outside that scope (related odd reads, several classes of right reads on different positions, > 32 pairs, IUPAC codes, quals >= 128,
 // unusual score constants ...) is handed on UNTOUCHED, both sides: gen_flag (-> k_consensus_fast / k_consensus_slow) and slot_flag
 // (-> k_score2 scores just those pairs).
 #pragma once
