@@ -105,6 +105,18 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
     return lo;
 }
 
+// The same for the 64 consecutive items base + lane of a wave (all lanes must call it; items past `last` are clamped): the wave's first
+// item is placed by one ballot over the <= 32 prefix entries, every lane then walks on from there -- two or three steps, not five
+// dependent LDS round trips.
+__device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base, int lane, int last) {
+    last = max(last, 0);
+    const int b0 = min(base, last), it = min(base + lane, last);
+    const int pl = lane < n ? (int)pre[lane] : 0x7FFFFFFF;
+    int s = __popcll(__ballot(pl <= b0)) - 1;
+    while (s + 1 < n && (int)pre[s + 1] <= it) s++;
+    return s;
+}
+
 #ifdef VB_PROF
 #define VB_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
 #else
@@ -321,13 +333,15 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     //      in registers until the write-back (an item keeps its lane: it = tid + VB_T k, k < VB_IPL)
 #define VB_IPL (VB_SIDES * (VB_COLS / 16) / VB_T)
     uint4 keep[VB_IPL];
+    int item_side[VB_IPL];                                                         // side of every pass-A item of this lane (P4, P7)
     const int n_items = s_ipre[VB_SIDES];
 #pragma unroll
     for (int kk = 0; kk < VB_IPL; kk++) {
         keep[kk] = make_uint4(0, 0, 0, 0);
         const int it = tid + VB_T * kk;
+        const int s = vb_find_wave(s_ipre, VB_SIDES, it - lane, lane, n_items - 1);
+        item_side[kk] = s;
         if (it < n_items) {
-            const int s = vb_find(s_ipre, VB_SIDES, it);
             const VSide sd = s_side[s];
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
             const VRead *rds = s_rd[s & 1] + s_glp0[sd.grp];
@@ -422,13 +436,12 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         // (c) one lane per (side, voter, contested column), columns fastest.  Two items per trip: the byte loads of both are issued
         //     before either is used (an item is two dependent round trips otherwise: LDS lookups -> its bytes)
         struct Item { int ci, side, grp, q, sb, mb, mq, mc, col; bool on, inov, cst; };
-        auto prep = [&](int it) -> Item {
+        auto prep = [&](int it, int s) -> Item {
             Item x; x.on = it < j0 + njob; x.ci = 0; x.side = 0; x.grp = 0; x.q = 0; x.sb = 0; x.mb = 0; x.mq = 0; x.mc = 0; x.col = 0; x.inov = false; x.cst = false;
             if (!x.on) return x;
-            const int s = s0 + vb_find(s_jpre + s0, s1 - s0, it);
             x.side = s & 1;
             const int ncs = (int)s_cpre[s + 1] - (int)s_cpre[s], local = it - (int)s_jpre[s];
-            const int kv = (int)(((uint32_t)local * ((65536u + (uint32_t)ncs - 1u) / (uint32_t)ncs)) >> 16), c = local - kv * ncs;
+            const int kv = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ncs)), c = local - kv * ncs;      // local / ncs (local < 1024, ncs <= 32: the half keeps it exact)
             x.ci = (int)s_cpre[s] + c; x.col = s_ccol[x.ci];
             const VSide *sd = &s_side[s];
             x.grp = sd->grp;
@@ -462,22 +475,26 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                     q = dq;                                                             // the rewritten quality is what the vote sees
                 }
             } else sc = d_qual2score(p, q);
-            const int bin = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : nb == 15 ? 4 : -1;
-            if (bin < 0 || (q & 0x80)) s_gflag[x.grp] = 2;
+            const int bin = (int)((uint32_t)(0x4777777377727107ull >> (nb * 4)) & 7u);        // A,C,G,T,N -> 0..4, anything else 7
+            if (bin == 7 || (q & 0x80)) s_gflag[x.grp] = 2;
             else {
                 uint32_t *t2 = &s_tal[x.ci - c0][bin][0];
                 atomicAdd(t2, 1u | ((uint32_t)(sc + p.score_bias) << 6) | ((uint32_t)q << 20)); atomicMax(t2 + 1, (uint32_t)q);
             }
         };
-        for (int it = j0 + tid; it < j0 + njob; it += 2 * VB_T) {
-            const Item x0 = prep(it), x1 = prep(it + VB_T);
+        for (int itb = j0 + tid - lane; itb < j0 + njob; itb += 2 * VB_T) {             // (wave-uniform trips: the side lookup is a wave operation)
+            const int sa = s0 + vb_find_wave(s_jpre + s0, s1 - s0, itb, lane, j0 + njob - 1), sb2 = s0 + vb_find_wave(s_jpre + s0, s1 - s0, itb + VB_T, lane, j0 + njob - 1);
+            const Item x0 = prep(itb + lane, sa), x1 = prep(itb + lane + VB_T, sb2);
             vote(x0); vote(x1);
         }
         __syncthreads();
         VB_TICK(6);
         // (d) one lane per column of the round: rule cascade + reference arbitration (group.cpp:394-501)
-        for (int ci = c0 + tid; ci < c0 + ncol; ci += VB_T) {
-            const int s = s0 + vb_find(s_cpre + s0, s1 - s0, ci), col = s_ccol[ci];
+        for (int cib = c0 + tid - lane; cib < c0 + ncol; cib += VB_T) {
+            const int ci = cib + lane;
+            const int s = s0 + vb_find_wave(s_cpre + s0, s1 - s0, cib, lane, c0 + ncol - 1);
+            if (ci >= c0 + ncol) continue;
+            const int col = s_ccol[ci];
             const VSide sd = s_side[s];
             int ref4 = 0;
             if (sd.ref) {                                                               // group.cpp:430-439
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     for (int kk = 0; kk < VB_IPL; kk++) {
         const int it = tid + VB_T * kk;
         if (it < n_items) {
-            const int s = vb_find(s_ipre, VB_SIDES, it);
+            const int s = item_side[kk];
             const VSide sd = s_side[s];
             if (sd.state == VS_RESTORE) {
                 any_restore = true;
@@ -569,13 +586,13 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     for (int kk = 0; kk < VB_IPL; kk++) {
         const int it = tid + VB_T * kk;
         if (it < n_items) {
-            const int s = vb_find(s_ipre, VB_SIDES, it);
+            const int s = item_side[kk];
             const VSide sd = s_side[s];
             if (sd.state != VS_ACTIVE && sd.state != VS_RESTORE) continue;
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
             const VRead *r = &s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl];
             uint8_t *oq = b.qual + r->qo + c16, *os = b.seq + r->so + 8 * chunk;
-            uint32_t qq[4] = {keep[kk].x, keep[kk].y, keep[kk].z, keep[kk].w};
+            uint64_t qlo = (uint64_t)keep[kk].x | ((uint64_t)keep[kk].y << 32), qhi = (uint64_t)keep[kk].z | ((uint64_t)keep[kk].w << 32);
             uint32_t cm = sd.state == VS_ACTIVE ? (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu : 0u;
             uint64_t x = 0, x0 = 0; int nbytes = 0;
             if (cm) {
@@ -584,17 +601,27 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                 for (int q = 0; q < (chunk >> 1); q++) ci += __popc(s_cmask[s][q]);
                 if (chunk & 1) ci += __popc(s_cmask[s][chunk >> 1] & 0xFFFFu);
                 nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
-                for (int k = 0; k < nbytes; k++) x |= (uint64_t)os[k] << (8 * k);
+                x = ld8_unaligned(os);                                                  // (blobs are readable past a read's last byte)
+                if (nbytes < 8) x &= (1ull << (8 * nbytes)) - 1ull;
                 x0 = x;
                 for (; cm; cm &= cm - 1, ci++) {
-                    const int k = __ffs((int)cm) - 1, sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4);
+                    const int k = __ffs((int)cm) - 1, sh = 8 * (k >> 1) + ((k & 1) ? 0 : 4), qs = 8 * (k & 7);
                     x = (x & ~(0xFull << sh)) | ((uint64_t)(s_cb[ci] & 0xF) << sh);
-                    qq[k >> 2] = (qq[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)s_cq[ci] << (8 * (k & 3)));
+                    const uint64_t qm = 0xFFull << qs, qv = (uint64_t)s_cq[ci] << qs;
+                    if (k & 8) qhi = (qhi & ~qm) | qv; else qlo = (qlo & ~qm) | qv;
                 }
             }
             typedef uint64_t u64u __attribute__((aligned(1)));
-            if (nval == 16) { *(u64u *)oq = (uint64_t)qq[0] | ((uint64_t)qq[1] << 32); *(u64u *)(oq + 8) = (uint64_t)qq[2] | ((uint64_t)qq[3] << 32); }
-            else for (int k = 0; k < nval; k++) oq[k] = (uint8_t)(qq[k >> 2] >> (8 * (k & 3)));
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            typedef uint16_t u16u __attribute__((aligned(1)));
+            if (nval == 16) { *(u64u *)oq = qlo; *(u64u *)(oq + 8) = qhi; }
+            else {                                                                      // the side's last chunk: 8 + 4 + 2 + 1 bytes as needed, never past the read
+                uint64_t v = qlo; int o = 0;
+                if (nval & 8) { *(u64u *)oq = qlo; v = qhi; o = 8; }
+                if (nval & 4) { *(u32u *)(oq + o) = (uint32_t)v; v >>= 32; o += 4; }
+                if (nval & 2) { *(u16u *)(oq + o) = (uint16_t)v; v >>= 16; o += 2; }
+                if (nval & 1) oq[o] = (uint8_t)v;
+            }
             if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
         }
     }
