@@ -462,19 +462,20 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         };
         auto vote = [&](const Item &x) {
             if (!x.on) return;
-            int q = x.q, sc;
+            int q = x.q;
             const int nb = (x.col & 1) ? (x.sb & 0xF) : (x.sb >> 4);
-            if (x.cst) sc = p.s_moderate;                                               // pair.cpp:89-105
-            else if (x.inov) {
-                const int mn = (x.mc & 1) ? (x.mb & 0xF) : (x.mb >> 4);
-                if (nb == mn) sc = d_qual2score(p, ((q + x.mq) / 2) & 0xFF) + 4;
-                else {
-                    const bool left_wins = x.side ? (x.mq >= q) : (q >= x.mq);        // `if(lq >= rq)`: the left read keeps a score
-                    const int dq = max(0, q - x.mq);
-                    sc = (x.side == 0) ? (left_wins ? d_qual2score(p, dq) - 3 : 0) : (left_wins ? 0 : d_qual2score(p, dq) - 3);
-                    q = dq;                                                             // the rewritten quality is what the vote sees
-                }
-            } else sc = d_qual2score(p, q);
+            // the three score rules without branches (pair.cpp:89-105 constant; :140-150 match; :151-168 mismatch): one qual2score of the
+            // quality each rule looks at, then the rule's offset
+            const int mn = (x.mc & 1) ? (x.mb & 0xF) : (x.mb >> 4);
+            const bool match = x.inov && nb == mn, mism = x.inov && nb != mn;
+            const bool left_wins = x.side ? (x.mq >= q) : (q >= x.mq);                // `if(lq >= rq)`: the left read keeps a score
+            const int dq = max(0, q - x.mq);
+            const int qlook = match ? (((q + x.mq) / 2) & 0xFF) : mism ? dq : q;
+            const bool scored = !mism || (x.side == 0 ? left_wins : !left_wins);        // the mismatch loser scores 0
+            int sc = d_qual2score(p, qlook) + (match ? 4 : mism ? -3 : 0);
+            sc = scored ? sc : 0;
+            sc = x.cst ? p.s_moderate : sc;
+            q = mism ? dq : q;                                                          // the rewritten quality is what the vote sees
             const int bin = (int)((uint32_t)(0x4777777377727107ull >> (nb * 4)) & 7u);        // A,C,G,T,N -> 0..4, anything else 7
             if (bin == 7 || (q & 0x80)) s_gflag[x.grp] = 2;
             else {
