@@ -45,6 +45,13 @@
 
 struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
 static_assert(sizeof(VRead) == 32, "VRead must stay 32 bytes");
+// the second 16 bytes of a VRead (everything but the two blob offsets) with ONE LDS load
+struct VTail { uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };
+__device__ __forceinline__ VTail vr_tail(const VRead *r) {
+    union { uint4 q; VTail t; } u;
+    u.q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(r) + 16);
+    return u.t;
+}
 struct VOv { uint16_t ls, rs, cmp, fl; };                   // fl: 1 = every score of the pair is the constant (pair.cpp:89-105), 2 = overlap [ls|rs, +cmp)
 enum : uint8_t { VS_FINAL = 0, VS_ACTIVE = 1, VS_GEN = 2, VS_RESTORE = 3 };
 struct __attribute__((aligned(8))) VSide {
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             } else {
                 uint32_t hm = 0, single = 0; int pmin = 0x7FFFFFFF, pmax = -0x7FFFFFFF;
                 for (int k = 0; k < np; k++) {
-                    const VRead r = rds[k];
+                    const VTail r = vr_tail(rds + k);
                     if (r.rd != NONE32) { hm |= 1u << k; if (r.nc == 1 && cig_op(r.c0) == 0) single |= 1u << k; pmin = min(pmin, r.pos); pmax = max(pmax, r.pos); }
                 }
                 if (hm != 0) {
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                     // 2-/3-op CIGAR and nothing else.
                     const bool multi = single == 0;
                     const int fl = multi ? __ffs((int)hm) - 1 : __ffs((int)single) - 1;
-                    const VRead t = rds[fl];
+                    const VTail t = vr_tail(rds + fl);
                     uint32_t o_cw1 = 0, o_cw2 = 0;
                     if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
                     const int len = t.lq;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                     uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1 || (ralign && multi);
                     for (int k = 0; k < np; k++) {
                         if (!((hm >> k) & 1u)) continue;
-                        const VRead r = rds[k];
+                        const VTail r = vr_tail(rds + k);
                         uint32_t cw1 = 0, cw2 = 0;
                         if (multi && r.nc >= 2 && r.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[r.rd]; cw1 = cg[1]; if (r.nc == 3) cw2 = cg[2]; }
                         const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq && (!ralign || r.pos == t.pos);
