@@ -615,6 +615,11 @@ int gce_process(gce_engine *e) {
         fprintf(stderr, "k_vote phases, mean per block (100 MHz ticks -> us), %.0f blocks:", blocks);
         for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
         fprintf(stderr, "\n");
+        static const char *pn[8] = {"windows", "name sort", "pairs", "umi words", "umi sort", "grouping", "layout sort", "layout write"};
+        const double cl = (double)hs.prof[30];
+        fprintf(stderr, "k_pairing_deep phases, mean per cluster (us), %.0f clusters:", cl);
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f;", pn[k], cl ? hs.prof[16 + k] / cl / 100.0 : 0.0);
+        fprintf(stderr, "\n");
     }
 #endif
     if (N > 0 && e->dev_error == 0) hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);

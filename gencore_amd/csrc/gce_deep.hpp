@@ -265,6 +265,11 @@ __device__ __forceinline__ uint32_t pd_scan(uint32_t v, uint32_t *s_w, int tid, 
     return base + inc - v;
 }
 
+#ifdef VB_PROF
+#define PD_TICK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[16 + (k)], now_ - pd_prev_); pd_prev_ = now_; } } while (0)
+#else
+#define PD_TICK(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, Work w) {
     __shared__ uint64_t s_key[PD_MAX][2];        // name windows of the reads, then UMI words of the pairs, then (u32) layout keys
     __shared__ uint16_t s_perm[PD_MAX];
@@ -297,6 +302,10 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         if (!take || s_flag) { if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }
         const uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
         if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } continue; }
+#ifdef VB_PROF
+        unsigned long long pd_prev_ = wall_clock64();
+        if (threadIdx.x == 0) atomicAdd(&w.si->prof[30], 1ull);
+#endif
         const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
         uint32_t *s_rd = s_x; uint32_t *s_qo = s_x + PD_MAX;
         uint16_t *s_dfirst = reinterpret_cast<uint16_t *>(s_x), *s_dcnt = s_dfirst + PD_MAX, *s_dgrp = s_dcnt + PD_MAX;
@@ -337,6 +346,9 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             } else s_perm[i] = PD_NONE16;
         }
         __syncthreads();
+        // The sort proper looks at LDS only: (window, read index).  Reads with equal windows (mates, as a rule) come out as one run in
+        // arrival order; a run that holds different names behind the window -- rare -- is put right afterwards by one lane, with the
+        // rest of the names compared 8 bytes at a time (inside the comparator those global loads were 60 % of the sort).
         auto name_less = [&](uint16_t a, uint16_t c2) -> bool {
             if (c2 == PD_NONE16) return a != PD_NONE16;
             if (a == PD_NONE16) return false;
@@ -344,10 +356,37 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             if (a0 != c0) return a0 < c0;
             const uint64_t a1 = s_key[a][1], c1 = s_key[c2][1];
             if (a1 != c1) return a1 < c1;
-            const int cmp = pd_rest_cmp(qbase + (int32_t)s_qo[a], (int)s_rest[a], qbase + (int32_t)s_qo[c2], (int)s_rest[c2]);        // the rest of the two names
-            return cmp < 0 || (cmp == 0 && s_rd[a] < s_rd[c2]);
+            return s_rd[a] < s_rd[c2];
         };
+        PD_TICK(0);
         pd_bitonic(s_perm, P, tid, name_less);
+        {
+            int toolong = 0;
+            for (int sidx = tid; sidx < (int)n; sidx += PD_T) {
+                const uint16_t m = s_perm[sidx];
+                const bool head = sidx == 0 || s_key[s_perm[sidx - 1]][0] != s_key[m][0] || s_key[s_perm[sidx - 1]][1] != s_key[m][1];
+                if (!head || s_rest[m] == 0) continue;                              // (a name that ends inside the window has no rest: equal windows = equal names)
+                int r = 1;
+                while (sidx + r < (int)n && s_key[s_perm[sidx + r]][0] == s_key[m][0] && s_key[s_perm[sidx + r]][1] == s_key[m][1]) r++;
+                if (r < 2) continue;
+                if (r > 32) { toolong = 1; continue; }
+                for (int x = 1; x < r; x++) {                                       // insertion sort of the run by (rest of the name, read index)
+                    const uint16_t e = s_perm[sidx + x];
+                    int y = x - 1;
+                    for (; y >= 0; y--) {
+                        const uint16_t o = s_perm[sidx + y];
+                        const int cmp = pd_rest_cmp(qbase + (int32_t)s_qo[o], (int)s_rest[o], qbase + (int32_t)s_qo[e], (int)s_rest[e]);
+                        if (cmp < 0 || (cmp == 0 && s_rd[o] < s_rd[e])) break;
+                        s_perm[sidx + y + 1] = o;
+                    }
+                    s_perm[sidx + y + 1] = e;
+                }
+            }
+            if (toolong) s_flag = 1;
+        }
+        __syncthreads();
+        if (s_flag) { __syncthreads(); if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }   // hundreds of names behind one window: generic kernels
+        PD_TICK(1);
         // ---- 2. pairs
         const int per = (P + PD_T - 1) / PD_T;                                     // sorted positions per thread (contiguous)
         uint32_t firsts = 0;
@@ -398,6 +437,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         __syncthreads();
         any_umi = s_flag;
         __syncthreads();
+        PD_TICK(2);
         // ---- 3. UMI grouping
         uint32_t ngroups = 1;
         if (!any_umi) { for (uint32_t i = tid; i < npairs; i += PD_T) s_pd[i] = 0; }
@@ -423,7 +463,9 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                 if (a1 != c1) return a1 < c1;
                 return a < c2;
             };
+            PD_TICK(3);
             pd_bitonic(s_perm, P2, tid, umi_less);
+            PD_TICK(4);
             const int per2 = (P2 + PD_T - 1) / PD_T;
             uint32_t heads = 0;
             for (int u = 0; u < per2; u++) {
@@ -489,6 +531,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             for (uint32_t i = tid; i < npairs; i += PD_T) s_pd[i] = s_dgrp[s_pd[i]];
         }
         __syncthreads();
+        PD_TICK(5);
         // ---- 4. layout: group by group, qname order kept inside a group (Group::addPair, group.cpp:17-22)
         {
             int P3 = 128; while (P3 < (int)npairs) P3 <<= 1;
@@ -496,19 +539,20 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             for (int i = tid; i < P3; i += PD_T) { lk[i] = i < (int)npairs ? ((uint32_t)s_pd[i] << 16 | (uint32_t)i) : 0xFFFFFFFFu; }
             __syncthreads();
             pd_bitonic(lk, P3, tid, [](uint32_t a, uint32_t c2) { return a < c2; });
+            PD_TICK(6);
             for (uint32_t sidx = tid; sidx < npairs; sidx += PD_T) {
                 const uint32_t key = lk[sidx], g = key >> 16, i = key & 0xFFFFu;
                 w.gpl[start + sidx] = w.members[start + s_pl[i]];
                 w.gpr[start + sidx] = s_pr[i] != PD_NONE16 ? w.members[start + s_pr[i]] : NONE32;
-                const bool head = sidx == 0 || (lk[sidx - 1] >> 16) != g;
-                if (head) {
-                    w.grp_begin[start + g] = start + sidx;
-                    uint32_t e2 = sidx + 1;                                       // group sizes: walk to the end of the run (heads are few)
-                    while (e2 < npairs && (lk[e2] >> 16) == g) e2++;
-                    w.grp_n[start + g] = e2 - sidx;
-                }
+                if (sidx == 0 || (lk[sidx - 1] >> 16) != g) { w.grp_begin[start + g] = start + sidx; s_pd[g] = (uint16_t)sidx; }   // (s_pd is free again: group -> first position)
+            }
+            __syncthreads();
+            for (uint32_t sidx = tid; sidx < npairs; sidx += PD_T) {
+                const uint32_t g = lk[sidx] >> 16;
+                if (sidx + 1 == npairs || (lk[sidx + 1] >> 16) != g) w.grp_n[start + g] = sidx + 1 - (uint32_t)s_pd[g];
             }
         }
+        PD_TICK(7);
         if (tid == 0) {
             const bool cross = d_key(b.core[w.members[start]], p).right < 0;
             w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0));

@@ -77,7 +77,7 @@ struct StreamInfo {
     int n_events;                        // E: flush events inside this slice
     int n_events_a;                      // E_A: events whose read index < U
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
-    unsigned long long prof[16];         // -DVB_PROF builds only: accumulated phase times of k_vote (tools/vote_prof.sh)
+    unsigned long long prof[32];         // -DVB_PROF builds only: accumulated phase times of k_vote (tools/vote_prof.sh)
     unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
