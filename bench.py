@@ -107,12 +107,15 @@ def main():
     ap.add_argument("--bed-targets", type=int, default=None, help="override the number of BED targets of cfg3 (0 = molecules spread uniformly)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--test-one-gpu", action="store_true", help="testing aid: every rank uses cuda:0 and torch.distributed runs over gloo, so the N > 1 code path (one stream cut into key ranges, ticks + flush events, Stats all-reduce) can be exercised on a 1-GPU box")
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.test_one_gpu:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -120,7 +123,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.test_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     workload = args.workload or ("cfg3" if world == 1 else "cfg4s")
 
     import __graft_entry__ as ge
