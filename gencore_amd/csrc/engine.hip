@@ -498,6 +498,7 @@ int gce_process(gce_engine *e) {
     HIPCHK(hipEventRecord(e->ev[EV_START], s));
     HIPCHK(hipMemsetAsync(e->table.p, 0, T * sizeof(TabEntry), s));
     HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
+    HIPCHK(hipMemsetAsync(e->chunk_cnt.p, 0, (size_t)(n_chunks + 1) * 4, s));
     if (N > 0) {
         // ---- prescan + tick scan + flush events (the latter two come with the batch for key-range shards)
         int cpb = (int)((n_chunks + 32767) / 32768); if (cpb < 1) cpb = 1;

@@ -80,7 +80,6 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
 
 // ===================================================================================================== prescan
 __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, Work w, int chunks_per_block) {
-    __shared__ unsigned int s_cnt[WAVES_PER_BLOCK];
     __shared__ long long s_stat[WAVES_PER_BLOCK][6];
     __shared__ unsigned int s_unm[WAVES_PER_BLOCK];
     long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
@@ -125,10 +124,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, W
             }
         }
         unsigned long long m = __ballot(c == CLS_CLUSTERED);
-        if (lane == 0) s_cnt[wv] = __popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) w.chunk_cnt[chunk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        __syncthreads();
+        if (lane == 0 && m) atomicAdd(&w.chunk_cnt[chunk], (unsigned int)__popcll(m));   // (cleared by a memset: no barrier between the chunks of a block)
     }
     for (int k = 0; k < 6; k++) { long long v = wave_sum64(st[k]); if (lane == 0) s_stat[wv][k] = v; }
     unsigned int fu = (unsigned)wave_min((int)(first_unm ^ 0x80000000u)) ^ 0x80000000u;   // unsigned min via signed flip
