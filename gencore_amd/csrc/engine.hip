@@ -465,7 +465,7 @@ int gce_process(gce_engine *e) {
     w.tsize = T; w.tinv = 1.0 / (double)T;
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
-    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDesc)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
+    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
     ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
     ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
@@ -476,7 +476,7 @@ int gce_process(gce_engine *e) {
     ENS(deep_list, (n1 / 64 + 64) * 16); w.deep_list = e->deep_list.p;
     const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, (size_t)(nblk_T > 2 * nblk_N ? nblk_T : 2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
-    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDesc>(); w.spatch = e->spatch.as<uint32_t>();
+    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
     w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();

@@ -50,25 +50,6 @@ struct DevParams {
     const int64_t *ref_len;           // [n_ref]
 };
 
-// Per-read descriptor written once by the thread-per-read prescan: everything the per-pair / per-group kernels need about a
-// read in ONE 48-byte record (three 16-byte loads) instead of the dependent chain core -> offsets -> first CIGAR word.
-struct __attribute__((aligned(16))) ReadDesc {
-    uint64_t so, qo;          // byte offsets of the packed bases / quals
-    uint32_t c0;              // first CIGAR word (0 if none)
-    int32_t pos, lq, isize;
-    int32_t mo, ml;           // BamUtil::getMOffsetAndLen: first M block (bamutil.cpp:316-336)
-    uint16_t nc; uint16_t tid16; int32_t rlen; // n_cigar; tid (0xFFFF = read it from the core record); bam_cigar2rlen
-};
-
-// three 16-byte loads instead of a dozen field loads
-__device__ __forceinline__ ReadDesc load_desc(const ReadDesc *base, uint32_t i) {
-    union { ReadDesc d; uint4 q[3]; } u;
-    const uint4 *src = reinterpret_cast<const uint4 *>(base + i);
-    u.q[0] = src[0]; u.q[1] = src[1]; u.q[2] = src[2];
-    return u.d;
-}
-static_assert(sizeof(ReadDesc) == 48, "ReadDesc must stay 48 bytes");
-
 // stream-level scalars produced by the prescan (device resident)
 struct StreamInfo {
     unsigned long long n_clustered;      // number of clustered reads (ticks)
@@ -107,6 +88,45 @@ __device__ __forceinline__ int cig_len(uint32_t w) { return (int)(w >> 4); }
 // bam_cigar_type bit0 = consumes query, bit1 = consumes reference; ops 10..15 consume nothing (bamutil.cpp:290-291)
 __device__ __forceinline__ int consumes_query(int op) { return (0x193 >> op) & 1; }   // M I S = X  -> bits 0,1,4,7,8
 __device__ __forceinline__ int consumes_ref(int op) { return (0x18D >> op) & 1; }     // M D N = X  -> bits 0,2,3,7,8
+
+// Per-read descriptor written once by the thread-per-read prescan: everything the per-pair / per-group kernels need about a
+// read in ONE 32-byte record (two 16-byte loads) instead of the dependent chain core -> offsets -> first CIGAR word.
+// In memory (ReadDescP): offsets, first CIGAR word, position with "isize != 0" in the sign bit (clustered reads are mapped: pos >= 0),
+// read length, first M block, op count -- 16-bit fields, reads longer than 65535 bases are rejected by the prescan.
+// Round 1 kept 48 bytes (tid, isize, reference length as well): 320 MB of writes and as many reads per 20 M reads for fields that the
+// template of a side alone needs (tid: its core record) or that follow from the first CIGAR word (reference length of a one-op read).
+struct __attribute__((aligned(16))) ReadDescP {
+    uint64_t so, qo;
+    uint32_t c0;
+    uint32_t pos_fl;          // pos | (isize != 0) << 31
+    uint16_t lq, mo, ml, nc;
+};
+static_assert(sizeof(ReadDescP) == 32, "ReadDescP must stay 32 bytes");
+struct ReadDesc {             // the unpacked form the kernels work with
+    uint64_t so, qo;          // byte offsets of the packed bases / quals
+    uint32_t c0;              // first CIGAR word (0 if none)
+    int32_t pos, lq, isize;   // isize: only "is it zero" survives (1 / 0)
+    int32_t mo, ml;           // BamUtil::getMOffsetAndLen: first M block (bamutil.cpp:316-336)
+    uint16_t nc; uint16_t tid16; int32_t rlen; // n_cigar; tid16 = 0xFFFF: read the tid from the core record; rlen = bam_cigar2rlen of a ONE-op read, else RLEN_WALK
+};
+#define RLEN_WALK (-0x40000000)     // more than one CIGAR op: d_cigar_rlen over the CIGAR (desc_rlen)
+__device__ __forceinline__ void store_desc(ReadDescP *base, uint64_t i, uint64_t so, uint64_t qo, uint32_t c0, int32_t pos, bool isize_nz, int lq, int mo, int ml, int nc) {
+    union { ReadDescP d; uint4 q[2]; } u;
+    u.d.so = so; u.d.qo = qo; u.d.c0 = c0; u.d.pos_fl = (uint32_t)pos | (isize_nz ? 0x80000000u : 0u);
+    u.d.lq = (uint16_t)lq; u.d.mo = (uint16_t)mo; u.d.ml = (uint16_t)ml; u.d.nc = (uint16_t)nc;
+    uint4 *dst = reinterpret_cast<uint4 *>(base + i); dst[0] = u.q[0]; dst[1] = u.q[1];
+}
+__device__ __forceinline__ ReadDesc load_desc(const ReadDescP *base, uint32_t i) {
+    union { ReadDescP d; uint4 q[2]; } u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(base + i);
+    u.q[0] = src[0]; u.q[1] = src[1];
+    ReadDesc r;
+    r.so = u.d.so; r.qo = u.d.qo; r.c0 = u.d.c0; r.pos = (int32_t)(u.d.pos_fl & 0x7FFFFFFFu); r.isize = (int32_t)(u.d.pos_fl >> 31);
+    r.lq = u.d.lq; r.mo = u.d.mo; r.ml = u.d.ml; r.nc = u.d.nc; r.tid16 = 0xFFFF;
+    r.rlen = u.d.nc == 1 ? (int32_t)(cig_len(u.d.c0) * consumes_ref(cig_op(u.d.c0))) : (u.d.nc == 0 ? 0 : RLEN_WALK);
+    return r;
+}
+
 
 // BamUtil::isPartOf (bamutil.cpp:204-255): op-by-op containment, from the end when right aligned.
 __device__ inline bool d_is_part_of(const uint32_t *part, int np, const uint32_t *whole, int nw, bool left) {

@@ -27,7 +27,7 @@ struct Work {
     // per read
     uint8_t *cls;
     const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
-    ReadDesc *rdesc;
+    ReadDescP *rdesc;
     uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
     uint32_t *slot, *rank;
     int8_t *score;                       // parallel to qual
@@ -106,13 +106,13 @@ __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, W
             w.cls[i] = c;
             if (c == CLS_BYPASS) w.out_flag[i] = 2;                            // (out_flag is cleared by a memset; nothing else is initialised per read)
             if (c == CLS_CLUSTERED) {
-                ReadDesc d;
-                d.so = b.seq_off[i]; d.qo = b.qual_off[i]; d.pos = k.pos; d.lq = k.l_qseq; d.isize = k.isize; d.nc = k.n_cigar; d.tid16 = (uint16_t)((uint32_t)k.tid < 0xFFFFu ? k.tid : 0xFFFF);
                 const uint32_t *cg = b.cigar + b.cigar_off[i];
-                d.c0 = k.n_cigar ? cg[0] : 0;
-                if (k.n_cigar == 1) { int op = cig_op(d.c0), ln = cig_len(d.c0); d.mo = 0; d.ml = op == 0 ? ln : 0; d.rlen = ln * consumes_ref(op); }
-                else { int mo_, ml_; d_first_m(cg, k.n_cigar, mo_, ml_); d.mo = mo_; d.ml = ml_; d.rlen = d_cigar_rlen(cg, k.n_cigar); }
-                { union { ReadDesc d; uint4 q[3]; } u; u.d = d; uint4 *dst = reinterpret_cast<uint4 *>(w.rdesc + i); dst[0] = u.q[0]; dst[1] = u.q[1]; dst[2] = u.q[2]; }
+                const uint32_t c0w = k.n_cigar ? cg[0] : 0;
+                int mo_ = 0, ml_ = 0;
+                if (k.n_cigar == 1) ml_ = cig_op(c0w) == 0 ? cig_len(c0w) : 0;
+                else d_first_m(cg, k.n_cigar, mo_, ml_);
+                if (k.l_qseq > 65535) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)i);      // the 16-bit fields of the descriptor (and of the overlap patches)
+                store_desc(w.rdesc, (uint64_t)i, b.seq_off[i], b.qual_off[i], c0w, k.pos, k.isize != 0, k.l_qseq, mo_, ml_, k.n_cigar);
             }
             if (c == CLS_CLUSTERED) {                                          // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38
                 const char *src; uint8_t hm = 0;
@@ -1188,7 +1188,7 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
             if (rd == NONE32) return;
             has = true;
             const ReadDesc d = load_desc(w.rdesc, rd);
-            n_ = d.nc; rr_ = is_left ? 0 : d.pos + d.rlen;
+            n_ = d.nc; rr_ = is_left ? 0 : d.pos + (d.rlen != RLEN_WALK ? d.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], d.nc));
             if (n_ == 1) w0 = d.c0;
             else if (n_ >= 2 && n_ <= 4) {                                     // oriented: i-th op from the compared end (bamutil.cpp:213-218)
                 const uint32_t *cg = b.cigar + b.cigar_off[rd];
@@ -1664,7 +1664,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     if (has) {
         patch = w.spatch[rd];
         const ReadDesc k = load_desc(w.rdesc, rd);
-        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + k.rlen; tid16 = k.tid16;
+        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + (k.rlen != RLEN_WALK ? k.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], k.nc)); tid16 = k.tid16;
         if ((nc > 1 || (nc == 1 && cig_op(c0) != 0))) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
     }
     const unsigned long long hmask = __ballot(has);

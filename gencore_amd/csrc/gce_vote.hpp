@@ -134,7 +134,6 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
     __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
-    __shared__ uint16_t s_tid[2][VB_MAXP];
     __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index inside the group), ascending
     __shared__ __attribute__((aligned(8))) uint32_t s_tal[VB_CCAP][5][2];          // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
                                                                                    // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         VRead vl, vr;
         vl.so = lk.so; vl.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
         vr.so = rk.so; vr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
-        s_rd[0][tid] = vl; s_rd[1][tid] = vr; s_tid[0][tid] = lk.tid16; s_tid[1][tid] = rk.tid16;
+        s_rd[0][tid] = vl; s_rd[1][tid] = vr;
         VOv ov; ov.ls = 0; ov.rs = 0; ov.cmp = 0; ov.fl = 0;
         if (L == NONE32 || R == NONE32 || !(lk.ml > 0 && rk.ml > 0)) ov.fl = 1;        // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
         else {
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                         sd.state = VS_ACTIVE; sd.vmask = vm; sd.tmpl = (uint8_t)fl; sd.nvot = (uint8_t)nvot; sd.len = (uint16_t)len;
                         sd.o_pos = t.pos; sd.o_c0 = t.c0; sd.o_nc = t.nc; sd.result = t.rd;
                         if (t.fl & 1) {                                                 // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
-                            const int t16 = s_tid[side][lp0 + fl], o_tid = t16 != 0xFFFF ? t16 : b.core[t.rd].tid;
+                            const int o_tid = b.core[t.rd].tid;                         // (the template's contig: one load per side)
                             if (o_tid >= 0 && o_tid < p.n_ref) {
                                 const uint8_t *rdp = p.ref_data[o_tid];
                                 const int64_t rl = p.ref_len[o_tid];
