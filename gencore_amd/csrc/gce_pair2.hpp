@@ -104,24 +104,53 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     const bool first = act2 && !(EQ & LOW), last = act2 && !(EQ & ~LOW);
     const uint32_t FIRST = sub_ballot<SUB>(first, hb);
     const uint32_t npairs = __popc(FIRST);
-    // ---- std::map order: lexicographic compares only against the first read of every OTHER name
+    // ---- std::map order: lexicographic compares only against the first read of every OTHER name.
+    //      The names of a cluster share a long prefix (instrument, run, lane, often the tile): the 8 bytes behind the cluster's common
+    //      prefix, one big-endian word per read, decide nearly every comparison -- one broadcast per other name instead of one per
+    //      name WORD.  Names whose order words tie (they differ later, or one is a prefix of the other) take the full compare.
     uint32_t LT = 0;
     {
+        int cpb = 64;                                       // bytes my name shares with the half's first read
+#pragma unroll
+        for (int k = 7; k >= 0; k--) if (k < nwords) { const uint64_t x = shfl64(nw[k], hb) ^ nw[k]; if (x) cpb = 8 * k + (__clzll((long long)x) >> 3); }
+        cpb = act2 ? cpb : 64;
+        int cp = -sub_max<SUB>(-cpb);                       // common prefix of the half (64: every name equal)
+        cp = min(cp, 56);
+        uint64_t okey;                                      // name bytes [cp, cp + 8)
+        {
+            const int wi = cp >> 3, sh = 8 * (cp & 7);
+            uint64_t a = 0, c2 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { if (k == wi) a = nw[k]; if (k == wi + 1) c2 = nw[k]; }
+            okey = sh ? ((a << sh) | (c2 >> (64 - sh))) : a;
+        }
         const int itmax = wave_max((int)npairs);
-        uint32_t fm = FIRST;
+        uint32_t fm = FIRST, TIE = 0;
         for (int it = 0; it < itmax; it++) {
             const bool has = fm != 0;
             const int j = has ? __ffs((int)fm) - 1 : hl;
             fm &= fm - 1;
-            int cmp = 0;                                    // sign of name_j - name_mine
+            const uint64_t o = shfl64(okey, hb + j);
+            if (has && o < okey) LT |= 1u << j;
+            if (has && o == okey && !((EQ >> j) & 1u) && j != hl) TIE |= 1u << j;      // another name with my order word
+        }
+        if (__any(act2 && TIE != 0)) {                      // (rare) settle the ties on the whole names
+            const int rounds = wave_max(__popc(TIE));
+            uint32_t tm = act2 ? TIE : 0u;
+            for (int it = 0; it < rounds; it++) {
+                const bool has = tm != 0;
+                const int j = has ? __ffs((int)tm) - 1 : hl;
+                tm &= tm - 1;
+                int cmp = 0;                                // sign of name_j - name_mine
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k < nwords) {
-                    const uint64_t o = shfl64(nw[k], hb + j);
-                    if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
+                for (int k = 0; k < 8; k++) {
+                    if (k < nwords) {
+                        const uint64_t o = shfl64(nw[k], hb + j);
+                        if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
+                    }
                 }
+                if (has && cmp < 0) LT |= 1u << j;
             }
-            if (has && cmp < 0) LT |= 1u << j;
         }
     }
     const uint32_t pidx = __popc(LT);                       // distinct names before mine
