@@ -811,19 +811,42 @@ __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, cons
     const bool first = act && !(EQ & LOW), last = act && !(EQ & ~LOW);
     const unsigned long long FIRST = __ballot(first);
     const uint32_t npairs = __popcll(FIRST);
-    // ---- map<string,Pair*> order: full lexicographic compares only against the first read of every OTHER name
+    // ---- map<string,Pair*> order: compares only against the first read of every OTHER name, and on ONE word: the 8 name bytes behind
+    //      the cluster's common prefix decide nearly every comparison (the names share instrument / run / lane / tile); names whose
+    //      order words tie take the full compare
     unsigned long long LT = 0;
-    for (unsigned long long fm = FIRST; fm; fm &= fm - 1) {
-        const int j = __ffsll((long long)fm) - 1;
-        int cmp = 0;                                        // sign of name_j - name_mine
+    {
+        int cpb = 64;                                       // bytes my name shares with the cluster's first read
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k < nwords) {
-                uint64_t o = rl64(nw[k], j);
-                if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
-            }
+        for (int k = 7; k >= 0; k--) if (k < nwords) { const uint64_t x = rl64(nw[k], 0) ^ nw[k]; if (x) cpb = 8 * k + (__clzll((long long)x) >> 3); }
+        const int cp = min(wave_min(act ? cpb : 64), 56);
+        uint64_t okey;
+        {
+            const int wi = cp >> 3, sh = 8 * (cp & 7);
+            uint64_t a = 0, c2 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { if (k == wi) a = nw[k]; if (k == wi + 1) c2 = nw[k]; }
+            okey = sh ? ((a << sh) | (c2 >> (64 - sh))) : a;
         }
-        if (cmp < 0) LT |= 1ull << j;
+        unsigned long long TIE = 0;
+        for (unsigned long long fm = FIRST; fm; fm &= fm - 1) {
+            const int j = __ffsll((long long)fm) - 1;
+            const uint64_t o = rl64(okey, j);
+            if (o < okey) LT |= 1ull << j;
+            if (o == okey && !((EQ >> j) & 1ull) && j != lane) TIE |= 1ull << j;
+        }
+        for (unsigned long long tm = __ballot(act && TIE != 0) ? FIRST : 0ull; tm; tm &= tm - 1) {      // (rare) ties: whole names, for the lanes that have one with j
+            const int j = __ffsll((long long)tm) - 1;
+            int cmp = 0;                                    // sign of name_j - name_mine
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < nwords) {
+                    uint64_t o = rl64(nw[k], j);
+                    if (cmp == 0) cmp = o < nw[k] ? -1 : (o > nw[k] ? 1 : 0);
+                }
+            }
+            if (((TIE >> j) & 1ull) && cmp < 0) LT |= 1ull << j;
+        }
     }
     const uint32_t pidx = __popcll(LT);                     // distinct names before mine
     // every read's UMI as big-endian words in registers (<= 24 bytes, checked above): no byte loops over global memory below
