@@ -786,10 +786,12 @@ __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, cons
     h32 ^= h32 >> 15;
     const unsigned long long ACT = __ballot(act);
     unsigned long long EQ = 0, LOW = 0;
-    for (int j = 0; j < (int)n; j++) {
+    for (unsigned long long todo = ACT; todo;) {             // one ballot per DISTINCT hash: a whole name class at a time
+        const int j = __ffsll((long long)todo) - 1;
         const uint32_t oh = (uint32_t)rl32((int)h32, j);
         const unsigned long long cls = __ballot(h32 == oh) & ACT;
         if (h32 == oh) EQ = cls;
+        todo &= ~cls;
     }
     EQ &= ~(1ull << lane);
     {   // exact verification of every hash match (all lanes run the shuffles)

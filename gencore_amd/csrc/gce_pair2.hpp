@@ -75,11 +75,16 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     h32 ^= h32 >> 15;
     const int nmax = wave_max(live ? (int)n : 0);
     uint32_t EQ = 0, LOW = 0;
-    for (int j = 0; j < nmax; j++) {
-        const uint32_t oh = (uint32_t)__shfl((int)h32, hb + j);
-        const bool same = act && j < (int)n && h32 == oh;
-        const uint32_t cls = sub_ballot<SUB>(same, hb);
-        if (same) EQ = cls;
+    {   // one ballot per DISTINCT hash of a half: a whole name class at a time (the halves run to the largest class count)
+        uint32_t todo = sub_ballot<SUB>(act, hb);
+        while (__any(todo != 0)) {
+            const int j = todo ? __ffs((int)todo) - 1 : hl;
+            const uint32_t oh = (uint32_t)__shfl((int)h32, hb + j);
+            const bool same = act && todo != 0 && h32 == oh;
+            const uint32_t cls = sub_ballot<SUB>(same, hb);
+            if (same) EQ = cls;
+            todo &= ~cls;
+        }
     }
     EQ &= ~(1u << hl);
     {   // exact verification of every hash match, arrival order inside the class (all lanes run the shuffles)
