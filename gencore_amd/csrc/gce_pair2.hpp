@@ -206,17 +206,26 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
         const bool grp = any_umi;                           // (a half without UMIs keeps its single group)
         int cnt = 0, urank = 0;                             // umiCount[umi], and the rank of my UMI in std::string order
-        const int pmax = wave_max(grp ? (int)npairs : 0);
         const bool one_word = wave_max(ulen) <= 8;
-        for (int q = 0; q < pmax; q++) {
-            const bool in = q < (int)npairs;
-            const uint64_t a0 = shfl64(uw[0], hb + q); const int al = __shfl(ulen, hb + q);
-            if (one_word) { cnt += (in && a0 == uw[0] && al == ulen); urank += (in && (a0 != uw[0] ? a0 < uw[0] : al < ulen)); }
-            else {
-                const uint64_t a1 = shfl64(uw[1], hb + q), a2 = shfl64(uw[2], hb + q);
-                const bool eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
-                const bool lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
-                cnt += (in && eq); urank += (in && lt);
+        {   // one round per DISTINCT UMI of a half: its pairs learn their count, the pairs with a larger UMI add it to their rank
+            uint32_t todo = sub_ballot<SUB>(pact, hb);
+            if (!grp) todo = 0u;
+            while (__any(todo != 0)) {
+                const bool open = todo != 0;
+                const int q = open ? __ffs((int)todo) - 1 : hl;
+                const uint64_t a0 = shfl64(uw[0], hb + q); const int al = __shfl(ulen, hb + q);
+                bool eq, lt;
+                if (one_word) { eq = a0 == uw[0] && al == ulen; lt = a0 != uw[0] ? a0 < uw[0] : al < ulen; }
+                else {
+                    const uint64_t a1 = shfl64(uw[1], hb + q), a2 = shfl64(uw[2], hb + q);
+                    eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
+                    lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
+                }
+                const uint32_t cls = sub_ballot<SUB>(open && pact && eq, hb);
+                const int sz = __popc(cls);
+                if (open && pact && eq) cnt = sz;
+                if (open && pact && lt) urank += sz;
+                todo &= ~cls;
             }
         }
         if (grp) { g_of = NONE32; ngroups = 0; }
