@@ -899,17 +899,24 @@ __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, cons
             if (!pact) ulen = 0;
         }
         int cnt = 0, urank = 0;                              // umiCount[umi], and the rank of my UMI in std::string order
-        if (wave_max(ulen) <= 8) {                           // every UMI fits the first word (the usual 6-8 bp barcode)
-            for (int q = 0; q < (int)npairs; q++) {
+        {   // one round per DISTINCT UMI: its pairs learn their count, the pairs with a larger UMI add it to their rank
+            const bool one_word = wave_max(ulen) <= 8;       // every UMI fits the first word (the usual 6-8 bp barcode)
+            for (unsigned long long todo = __ballot(pact); todo;) {
+                const int q = __ffsll((long long)todo) - 1;
                 const uint64_t a0 = rl64(uw[0], q); const int al = rl32(ulen, q);
-                cnt += (a0 == uw[0] && al == ulen); urank += (a0 != uw[0] ? a0 < uw[0] : al < ulen);
+                bool eq, lt;
+                if (one_word) { eq = a0 == uw[0] && al == ulen; lt = a0 != uw[0] ? a0 < uw[0] : al < ulen; }
+                else {
+                    const uint64_t a1 = rl64(uw[1], q), a2 = rl64(uw[2], q);
+                    eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
+                    lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
+                }
+                const unsigned long long cls = __ballot(pact && eq);
+                const int sz = __popcll(cls);
+                if (pact && eq) cnt = sz;
+                if (pact && lt) urank += sz;
+                todo &= ~cls;
             }
-        } else
-        for (int q = 0; q < (int)npairs; q++) {
-            uint64_t a0 = rl64(uw[0], q), a1 = rl64(uw[1], q), a2 = rl64(uw[2], q); int al = rl32(ulen, q);
-            bool eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
-            bool lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
-            cnt += eq; urank += lt;
         }
         g_of = NONE32; ngroups = 0;
         unsigned long long remaining = __ballot(pact);
