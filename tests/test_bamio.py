@@ -226,3 +226,43 @@ def test_bam_end_to_end(built, oracle, tmp_path, workload, n_pairs, chunk):
         assert (g["qname"], g["flag"], g["tid"], g["pos"], g["seq"], g["qual"]) == (e["qname"], e["flag"], e["tid"], e["pos"], e["seq"], e["qual"])
         assert g["aux"].get("FR", (None, -1))[1] == e["fr"] and g["aux"].get("RR", (None, -1))[1] == e["rr"]
         assert e["nm"] is None or g["aux"]["NM"][1] == e["nm"]
+
+
+@pytest.mark.gpu
+def test_bam_end_to_end_with_mi_tags(built, oracle, tmp_path):
+    """MI:Z tags carry the UMIs (src/bamutil.cpp:23-38): the reader hands them on, gce_run_bam takes the staged (not the reserved) submit
+    path for such files, and the output still equals the oracle's."""
+    from gencore_amd.bamio import run_bam
+    import random
+    rng = random.Random(11)
+    ref = "ACGT" * 500
+    recs = []
+    for m in range(30):
+        left = 100 + 37 * m
+        right = left + 200 + rng.randrange(30)
+        umi = "".join(rng.choice("ACGT") for _ in range(6))
+        for dpl in range(1 + rng.randrange(4)):
+            name = "m%02d_%d" % (m, dpl)
+            u = umi if rng.random() < 0.8 else umi[:5] + rng.choice("ACGT")
+            isz = right + 20 - left
+            ls, rs = ref[left:left + 20], ref[right:right + 20]
+            recs.append(dict(qname=name, flag=99, tid=0, pos=left, cigar="20M", mtid=0, mpos=right, isize=isz, seq=ls, qual=[rng.choice([37, 25, 11]) for _ in range(20)], nm=0, mi=u))
+            recs.append(dict(qname=name, flag=147, tid=0, pos=right, cigar="20M", mtid=0, mpos=left, isize=-isz, seq=rs, qual=[rng.choice([37, 25, 11]) for _ in range(20)], nm=0, mi=u))
+    recs.sort(key=lambda r: r["pos"])
+    batch = ReadBatch.from_records(recs)
+    tl = np.asarray([len(ref)], np.uint32)
+    prm = default_params(n_targets=1, target_len=tl.ctypes.data, flush_period=40)
+    want = oracle.run(batch, prm, [(oracle.pack_reference(ref), len(ref))])
+    assert want.status == 0
+    src, out, fa = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "ref.fa")
+    pybam.write_bam(src, recs, [("c0", len(ref))])
+    open(fa, "w").write(">c0\n" + ref + "\n")
+    run = run_bam(src, out, default_params(flush_period=40), fasta=fa, threads=2, chunk_reads=50)
+    assert run.n_reads == batch.n and run.n_out == len(want.emitted())
+    assert bytes(run.pre) == bytes(want.pre) and bytes(run.post) == bytes(want.post)
+    _, _, got = pybam.read_bam(out)
+    key = lambda r: (r["tid"], r["pos"], r["qname"], r["flag"], r["seq"])
+    exp = sorted(({**r, "qname": r["qname"].rstrip("\0")} for r in want.records(batch)), key=key)
+    for g, e in zip(sorted(got, key=key), exp):
+        assert (g["qname"], g["flag"], g["pos"], g["seq"], g["qual"]) == (e["qname"], e["flag"], e["pos"], e["seq"], e["qual"])
+        assert g["aux"].get("FR", (None, -1))[1] == e["fr"] and g["aux"]["MI"][0] == "Z"
