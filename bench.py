@@ -301,7 +301,8 @@ def main():
             parity["first_diffs"] = diffs[:3]
         # all host cores: N independent processes on contiguous shards of the same sample cut where no cluster spans (the only way
         # the single-threaded reference scales), Stats merged and compared; wall time from a common start to the last result
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        from gencore_amd.shard import effective_cpus
+        cores = effective_cpus()                            # affinity mask capped by the cgroup CPU quota
         multi = None
         if cores > 1:
             import multiprocessing as mp

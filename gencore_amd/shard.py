@@ -199,3 +199,16 @@ def shard_contiguous(batch, bounds, rank, flush_period=10000):
     before, mine, total = int(cm[:lo].sum()), int(cm[lo:hi].sum()), int(cm.sum())
     ctx = dict(tick_offset=before, trailing_flush=int(total // flush_period > (before + mine) // flush_period))
     return slice_contiguous(batch, lo, hi), np.arange(lo, hi), ctx
+
+
+def effective_cpus():
+    """CPUs this process can actually use: affinity mask, capped by the cgroup-v2 CPU quota (a container may see 256 CPUs and own 16)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return n

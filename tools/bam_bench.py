@@ -15,6 +15,7 @@ import numpy as np  # noqa: E402
 
 from gencore_amd import capi, synth  # noqa: E402
 from gencore_amd.bamio import run_bam, write_batch_as_bam  # noqa: E402
+from gencore_amd.shard import effective_cpus  # noqa: E402
 
 
 def main():
@@ -60,7 +61,7 @@ def main():
     n_pairs = d.info["n_pairs"]
     in_bytes, out_bytes = os.path.getsize(src), os.path.getsize(out)
     unc = int(batch.seq.size + batch.qual.size + batch.qname.size + 4 * batch.cigar.size + 40 * batch.n)
-    res = dict(workload=args.workload, pairs=int(n_pairs), reads=int(batch.n), host_threads=(args.threads or os.cpu_count()),
+    res = dict(workload=args.workload, pairs=int(n_pairs), reads=int(batch.n), host_threads=(args.threads or min(effective_cpus(), 64)), visible_cpus=os.cpu_count(),
                in_bam_bytes=in_bytes, out_bam_bytes=out_bytes, uncompressed_bytes=unc, records_out=int(r.n_out),
                stage_s=dict(open=round(r.open_s, 4), open_read=round(r.read_s, 4), open_inflate=round(r.inflate_s, 4), open_index=round(r.index_s, 4), soa_fill_and_submit=round(r.submit_s, 4), process=round(r.process_s, 4), drain=round(r.drain_s, 4),
                             write=round(r.write_s, 4), total=round(r.total_s, 4)),
