@@ -444,7 +444,7 @@ int gce_process(gce_engine *e) {
     }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);
     p.n_targets = (int)e->target_len.size(); p.target_len = e->d_target_len.as<uint32_t>(); p.target_cum = e->target_len.empty() ? nullptr : e->d_target_cum.as<uint64_t>();
-    p.tick_offset = e->have_tick ? 0 : e->prm.tick_offset; p.trailing_flush = e->have_tick ? 0 : e->prm.trailing_flush;
+    p.tick_offset = e->have_tick ? 0 : e->prm.tick_offset; p.tick_epoch0 = p.tick_offset / p.period; p.tick_rem0 = (int32_t)(p.tick_offset % p.period); p.trailing_flush = e->have_tick ? 0 : e->prm.trailing_flush;
     {   // packed cluster key of the bucket table: bits of the largest tid and of the longest contig
         uint32_t mx = 1; for (uint32_t v : e->target_len) mx = std::max(mx, v);
         int bt = 1; while (bt < 31 && (1ll << bt) < (long long)std::max<size_t>(e->target_len.size(), 1)) bt++;
@@ -510,6 +510,16 @@ int gce_process(gce_engine *e) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
     if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)cdiv(n_chunks, CL_U)), dim3(CHUNK), 0, s, b, p, w);
+#ifdef CL_PROF
+    if (N > 0) {
+        StreamInfo hs; (void)hipStreamSynchronize(s); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
+        static const char *nm[6] = {"key records", "events + instance", "LDS leaders", "first CAS", "probe + count", "stores"};
+        const double blocks = (double)hs.prof[15];
+        fprintf(stderr, "k_cluster phases, mean per block (us), %.0f blocks:", blocks);
+        for (int k = 0; k < 6; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
     // ---- bucket offsets + compact cluster list.  cl_* arrays are sized by N (a cluster has >= 1 read).
     ENS(cl_slot, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);

@@ -44,6 +44,7 @@ struct DevParams {
     int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
     int32_t vote_ok, vote_accept_by_qual, s_min_lb;   // gce_vote.hpp: score constants in range; "top quality >= moderate" implies "score sum >= baseScoreReq"; smallest score
     int64_t tick_offset;
+    int64_t tick_epoch0; int32_t tick_rem0;   // tick_offset / period, tick_offset % period (host side: no 64-bit division in the scan)
     int32_t trailing_flush;
     int32_t n_ref;
     const uint8_t *const *ref_data;   // [n_ref] device pointers or nullptr

@@ -256,6 +256,11 @@ __device__ __forceinline__ unsigned long long d_tab_key(const ClusterKey &k, uin
 // dependent chains (key record -> flush events -> bucket probe -> CAS -> rank atomic) overlap their
 // memory round trips: the scan is bound by latency x occupancy, not by issue.
 #define CL_U 2
+#ifdef CL_PROF
+#define CL_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define CL_TICK(k) do { } while (0)
+#endif
 #define CL_LDS_SLOTS 1024          // LDS hash slots for the <= 512 distinct keys of a block
 __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, Work w) {
     __shared__ uint32_t s_slot[CL_LDS_SLOTS], s_cnt[CL_U * CHUNK], s_ik[CL_U * CHUNK], s_h[CL_U * CHUNK], s_base[CL_U * CHUNK];
@@ -266,7 +271,13 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
     const unsigned int first_unm = si->first_unmapped;
     const int n_ev_a = si->n_events_a, n_ev = si->n_events;
     const long long per = p.period;
+#ifdef CL_PROF
+    unsigned long long t_prev_ = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) atomicAdd(&w.si->prof[15], 1ull);
+#endif
     int64_t idx[CL_U]; bool cl[CL_U]; gce_core k[CL_U]; unsigned long long m[CL_U];
+    unsigned int cb = 0u;                                         // first of all loads: the event window below hangs on it
+    if (threadIdx.x < 8 * CL_U) { const int64_t ch = (int64_t)blockIdx.x * CL_U + (threadIdx.x >> 3); cb = (!b.tick && ch < w.n_chunks) ? w.chunk_base[ch] : 0u; }
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
         idx[u] = ((int64_t)blockIdx.x * CL_U + u) * CHUNK + threadIdx.x;
@@ -275,6 +286,25 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
         if (idx[u] < b.n) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + idx[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
         k[u] = t.c;
     }
+    // The flush events a chunk's reads can ask for, fetched NOW by 16 lanes of the first wave (in flight together with the key
+    // records) and handed over in LDS: the 256 reads of a chunk carry consecutive ticks, so their own epochs are E or E + 1 and
+    // the three probes of every read fall into the four events [jb, jb + 3].  Fetched per read after the key record, chunk base ->
+    // tick -> event was two more dependent round trips (4.8 of the 18.5 us a block lives).  Reads the window misses (the segment
+    // behind the first unmapped read, periods shorter than a chunk, ticks handed in with the batch) load their events themselves.
+    int *s_win = reinterpret_cast<int *>(s_base);                // [CL_U][8]: ev_tid[jb..jb+3], ev_pos[jb..jb+3]  (s_base is written at the very end)
+    int *s_jb = s_win + 8 * CL_U;                                // [CL_U][3]: jb; epoch of the chunk's first tick (relative to the stream's first); its remainder
+    const int ev_last = max(n_ev - 1, 0);
+    if (threadIdx.x < 8 * CL_U) {
+        const int u = threadIdx.x >> 3, q = threadIdx.x & 3;
+        const unsigned long long t0 = (unsigned long long)(unsigned int)p.tick_rem0 + cb;      // ticks in front of the chunk, from the epoch boundary
+        const unsigned int uper = (unsigned int)per;
+        unsigned int E, r;
+        if ((t0 >> 32) == 0) { E = (unsigned int)t0 / uper; r = (unsigned int)t0 - E * uper; }
+        else { E = (unsigned int)(t0 / uper); r = (unsigned int)(t0 - (unsigned long long)E * uper); }
+        const int jb = max(min((int)E, n_ev_a) - 1, 0), j = min(jb + q, ev_last);
+        s_win[threadIdx.x] = (threadIdx.x & 4) ? w.ev_pos[j] : w.ev_tid[j];
+        if ((threadIdx.x & 7) == 0) { s_jb[3 * u] = jb; s_jb[3 * u + 1] = (int)E; s_jb[3 * u + 2] = (int)r; }
+    }
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
         cl[u] = idx[u] < b.n && d_classify(k[u]) == CLS_CLUSTERED;
@@ -282,10 +312,10 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
         if (lane == 0) s_wcnt[u][wv] = __popcll(m[u]);
     }
     __syncthreads();
+    CL_TICK(0);
     // ---- instance of each read: events before it (own epoch) vs. the first event whose walk takes its key
     ClusterKey key[CL_U]; uint32_t ikey[CL_U]; int e_[CL_U], lo[CL_U], hi[CL_U], g[CL_U];
     int T0[CL_U], P0[CL_U], T1[CL_U], P1[CL_U], T2[CL_U], P2[CL_U];
-    const int ev_last = max(n_ev - 1, 0);
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
         key[u].tid = -1; key[u].left = -1; key[u].right = 0; ikey[u] = 0xFFFFFFFFu; e_[u] = 0; lo[u] = hi[u] = g[u] = 0;
@@ -293,9 +323,13 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
         if (cl[u]) {
             unsigned int inblock = lanes_below(m[u]) + 1;
             for (int q = 0; q < wv; q++) inblock += s_wcnt[u][q];
-            // the reference's `tick` after ++ (gencore.cpp:319-320): counted here, or handed in with the batch (key-range shards)
-            const long long tick = b.tick ? (long long)b.tick[idx[u]] : p.tick_offset + (long long)w.chunk_base[blockIdx.x * CL_U + u] + inblock;
-            e_[u] = (int)((tick - 1) / per - p.tick_offset / per);                          // flush events before this read
+            // the reference's `tick` after ++ (gencore.cpp:319-320) -> flush events before this read, (tick - 1) / period: counted here
+            // from the chunk's epoch and remainder, or from the tick handed in with the batch (key-range shards)
+            if (b.tick) e_[u] = (int)(((long long)b.tick[idx[u]] - 1) / per - p.tick_epoch0);
+            else {
+                const unsigned int x = (unsigned int)s_jb[3 * u + 2] + (inblock - 1u), uper = (unsigned int)per;   // < 2^31 + 256
+                e_[u] = s_jb[3 * u + 1] + (int)(uper > (unsigned int)CHUNK ? (x >= uper ? 1u : 0u) : x / uper);
+            }
             const bool seg_b = (first_unm != NONE32) && ((unsigned)idx[u] > first_unm);
             key[u] = d_key(k[u], p);
             lo[u] = seg_b ? n_ev_a : 0; hi[u] = seg_b ? n_ev : n_ev_a;                      // events [lo, hi) 0-based
@@ -303,7 +337,12 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
             ikey[u] = seg_b ? 0x80000000u : 0u;
             // the answer is almost always the read's own epoch or the next one: fetch the three probes at once
             const int j0 = min(max(g[u] - 1, 0), ev_last), j1 = min(g[u], ev_last), j2 = min(g[u] + 1, ev_last);
-            T0[u] = w.ev_tid[j0]; P0[u] = w.ev_pos[j0]; T1[u] = w.ev_tid[j1]; P1[u] = w.ev_pos[j1]; T2[u] = w.ev_tid[j2]; P2[u] = w.ev_pos[j2];
+            const int jbu = s_jb[3 * u];
+            const unsigned k0 = (unsigned)(j0 - jbu), k1 = (unsigned)(j1 - jbu), k2 = (unsigned)(j2 - jbu);
+            if (!b.tick && k0 < 4u && k2 < 4u) {
+                const int *wn = s_win + 8 * u;
+                T0[u] = wn[k0]; P0[u] = wn[4 + k0]; T1[u] = wn[k1]; P1[u] = wn[4 + k1]; T2[u] = wn[k2]; P2[u] = wn[4 + k2];
+            } else { T0[u] = w.ev_tid[j0]; P0[u] = w.ev_pos[j0]; T1[u] = w.ev_tid[j1]; P1[u] = w.ev_pos[j1]; T2[u] = w.ev_tid[j2]; P2[u] = w.ev_pos[j2]; }
         }
     }
     bool implied[CL_U];
@@ -346,6 +385,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
         s_ik[id] = ikey[u];
     }
     __syncthreads();
+    CL_TICK(1);
     int leader[CL_U]; uint32_t lrank[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
@@ -366,6 +406,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
         }
     }
     __syncthreads();
+    CL_TICK(2);
     // ---- leaders: the bucket table
     bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
 #pragma unroll
@@ -388,6 +429,10 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
             if (cur[u] == 0ull) { owner[u] = true; cur[u] = tk[u]; }
         }
     }
+#ifdef CL_PROF
+    { unsigned long long z_ = 0; for (int u = 0; u < CL_U; u++) z_ += cur[u]; if (z_ == 0x123456789ull) w.si->prof[14] = 1; }
+#endif
+    CL_TICK(3);
     gce_core oc[CL_U];                                                                     // exotic followers: the claiming read's key record
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
@@ -431,6 +476,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
     for (int u = 0; u < CL_U; u++)
         if (khead[u]) { s_h[u * CHUNK + id0] = (uint32_t)h[u]; s_base[u * CHUNK + id0] = rbase[u]; }
     __syncthreads();
+    CL_TICK(4);
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
         if (idx[u] < b.n) {
@@ -438,6 +484,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, W
             else w.slot[idx[u]] = NONE32;
         }
     }
+    CL_TICK(5);
 }
 
 // ===================================================================================================== cluster list + member lists
