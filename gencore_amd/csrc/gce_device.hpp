@@ -92,15 +92,19 @@ __device__ __forceinline__ int consumes_ref(int op) { return (0x18D >> op) & 1; 
 
 // Per-read descriptor written once by the thread-per-read prescan: everything the per-pair / per-group kernels need about a
 // read in ONE 32-byte record (two 16-byte loads) instead of the dependent chain core -> offsets -> first CIGAR word.
-// In memory (ReadDescP): offsets, first CIGAR word, position with "isize != 0" in the sign bit (clustered reads are mapped: pos >= 0),
-// read length, first M block, op count -- 16-bit fields, reads longer than 65535 bases are rejected by the prescan.
-// Round 1 kept 48 bytes (tid, isize, reference length as well): 320 MB of writes and as many reads per 20 M reads for fields that the
-// template of a side alone needs (tid: its core record) or that follow from the first CIGAR word (reference length of a one-op read).
+// In memory (ReadDescP): 40-bit blob offsets, first CIGAR word, position with "isize != 0" in the sign bit (clustered reads are mapped:
+// pos >= 0), read length, first M block, op count -- 16-bit fields, reads longer than 65535 bases are rejected by the prescan -- and the
+// contig: the template of a side needs it for the reference lookup, and fetching it from the core record there was one more dependent
+// round trip in a single-wave phase of k_vote.
+// Round 1 kept 48 bytes (isize, reference length as well): 320 MB of writes and as many reads per 20 M reads for fields that follow from
+// the first CIGAR word (reference length of a one-op read) or of which one bit is used.
 struct __attribute__((aligned(16))) ReadDescP {
-    uint64_t so, qo;
+    uint32_t so_lo, qo_lo;
     uint32_t c0;
     uint32_t pos_fl;          // pos | (isize != 0) << 31
     uint16_t lq, mo, ml, nc;
+    int32_t tid;
+    uint32_t hi;              // so >> 32 | (qo >> 32) << 8   (blobs live in HBM: offsets < 2^40) | lastm << 16
 };
 static_assert(sizeof(ReadDescP) == 32, "ReadDescP must stay 32 bytes");
 struct ReadDesc {             // the unpacked form the kernels work with
@@ -108,13 +112,18 @@ struct ReadDesc {             // the unpacked form the kernels work with
     uint32_t c0;              // first CIGAR word (0 if none)
     int32_t pos, lq, isize;   // isize: only "is it zero" survives (1 / 0)
     int32_t mo, ml;           // BamUtil::getMOffsetAndLen: first M block (bamutil.cpp:316-336)
-    uint16_t nc; uint16_t tid16; int32_t rlen; // n_cigar; tid16 = 0xFFFF: read the tid from the core record; rlen = bam_cigar2rlen of a ONE-op read, else RLEN_WALK
+    int32_t tid;
+    uint16_t nc, lastm;       // n_cigar; length of the LAST CIGAR op if it is an M block (capped at 65535), else 0: what isPartOf looks at
+                              // first when reads are aligned at their right end (bamutil.cpp:204-255)
+    int32_t rlen;             // bam_cigar2rlen of a ONE-op read, else RLEN_WALK
 };
 #define RLEN_WALK (-0x40000000)     // more than one CIGAR op: d_cigar_rlen over the CIGAR (desc_rlen)
-__device__ __forceinline__ void store_desc(ReadDescP *base, uint64_t i, uint64_t so, uint64_t qo, uint32_t c0, int32_t pos, bool isize_nz, int lq, int mo, int ml, int nc) {
+__device__ __forceinline__ void store_desc(ReadDescP *base, uint64_t i, uint64_t so, uint64_t qo, uint32_t c0, int32_t pos, bool isize_nz, int lq, int mo, int ml, int nc, int32_t tid, uint32_t last_op) {
     union { ReadDescP d; uint4 q[2]; } u;
-    u.d.so = so; u.d.qo = qo; u.d.c0 = c0; u.d.pos_fl = (uint32_t)pos | (isize_nz ? 0x80000000u : 0u);
-    u.d.lq = (uint16_t)lq; u.d.mo = (uint16_t)mo; u.d.ml = (uint16_t)ml; u.d.nc = (uint16_t)nc;
+    u.d.so_lo = (uint32_t)so; u.d.qo_lo = (uint32_t)qo; const uint32_t lastm = cig_op(last_op) == 0 ? min((uint32_t)cig_len(last_op), 65535u) : 0u;
+    u.d.hi = ((uint32_t)(so >> 32) & 0xFFu) | ((uint32_t)(qo >> 32) & 0xFFu) << 8 | lastm << 16;
+    u.d.c0 = c0; u.d.pos_fl = (uint32_t)pos | (isize_nz ? 0x80000000u : 0u);
+    u.d.lq = (uint16_t)lq; u.d.mo = (uint16_t)mo; u.d.ml = (uint16_t)ml; u.d.nc = (uint16_t)nc; u.d.tid = tid;
     uint4 *dst = reinterpret_cast<uint4 *>(base + i); dst[0] = u.q[0]; dst[1] = u.q[1];
 }
 __device__ __forceinline__ ReadDesc load_desc(const ReadDescP *base, uint32_t i) {
@@ -122,8 +131,9 @@ __device__ __forceinline__ ReadDesc load_desc(const ReadDescP *base, uint32_t i)
     const uint4 *src = reinterpret_cast<const uint4 *>(base + i);
     u.q[0] = src[0]; u.q[1] = src[1];
     ReadDesc r;
-    r.so = u.d.so; r.qo = u.d.qo; r.c0 = u.d.c0; r.pos = (int32_t)(u.d.pos_fl & 0x7FFFFFFFu); r.isize = (int32_t)(u.d.pos_fl >> 31);
-    r.lq = u.d.lq; r.mo = u.d.mo; r.ml = u.d.ml; r.nc = u.d.nc; r.tid16 = 0xFFFF;
+    r.so = (uint64_t)u.d.so_lo | (uint64_t)(u.d.hi & 0xFFu) << 32; r.qo = (uint64_t)u.d.qo_lo | (uint64_t)((u.d.hi >> 8) & 0xFFu) << 32;
+    r.c0 = u.d.c0; r.pos = (int32_t)(u.d.pos_fl & 0x7FFFFFFFu); r.isize = (int32_t)(u.d.pos_fl >> 31);
+    r.lq = u.d.lq; r.mo = u.d.mo; r.ml = u.d.ml; r.nc = u.d.nc; r.tid = u.d.tid; r.lastm = (uint16_t)(u.d.hi >> 16);
     r.rlen = u.d.nc == 1 ? (int32_t)(cig_len(u.d.c0) * consumes_ref(cig_op(u.d.c0))) : (u.d.nc == 0 ? 0 : RLEN_WALK);
     return r;
 }

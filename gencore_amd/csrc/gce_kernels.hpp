@@ -112,7 +112,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, W
                 if (k.n_cigar == 1) ml_ = cig_op(c0w) == 0 ? cig_len(c0w) : 0;
                 else d_first_m(cg, k.n_cigar, mo_, ml_);
                 if (k.l_qseq > 65535) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)i);      // the 16-bit fields of the descriptor (and of the overlap patches)
-                store_desc(w.rdesc, (uint64_t)i, b.seq_off[i], b.qual_off[i], c0w, k.pos, k.isize != 0, k.l_qseq, mo_, ml_, k.n_cigar);
+                store_desc(w.rdesc, (uint64_t)i, b.seq_off[i], b.qual_off[i], c0w, k.pos, k.isize != 0, k.l_qseq, mo_, ml_, k.n_cigar, k.tid, k.n_cigar > 1 ? cg[k.n_cigar - 1] : c0w);
             }
             if (c == CLS_CLUSTERED) {                                          // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38
                 const char *src; uint8_t hm = 0;
@@ -1739,11 +1739,11 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
     uint32_t rd = lane < (int)np ? side[begin + lane] : NONE32;
     const bool has = rd != NONE32;
     int pos = 0, lq = 0, nc = 0, rrp = 0; uint32_t c0 = 0; uint64_t cigo = 0, so = 0, qo = 0;
-    int isz = 0; uint32_t patch = 0; int tid16 = 0;
+    int isz = 0; uint32_t patch = 0; int rtid = 0;
     if (has) {
         patch = w.spatch[rd];
         const ReadDesc k = load_desc(w.rdesc, rd);
-        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + (k.rlen != RLEN_WALK ? k.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], k.nc)); tid16 = k.tid16;
+        pos = k.pos; lq = k.lq; nc = k.nc; isz = k.isize; so = k.so; qo = k.qo; c0 = k.c0; rrp = pos + (k.rlen != RLEN_WALK ? k.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], k.nc)); rtid = k.tid;
         if ((nc > 1 || (nc == 1 && cig_op(c0) != 0))) cigo = b.cigar_off[rd];     // anything but a single M block is walked from memory (rare)
     }
     const unsigned long long hmask = __ballot(has);
@@ -1799,7 +1799,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
-    const int o_isz = rl32(isz, best), o_t16 = rl32(tid16, best), o_tid = o_t16 != 0xFFFF ? o_t16 : b.core[out].tid;
+    const int o_isz = rl32(isz, best), o_tid = rl32(rtid, best);
     // NM of the template (group.cpp:528-573), needed only at the very end: fetched now, off the critical path
     const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
     const uint8_t *ref = nullptr; int64_t ref_len = 0;

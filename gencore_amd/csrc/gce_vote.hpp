@@ -143,6 +143,15 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
     __shared__ uint8_t s_glp0[VB_MAXG + 1], s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng;
+    // P1 -> P3 only, in the (not yet used) tally space: contig of either read of a pair (the template's reference lookup); length of its
+    // last CIGAR op if that is an M block (isPartOf from the right end); per side the masks of its reads / its single-M reads, the range of
+    // their positions, the voters and "a read outside the scope was seen"; the group of every pair
+    int32_t (*s_ptid)[VB_MAXP] = reinterpret_cast<int32_t (*)[VB_MAXP]>(&s_tal[0][0][0]);
+    uint16_t (*s_lastm)[VB_MAXP] = reinterpret_cast<uint16_t (*)[VB_MAXP]>(&s_tal[0][0][0] + 2 * VB_MAXP);
+    uint32_t *s_hm = &s_tal[0][0][0] + 3 * VB_MAXP, *s_single = s_hm + VB_SIDES, *s_vm = s_single + VB_SIDES, *s_unf = s_vm + VB_SIDES;
+    int32_t *s_pmin = reinterpret_cast<int32_t *>(s_unf + VB_SIDES), *s_pmax = s_pmin + VB_SIDES;
+    uint8_t *s_pg = reinterpret_cast<uint8_t *>(s_pmax + VB_SIDES);
+    static_assert(sizeof(s_tal) >= (3 * VB_MAXP + 6 * VB_SIDES) * 4 + VB_MAXP, "P1 scratch must fit the tally space");
     // work index of a thread: rotated by the batch number, so that the single-wave phases (P0, P2, P5a, P6) and the half-empty ones
     // do not all land on the same SIMD of the CU (wave k of every workgroup runs on SIMD k)
     const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
@@ -172,6 +181,11 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         }
     }
     for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
+    if (tid >= VB_T - 4 * VB_SIDES) {                                                  // (the last waves: the first one is busy with the groups)
+        const int k = tid - (VB_T - 4 * VB_SIDES);
+        s_hm[k] = 0u;                                                                   // s_hm, s_single, s_vm, s_unf are adjacent
+        if (k < VB_SIDES) { s_pmin[k] = 0x7FFFFFFF; s_pmax[k] = -0x7FFFFFFF; }
+    }
     __syncthreads();
     const int ng = s_ng, npairs = s_glp0[ng];
     VB_TICK(0);
@@ -187,7 +201,13 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         VRead vl, vr;
         vl.so = lk.so; vl.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
         vr.so = rk.so; vr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
-        s_rd[0][tid] = vl; s_rd[1][tid] = vr;
+        s_rd[0][tid] = vl; s_rd[1][tid] = vr; s_ptid[0][tid] = lk.tid; s_ptid[1][tid] = rk.tid; s_lastm[0][tid] = lk.lastm; s_lastm[1][tid] = rk.lastm;
+        s_pg[tid] = (uint8_t)j;
+        {   // what the sides' template choice needs of their reads (group.cpp:177-194), gathered by the pairs
+            const uint32_t kb = 1u << (tid - (int)s_glp0[j]);
+            if (L != NONE32) { atomicOr(&s_hm[2 * j], kb); if (vl.nc == 1 && cig_op(vl.c0) == 0) atomicOr(&s_single[2 * j], kb); atomicMin(&s_pmin[2 * j], vl.pos); atomicMax(&s_pmax[2 * j], vl.pos); }
+            if (R != NONE32) { atomicOr(&s_hm[2 * j + 1], kb); if (vr.nc == 1 && cig_op(vr.c0) == 0) atomicOr(&s_single[2 * j + 1], kb); atomicMin(&s_pmin[2 * j + 1], vr.pos); atomicMax(&s_pmax[2 * j + 1], vr.pos); }
+        }
         VOv ov; ov.ls = 0; ov.rs = 0; ov.cmp = 0; ov.fl = 0;
         if (L == NONE32 || R == NONE32 || !(lk.ml > 0 && rk.ml > 0)) ov.fl = 1;        // pair.cpp:89-105: memset(scoreOfNotOverlappedModerateQual)
         else {
@@ -205,6 +225,41 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __syncthreads();
     VB_TICK(1);
     // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
+    // The side's majority class = CIGAR and length of its first single-M read (see gce_lean2.hpp for the argument):
+    // group.cpp:177-261 collapse to "template = first read of the class, voters = the class" when every other read is
+    // provably unrelated to it (>= 2 CIGAR ops and a first op that is not an M block of >= len bases) and in the
+    // minority, and — right side — all positions are equal (leftReadMode).  No single-M read: one class with the same
+    // 2-/3-op CIGAR and nothing else.
+    // Right reads on different positions: not leftReadMode (group.cpp:177-194) -- isPartOf then compares CIGARs from their
+    // END, containedBy only counts reads with the same right end (:220-224), columns align at the right end.  For one
+    // class of identical reads (same CIGAR, length AND position) nothing changes, as long as every other read is unrelated
+    // to it from the end as well: >= 2 ops and a LAST op that is not an M block of >= len bases (a leading soft clip,
+    // typically) -- such a read neither votes (group.cpp:287-313) nor contains or is contained.
+    // (a) lane = (pair, side): is my read of the template's class?  (one wave walking the <= 32 reads of its sides one after the other
+    //     was a quarter of the batch's life time: 2 x 32 trips for the deepest group of the wave, at one wave's issue rate)
+    for (int it = tid; it < 2 * npairs; it += VB_T) {
+        const int pr = it >> 1, side = it & 1, jg = s_pg[pr], sl = 2 * jg + side, lp0 = s_glp0[jg];
+        const VTail r = vr_tail(&s_rd[side][pr]);
+        if (r.rd == NONE32 || s_gflag[jg] != 0) continue;
+        const uint32_t hm = s_hm[sl], single = s_single[sl];
+        const bool multi = single == 0;
+        const int fl = multi ? __ffs((int)hm) - 1 : __ffs((int)single) - 1;
+        const VTail t = vr_tail(&s_rd[side][lp0 + fl]);
+        const bool ralign = side == 1 && s_pmin[sl] != s_pmax[sl];                     // (some read off the template's position <=> not all positions equal)
+        uint32_t o_cw1 = 0, o_cw2 = 0, cw1 = 0, cw2 = 0;
+        if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
+        if (multi && r.nc >= 2 && r.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[r.rd]; cw1 = cg[1]; if (r.nc == 3) cw2 = cg[2]; }
+        const int len = t.lq;
+        const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq && (!ralign || r.pos == t.pos);
+        if (major) atomicOr(&s_vm[sl], 1u << (pr - lp0));
+        else {
+            // the op isPartOf looks at first: the first one, or the last when right aligned (its M length comes with the descriptor)
+            const bool edge_m = (ralign && r.nc >= 2) ? (int)s_lastm[side][pr] >= len : (cig_op(r.c0) == 0 && cig_len(r.c0) >= len);
+            if (multi || r.nc < 2 || edge_m) s_unf[sl] = 1u;
+        }
+    }
+    __syncthreads();
+    // (b) lane = (group, side)
     if (tid < 64) {
         const int j = lane >> 1, side = lane & 1;
         const bool mine = lane < 2 * ng && s_gflag[j] == 0;
@@ -214,57 +269,33 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         if (mine) {
             const int np = s_gnp[j], lp0 = s_glp0[j];
             const VRead *rds = s_rd[side] + lp0;
+            // the reference of the side's contig (a side's reads share it, cross-contig clusters aside): asked for now, needed further down
+            const int tid0 = s_ptid[side][lp0];
+            const bool tid0_ok = tid0 >= 0 && tid0 < p.n_ref;
+            const uint8_t *rdp0 = tid0_ok ? p.ref_data[tid0] : nullptr;
+            const int64_t rl0 = tid0_ok ? p.ref_len[tid0] : 0;
             if (np == 1 && s_rd[1][lp0].rd == NONE32) {                                 // group.cpp:73-77: returned untouched
                 sd.result = side == 0 ? s_rd[0][lp0].rd : NONE32;
             } else {
-                uint32_t hm = 0, single = 0; int pmin = 0x7FFFFFFF, pmax = -0x7FFFFFFF;
-                for (int k = 0; k < np; k++) {
-                    const VTail r = vr_tail(rds + k);
-                    if (r.rd != NONE32) { hm |= 1u << k; if (r.nc == 1 && cig_op(r.c0) == 0) single |= 1u << k; pmin = min(pmin, r.pos); pmax = max(pmax, r.pos); }
-                }
+                const uint32_t hm = s_hm[lane], single = s_single[lane];
                 if (hm != 0) {
-                    // The side's majority class = CIGAR and length of its first single-M read (see gce_lean2.hpp for the argument):
-                    // group.cpp:177-261 collapse to "template = first read of the class, voters = the class" when every other read is
-                    // provably unrelated to it (>= 2 CIGAR ops and a first op that is not an M block of >= len bases) and in the
-                    // minority, and — right side — all positions are equal (leftReadMode).  No single-M read: one class with the same
-                    // 2-/3-op CIGAR and nothing else.
                     const bool multi = single == 0;
                     const int fl = multi ? __ffs((int)hm) - 1 : __ffs((int)single) - 1;
                     const VTail t = vr_tail(rds + fl);
-                    uint32_t o_cw1 = 0, o_cw2 = 0;
-                    if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
                     const int len = t.lq;
-                    // right reads on different positions: not leftReadMode (group.cpp:177-194) -- isPartOf then compares CIGARs from their
-                    // END, containedBy only counts reads with the same right end (:220-224), columns align at the right end.  For one
-                    // class of identical reads (same CIGAR, length AND position) nothing changes, as long as every other read is unrelated
-                    // to it from the end as well: >= 2 ops and a LAST op that is not an M block of >= len bases (a leading soft clip,
-                    // typically) -- such a read neither votes (group.cpp:287-313) nor contains or is contained.
-                    const bool ralign = side == 1 && pmin != pmax;                     // (some read off the template's position <=> not all positions equal)
-                    uint32_t vm = 0; bool unfit = t.nc > 3 || t.nc < 1 || (ralign && multi);
-                    for (int k = 0; k < np; k++) {
-                        if (!((hm >> k) & 1u)) continue;
-                        const VTail r = vr_tail(rds + k);
-                        uint32_t cw1 = 0, cw2 = 0;
-                        if (multi && r.nc >= 2 && r.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[r.rd]; cw1 = cg[1]; if (r.nc == 3) cw2 = cg[2]; }
-                        const bool major = r.nc == t.nc && r.c0 == t.c0 && cw1 == o_cw1 && cw2 == o_cw2 && r.lq == t.lq && (!ralign || r.pos == t.pos);
-                        if (major) { s_vlist[lane][__popc(vm)] = (uint8_t)k; vm |= 1u << k; }
-                        else {
-                            uint32_t edge = r.c0;                                       // the op isPartOf looks at first: the first one, or the last when right aligned
-                            if (ralign && r.nc >= 2) edge = b.cigar[b.cigar_off[r.rd] + r.nc - 1];
-                            if (multi || r.nc < 2 || (cig_op(edge) == 0 && cig_len(edge) >= len)) unfit = true;
-                        }
-                        if (side == 1 && !ralign && r.pos != t.pos) unfit = true;
-                    }
+                    const bool ralign = side == 1 && s_pmin[lane] != s_pmax[lane];
+                    const uint32_t vm = s_vm[lane];
+                    const bool unfit = t.nc > 3 || t.nc < 1 || (ralign && multi) || s_unf[lane] != 0;
                     const int nvot = __popc(vm);
                     to_gen = unfit || nvot <= __popc(hm) - nvot || len > VB_COLS || len < 1;
                     if (!to_gen && !((double)nvot < (double)np * 0.4 && np != 1)) {    // group.cpp:264-266: else "no majority", result stays NONE
                         sd.state = VS_ACTIVE; sd.vmask = vm; sd.tmpl = (uint8_t)fl; sd.nvot = (uint8_t)nvot; sd.len = (uint16_t)len;
                         sd.o_pos = t.pos; sd.o_c0 = t.c0; sd.o_nc = t.nc; sd.result = t.rd;
                         if (t.fl & 1) {                                                 // group.cpp:362-367 -> Reference::getData (reference.cpp:33-70)
-                            const int o_tid = b.core[t.rd].tid;                         // (the template's contig: one load per side)
+                            const int o_tid = s_ptid[side][lp0 + fl];
                             if (o_tid >= 0 && o_tid < p.n_ref) {
-                                const uint8_t *rdp = p.ref_data[o_tid];
-                                const int64_t rl = p.ref_len[o_tid];
+                                const uint8_t *rdp = o_tid == tid0 ? rdp0 : p.ref_data[o_tid];
+                                const int64_t rl = o_tid == tid0 ? rl0 : p.ref_len[o_tid];
                                 const int64_t need_len = (int64_t)(t.nc == 1 ? ((len - 1) < cig_len(t.c0) ? (len - 1) : -1) : d_ref_offset(b.cigar + b.cigar_off[t.rd], t.nc, len - 1)) + 1;
                                 if (rdp && (int64_t)t.pos + need_len < rl) { sd.ref = (uint64_t)rdp; sd.ref_len = rl; }
                             }
@@ -299,8 +330,15 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten)
     if (tid < npairs) {
         const VOv ov = s_ov[tid];
-        int j = 0;
-        while (j + 1 < ng && (int)s_glp0[j + 1] <= tid) j++;
+        const int j = s_pg[tid];
+        {   // the voter lists of the pair's two sides (ascending pair index): every voter knows its place from the side's mask
+            const int k = tid - (int)s_glp0[j];
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint32_t vm = s_side[2 * j + side].vmask;                         // (0 unless the side is active)
+                if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)k;
+            }
+        }
         if ((ov.fl & 2) && s_gflag[j] == 0) {
             const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
             // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
