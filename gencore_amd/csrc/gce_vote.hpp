@@ -222,6 +222,44 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         }
         s_ov[tid] = ov;
     }
+    // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
+    //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten).
+    //      The same lanes as P1, on what they wrote themselves: no barrier in between.
+    if (tid < npairs) {
+        const VOv ov = s_ov[tid];
+        const int j = s_pg[tid];
+        if ((ov.fl & 2) && s_gflag[j] == 0) {
+            const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
+            // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
+            auto cols8 = [](uint64_t x, int c0) {
+                const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
+                return (uint32_t)(y >> (4 * (c0 & 1)));
+            };
+            for (int i = 0; i < (int)ov.cmp; i += 32) {                                 // four 8-column words per step, loads first
+                uint64_t lw[4], rw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = min(i + 8 * u, (int)ov.cmp - 1);                     // (clamped: a short last step re-reads a valid word)
+                    lw[u] = ld8_unaligned(ls + ((ov.ls + ii) >> 1)); rw[u] = ld8_unaligned(rs + ((ov.rs + ii) >> 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i0 = i + 8 * u, nv = min(8, (int)ov.cmp - i0);
+                    if (nv <= 0) continue;
+                    const int l0 = ov.ls + i0, r0 = ov.rs + i0;
+                    uint32_t d = (cols8(lw[u], l0) ^ cols8(rw[u], r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
+                    d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
+                    while (d) {
+                        const int k = (__ffs((int)d) - 1) >> 2;
+                        d &= d - 1;
+                        const int l = l0 + k, r = r0 + k;
+                        if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
+                        if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
+                    }
+                }
+            }
+        }
+    }
     __syncthreads();
     VB_TICK(1);
     // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
@@ -326,52 +364,15 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     }
     __syncthreads();
     VB_TICK(2);
-    // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
-    //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten)
+    // the voter lists of a pair's two sides (ascending pair index): every voter knows its place from the side's mask  (read in P5)
     if (tid < npairs) {
-        const VOv ov = s_ov[tid];
-        const int j = s_pg[tid];
-        {   // the voter lists of the pair's two sides (ascending pair index): every voter knows its place from the side's mask
-            const int k = tid - (int)s_glp0[j];
+        const int j = s_pg[tid], k = tid - (int)s_glp0[j];
 #pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const uint32_t vm = s_side[2 * j + side].vmask;                         // (0 unless the side is active)
-                if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)k;
-            }
-        }
-        if ((ov.fl & 2) && s_gflag[j] == 0) {
-            const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
-            // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
-            auto cols8 = [](uint64_t x, int c0) {
-                const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
-                return (uint32_t)(y >> (4 * (c0 & 1)));
-            };
-            for (int i = 0; i < (int)ov.cmp; i += 32) {                                 // four 8-column words per step, loads first
-                uint64_t lw[4], rw[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ii = min(i + 8 * u, (int)ov.cmp - 1);                     // (clamped: a short last step re-reads a valid word)
-                    lw[u] = ld8_unaligned(ls + ((ov.ls + ii) >> 1)); rw[u] = ld8_unaligned(rs + ((ov.rs + ii) >> 1));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i0 = i + 8 * u, nv = min(8, (int)ov.cmp - i0);
-                    if (nv <= 0) continue;
-                    const int l0 = ov.ls + i0, r0 = ov.rs + i0;
-                    uint32_t d = (cols8(lw[u], l0) ^ cols8(rw[u], r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
-                    d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
-                    while (d) {
-                        const int k = (__ffs((int)d) - 1) >> 2;
-                        d &= d - 1;
-                        const int l = l0 + k, r = r0 + k;
-                        if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
-                        if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
-                    }
-                }
-            }
+        for (int side = 0; side < 2; side++) {
+            const uint32_t vm = s_side[2 * j + side].vmask;                             // (0 unless the side is active)
+            if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)k;
         }
     }
-    __syncthreads();
     VB_TICK(3);
     // ---------------------------------------------------------------- P4: pass A, one lane per (side, 16 columns); the 16 top qualities stay
     //      in registers until the write-back (an item keeps its lane: it = tid + VB_T k, k < VB_IPL)
