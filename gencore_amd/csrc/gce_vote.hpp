@@ -33,13 +33,18 @@
 #ifndef VB_T
 #define VB_T 256           // threads per batch
 #endif
+#ifndef VB_W
 #define VB_W 64            // batch capacity in weight units (weight of a group = max(pairs, 4); a handed-on deep group takes a whole batch)
+#endif
 #define VB_MINW 4
-#define VB_MAXG 16
-#define VB_MAXP 96
+#define VB_MAXG (VB_W / VB_MINW)
+#define VB_MAXP (VB_W + 32)                // a batch's last group may reach over the end: < VB_W + 32 pairs
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
-#define VB_CCAP 192        // contested columns voted per round (LDS tallies)
+#ifndef VB_CCAP
+#define VB_CCAP 192
+#endif
+//   VB_CCAP: contested columns voted per round (LDS tallies)
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #define VB_RCAP (VB_SIDES * VB_SMAX)
 
