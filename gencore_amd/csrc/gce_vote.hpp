@@ -347,6 +347,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                 }
             }
         }
+        if (lane < VB_SIDES) s_hm[lane] = 0u;                                          // from here on: contested columns of the side, counted by pass A
         // a group goes on as a whole (all shuffles on wave-uniform paths)
         const int other_gen = __shfl_xor((int)to_gen, 1);                              // (unconditional: `a || shfl(..)` would shuffle in a divergent branch)
         const bool grp_gen = to_gen || other_gen != 0;
@@ -434,27 +435,21 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             const uint32_t hib = (msb4(t0) | (msb4(t1) << 4) | (msb4(t2) << 8) | (msb4(t3) << 12)) & colmask;
             if (hib != 0 || p.moderate_q > 127) s_gflag[sd.grp] = 2;
             keep[kk] = make_uint4(t0, t1, t2, t3);
-            if (contested) atomicOr(&s_cmask[s][chunk >> 1], contested << (16 * (chunk & 1)));
+            {   // into the side's column mask, next to the columns P3 forced (complete by now); the side's count goes along
+                const uint32_t sh = 16u * (chunk & 1), forced = (s_cmask[s][chunk >> 1] >> sh) & colmask, tot = forced | contested;
+                if (contested & ~forced) atomicOr(&s_cmask[s][chunk >> 1], contested << sh);
+                if (tot) atomicAdd(&s_hm[s], (uint32_t)__popc(tot));
+            }
         }
     }
     __syncthreads();
     VB_TICK(4);
     // ---------------------------------------------------------------- P5: pass B
-    // (a) contested columns per side (forced columns behind the template's end do not exist); a side with too many hands its group on;
+    // (a) contested columns per side (counted by pass A); a side with too many hands its group on;
     //     prefixes over the sides: of the columns, and of the (voter, column) items
     if (tid < 64) {
-        int cnt = 0;
         const bool act = lane < VB_SIDES && s_side[lane].state == VS_ACTIVE && s_gflag[s_side[lane].grp] == 0;
-        if (act) {
-            const int len = s_side[lane].len;
-            for (int k = 0; k < VB_COLS / 32; k++) {
-                uint32_t m = s_cmask[lane][k];
-                const int hi = len - 32 * k;
-                if (hi < 32) m &= hi <= 0 ? 0u : ((1u << hi) - 1u);
-                s_cmask[lane][k] = m;
-                cnt += __popc(m);
-            }
-        }
+        int cnt = act ? (int)s_hm[lane] : 0;
         const int over = cnt > VB_SMAX, other_over = __shfl_xor(over, 1);
         if (over && lane < VB_SIDES) s_gflag[s_side[lane].grp] = 2;
         if (over || other_over || !act) cnt = 0;
@@ -468,10 +463,16 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     // (b) the list of contested columns, side by side: thread = (side, mask word)
     for (int q = tid; q < VB_SIDES * (VB_COLS / 32); q += VB_T) {
         const int s = q / (VB_COLS / 32), k = q % (VB_COLS / 32);
-        if (s_cpre[s + 1] > s_cpre[s]) {
-            int base = s_cpre[s];
-            for (int x = 0; x < k; x++) base += __popc(s_cmask[s][x]);
-            for (uint32_t m = s_cmask[s][k]; m; m &= m - 1) s_ccol[base++] = (uint8_t)(32 * k + __ffs((int)m) - 1);
+        if (s_side[s].state == VS_ACTIVE) {
+            const int len = s_side[s].len;
+            auto word = [&](int x) { uint32_t m = s_cmask[s][x]; const int hi = len - 32 * x; if (hi < 32) m &= hi <= 0 ? 0u : ((1u << hi) - 1u); return m; };   // forced columns behind the template's end do not exist
+            const uint32_t mk = word(k);
+            s_cmask[s][k] = mk;                                                         // (P7 reads the words again; a neighbour that still sees the unmasked word masks it itself)
+            if (s_cpre[s + 1] > s_cpre[s]) {
+                int base = s_cpre[s];
+                for (int x = 0; x < k; x++) base += __popc(word(x));
+                for (uint32_t m = mk; m; m &= m - 1) s_ccol[base++] = (uint8_t)(32 * k + __ffs((int)m) - 1);
+            }
         }
     }
     const int n_cont = s_cpre[VB_SIDES];
