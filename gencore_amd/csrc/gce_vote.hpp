@@ -111,6 +111,18 @@ __global__ __launch_bounds__(256) void k_vote_batches(Work w, const unsigned lon
     }
 }
 
+// inclusive scan over the 64 lanes of a fully active wave in six DPP adds (row shifts 1, 2, 4, 8 inside the rows of 16, then lane 15 /
+// lane 31 broadcast into the following rows): __shfl_up is a ds_bpermute round trip per step, and the scans sit in the single-wave phases
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {       // largest s < n with pre[s] <= it  (pre ascending, pre[0] = 0)
     int lo = 0, hi = n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)pre[mid] <= it) lo = mid; else hi = mid - 1; }
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         const unsigned long long im = __ballot(in);
         const int ng = __popcll(im);                                                   // (groups of a batch are consecutive: im = low bits)
         int x = deep ? 0 : (int)np, pre = x;
-        for (int o = 1; o < VB_MAXG; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+        pre = wave_scan_incl(pre);
         if (in) { s_ggi[lane] = gi; s_gbeg[lane] = w.g_begin[gi]; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
         if (lane == ng - 1) s_glp0[ng] = (uint8_t)pre;
         if (lane == 0) s_ng = ng;
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         // pass-A items: 16-column chunks of the active sides, prefix over the sides
         const int nchunk = (mine && sd.state == VS_ACTIVE) ? (sd.len + 15) >> 4 : 0;
         int pre = nchunk;
-        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o); if (lane >= o) pre += t2; }
+        pre = wave_scan_incl(pre);
         sd.item0 = (uint16_t)(pre - nchunk);
         if (lane < VB_SIDES) { s_side[lane] = sd; s_ipre[lane] = (uint16_t)(pre - nchunk); }
         if (lane == VB_SIDES - 1) s_ipre[VB_SIDES] = (uint16_t)pre;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         if (over || other_over || !act) cnt = 0;
         const int nit = act ? cnt * (int)s_side[lane].nvot : 0;
         int pre = cnt, pre2 = nit;
-        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(pre, o), t3 = __shfl_up(pre2, o); if (lane >= o) { pre += t2; pre2 += t3; } }
+        pre = wave_scan_incl(pre); pre2 = wave_scan_incl(pre2);
         if (lane < VB_SIDES) { s_cpre[lane] = (uint16_t)(pre - cnt); s_jpre[lane] = (uint16_t)(pre2 - nit); }
         if (lane == VB_SIDES - 1) { s_cpre[VB_SIDES] = (uint16_t)pre; s_jpre[VB_SIDES] = (uint16_t)pre2; }
     }
