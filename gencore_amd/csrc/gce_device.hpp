@@ -468,6 +468,20 @@ __device__ __forceinline__ int wave_min(int v) {
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
     return v;
 }
+// The same reductions on the DPP path, for fully active waves: rotations inside the rows of 16 lanes (one VALU op a step, no LDS
+// crossbar round trip), the four row results read back as scalars.  The result is wave-uniform (an SGPR).
+template <int CTRL> __device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_max16(int v) {          // max over the lane's row of 16, in every lane of the row
+    v = max(v, dpp_move<0x128>(v));                          // row_ror:8
+    v = max(v, dpp_move<0x124>(v));                          // row_ror:4
+    v = max(v, dpp_move<0x122>(v));                          // row_ror:2
+    v = max(v, dpp_move<0x121>(v));                          // row_ror:1
+    return v;
+}
+__device__ __forceinline__ int wave_max_u(int v) {
+    const int r = row_max16(v);
+    return max(max(__builtin_amdgcn_readlane(r, 0), __builtin_amdgcn_readlane(r, 16)), max(__builtin_amdgcn_readlane(r, 32), __builtin_amdgcn_readlane(r, 48)));
+}
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {   // popcount of mask bits below this lane
     return __popcll(mask & ((1ull << lane_id()) - 1ull));
 }

@@ -14,8 +14,9 @@
 // = the SUB-lane group of a cluster).
 #pragma once
 
-template <int SUB> __device__ __forceinline__ int sub_max(int v) {
-    for (int o = SUB / 2; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
+template <int SUB> __device__ __forceinline__ int sub_max(int v) {       // (all lanes of the wave must call it)
+    v = row_max16(v);
+    if (SUB == 32) { const int t = __shfl_xor(v, 16); v = t > v ? t : v; }
     return v;
 }
 // my sub-group's bits of a wave ballot
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
     if (!__any(live)) return;
     const bool act = live && hl < (int)n;
-    const int nwords = (wave_max(act ? nl : 0) + 7) >> 3;
+    const int nwords = (wave_max_u(act ? nl : 0) + 7) >> 3;
     uint64_t nw[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         h32 = __builtin_rotateleft32(h32, 11) ^ (hi + 0x7F4A7C15u);
     }
     h32 ^= h32 >> 15;
-    const int nmax = wave_max(live ? (int)n : 0);
+    const int nmax = wave_max_u(live ? (int)n : 0);
     uint32_t EQ = 0, LOW = 0;
     {   // one ballot per DISTINCT hash of a half: a whole name class at a time (the halves run to the largest class count)
         uint32_t todo = sub_ballot<SUB>(act, hb);
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     EQ &= ~(1u << hl);
     {   // exact verification of every hash match, arrival order inside the class (all lanes run the shuffles)
         bool bad = false;
-        const int rounds = wave_max(act ? __popc(EQ) : 0);
+        const int rounds = wave_max_u(act ? __popc(EQ) : 0);
         uint32_t rest = act ? EQ : 0u;
         for (int r = 0; r < rounds; r++) {
             const bool has = rest != 0;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             for (int k = 0; k < 8; k++) { if (k == wi) a = nw[k]; if (k == wi + 1) c2 = nw[k]; }
             okey = sh ? ((a << sh) | (c2 >> (64 - sh))) : a;
         }
-        const int itmax = wave_max((int)npairs);
+        const int itmax = wave_max_u((int)npairs);
         uint32_t fm = FIRST, TIE = 0;
         for (int it = 0; it < itmax; it++) {
             const bool has = fm != 0;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             if (has && o == okey && !((EQ >> j) & 1u) && j != hl) TIE |= 1u << j;      // another name with my order word
         }
         if (__any(act2 && TIE != 0)) {                      // (rare) settle the ties on the whole names
-            const int rounds = wave_max(__popc(TIE));
+            const int rounds = wave_max_u(__popc(TIE));
             uint32_t tm = act2 ? TIE : 0u;
             for (int it = 0; it < rounds; it++) {
                 const bool has = tm != 0;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty; the pair's current read is
         // the predecessor in arrival order = the largest read index among the same-name reads before mine
         uint32_t prev = act2 ? (EQ & LOW) : 0u;
-        const int rounds = wave_max(__popc(prev));
+        const int rounds = wave_max_u(__popc(prev));
         int plane = -1; uint32_t pv = 0;
         for (int r = 0; r < rounds; r++) {
             const bool has = prev != 0;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
         const bool grp = any_umi;                           // (a half without UMIs keeps its single group)
         int cnt = 0, urank = 0;                             // umiCount[umi], and the rank of my UMI in std::string order
-        const bool one_word = wave_max(ulen) <= 8;
+        const bool one_word = wave_max_u(ulen) <= 8;
         {   // one round per DISTINCT UMI of a half: its pairs learn their count, the pairs with a larger UMI add it to their rank
             uint32_t todo = sub_ballot<SUB>(pact, hb);
             if (!grp) todo = 0u;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     // ---- lay the pairs out group by group (qname order inside a group)
     {
         uint32_t gbase = 0;
-        const int gmax = wave_max((int)ngroups);
+        const int gmax = wave_max_u((int)ngroups);
         for (int g = 0; g < gmax; g++) {
             const bool in = pact && g_of == (uint32_t)g;
             const uint32_t m = sub_ballot<SUB>(in, hb);
