@@ -633,7 +633,6 @@ int gce_process(gce_engine *e) {
         fprintf(stderr, "\n");
     }
 #endif
-    if (N > 0 && e->dev_error == 0) hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);
     HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
     // ---- the output set: emitted reads in bamComp order (gencore.h:19-47) as one compact table.  Capacities are worst case
     //      (every read emitted): nothing here needs a host round trip.
@@ -648,6 +647,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_flag_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, w.scan_part);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_out, (unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_flag_apply, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, (const uint64_t *)w.scan_part, w.out_index);
+        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups, emitted reads (out_index)
         const unsigned og = std::min<unsigned>(cdiv(n1, 256), 8192u);
         hipLaunchKernelGGL(k_out_order, dim3(og), dim3(256), 0, s, b, w, o);
         hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, b, w, o);

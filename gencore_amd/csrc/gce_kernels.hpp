@@ -2163,7 +2163,8 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
             d_record_umi(b, p, w, right, qsr, u2, ul2);
             if (left != NONE32 && ul != 0) {                               // (two word loads per side instead of a byte loop with a data-dependent exit)
                 bool same = ul == ul2;
-                if (same && ul <= 24) { uint64_t a[3], c3[3]; load_be_words<3>(u, ul, a); load_be_words<3>(u2, ul2, c3); same = a[0] == c3[0] && a[1] == c3[1] && a[2] == c3[2]; }
+                if (same && u == u2) { }                                    // both records carry the same read's name (the usual case): nothing to fetch
+                else if (same && ul <= 24) { uint64_t a[3], c3[3]; load_be_words<3>(u, ul, a); load_be_words<3>(u2, ul2, c3); same = a[0] == c3[0] && a[1] == c3[1] && a[2] == c3[2]; }
                 else if (same) same = d_bytes_equal(u, ul, u2, ul2);
                 if (!same) raise_error(w.si, GCE_ERR_UMI_MISMATCH, right);
             }
@@ -2264,8 +2265,9 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
             post[8] += 1; post_h1 += 1; post[pe ? 10 : 9] += 1;                          // outputPair: addMolecule(1, PE)
         }
     }
-    for (uint64_t i = tid0; i < (uint64_t)b.n; i += stride) {                             // writeBam -> mPostStats->addRead
-        if (!w.out_flag[i]) continue;
+    const uint64_t n_out = w.si->n_out;                                                   // (launched behind the scan that lists the emitted reads:
+    for (uint64_t r = tid0; r < n_out; r += stride) {                                     //  an eighth of the reads instead of a flag per read)
+        const uint32_t i = w.out_index[r];                                                // writeBam -> mPostStats->addRead
         gce_core k = b.core[i];
         bool mapped = k.tid >= 0;
         const int nmn = w.out_flag[i] == 1 ? (int)w.orec[i].nm_new : -1;
