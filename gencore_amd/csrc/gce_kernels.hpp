@@ -1,18 +1,21 @@
 // gce_kernels.hpp — HIP kernels of the MI355X consensus engine (gfx950, wave64).
 //
-// Pipeline (one gce_process call, everything resident in HBM):
-//   k_prescan      read classification, sortedness check, UMI slice, pre-Stats, per-chunk clustered counts
-//   k_scan_chunks  exclusive scan of the chunk counts -> tick of every clustered read
-//   k_events       locate the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
-//   k_cluster      THE CLUSTERING SCAN: key (tid,left,right,instance) -> hash partition -> (slot, rank) per read
-//   k_table_*      bucket offsets (exclusive scan over the table) + compact cluster list
-//   k_scatter      CSR fill: members[] per cluster
-//   k_pairing      per cluster: qname order, mate pairing (cluster.cpp:260-273), greedy UMI grouping (cluster.cpp:55-100)
-//   k_group_fill   compact (cluster, group) list
-//   k_score        per group: Pair::computeScore (pair.cpp:88-172) -> score bytes, quals mutated in place
-//   k_consensus    per group: template pick (group.cpp:136-318) + column vote (group.cpp:320-579), both sides
-//   k_finish       per cluster: duplex merge / filter / FR,RR tags (cluster.cpp:116-188, pair.cpp:43-68)
-//   k_stats        Stats reductions (stats.cpp:101-139)
+// Pipeline (one gce_process call, everything resident in HBM; engine.hip launches them in this order):
+//   k_prescan        read classification, sortedness check, UMI slice, pre-Stats, per-chunk clustered counts, the 32-byte ReadDesc
+//   k_scan_chunks    exclusive scan of the chunk counts -> tick of every clustered read
+//   k_events         locate the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
+//   k_cluster        THE CLUSTERING SCAN: key (tid,left,right,instance) -> bucket table -> (slot, rank) per read
+//   k_own_* k_scatter  cluster list (one claiming read per cluster) + CSR fill: members[] per cluster
+//   k_pairing_sub<16|32> (gce_pair2.hpp), k_pairing_fast, k_pairing_deep (gce_deep.hpp), k_pairing_slow
+//                    per cluster: qname order, mate pairing (cluster.cpp:260-273), greedy UMI grouping (cluster.cpp:55-100)
+//   k_group_fill, k_vote_batches   compact (cluster, group) list, batches of groups
+//   k_vote (gce_vote.hpp)   per batch of groups: Pair::computeScore (pair.cpp:88-172) + template pick (group.cpp:136-318) + column
+//                    vote (group.cpp:320-579), both sides; groups outside its scope go on through
+//   k_score2, k_consensus_fast, k_deep_prepare + k_vote_deep (gce_deep.hpp), k_consensus_slow
+//   k_group_tail, k_finish_screen, k_finish   qname reconciliation; duplex merge / filter / FR,RR tags (cluster.cpp:116-188, pair.cpp:43-68)
+//   k_out_* (gce_output.hpp)   emitted records in bamComp order as one compact table
+//   k_stats          Stats reductions (stats.cpp:101-139)
+//   k_depth (gce_depth.hpp)   depth / BED statistics on request
 #pragma once
 #include "gce_device.hpp"
 

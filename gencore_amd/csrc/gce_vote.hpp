@@ -280,11 +280,15 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __syncthreads();
     VB_TICK(1);
     // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
-    // The side's majority class = CIGAR and length of its first single-M read (see gce_lean2.hpp for the argument):
-    // group.cpp:177-261 collapse to "template = first read of the class, voters = the class" when every other read is
-    // provably unrelated to it (>= 2 CIGAR ops and a first op that is not an M block of >= len bases) and in the
-    // minority, and — right side — all positions are equal (leftReadMode).  No single-M read: one class with the same
-    // 2-/3-op CIGAR and nothing else.
+    // The side's majority class = CIGAR and length of its first single-M read.  The argument, on group.cpp:196-261: containedBy[i]
+    // = 1 + #{j != i : isPartOf(read i, read j)}.  Identical reads (same CIGAR, same length) are part of each other, so every read of a
+    // class C of n_c identical reads scores >= n_c.  A read that is UNRELATED to the class (isPartOf fails in both directions: it has >= 2
+    // CIGAR ops and its first op is not an M block of >= len bases, while the class is one M block of len bases) scores at most the
+    // number of unrelated reads, which is < n_c when the class is the strict majority.  The maximum is therefore taken by the class
+    // reads, all with the same score and the same length, and the `>` / shorter-read scan of :235-258 keeps the FIRST of them: template
+    // = first read of the class.  The voters of :287-313 are the reads isPartOf-compatible with the template = the class.  Right
+    // side: only if all positions are equal (leftReadMode).  No single-M read at all: one class with the same 2-/3-op CIGAR and
+    // nothing else.  Every side that is not of this shape hands its whole group on, untouched.
     // Right reads on different positions: not leftReadMode (group.cpp:177-194) -- isPartOf then compares CIGARs from their
     // END, containedBy only counts reads with the same right end (:220-224), columns align at the right end.  For one
     // class of identical reads (same CIGAR, length AND position) nothing changes, as long as every other read is unrelated
