@@ -1,5 +1,5 @@
 """Fuzz sweep: tests/fuzzgen.py cases over a range of seeds the test-suite does not hold, engine vs oracle (every record, both
-Stats blocks, order, error status).  Run on the GPU box:  python tools/fuzz_sweep.py [first_seed] [count] [n_mol]"""
+Stats blocks, order, error status).  Run on the GPU box:  python tests/fuzz_sweep.py [first_seed] [count] [n_mol]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
