@@ -32,6 +32,20 @@ def test_fuzz_stream(built, seed):
     run_both(batch, fuzzgen.make_params(over, contig_len), reference)
 
 
+def test_blob_offsets_beyond_4gb(built):
+    """The 32-byte read descriptor keeps 40-bit blob offsets (8 high bits each in one word): a stream whose bases and qualities
+    lie behind 4.3 / 4.6 GB of padding must give what the same reads give at offset 0."""
+    batch, over, reference, contig_len = fuzzgen.make_case(31, n_mol=50)
+    far = batch.copy()
+    pad_s, pad_q = (1 << 32) + (5 << 24) + 7, (1 << 32) + (19 << 24) + 1
+    far.seq = np.concatenate([np.full(pad_s, 0x11, np.uint8), batch.seq]); far.seq_off = batch.seq_off + np.uint64(pad_s)
+    far.qual = np.concatenate([np.full(pad_q, 30, np.uint8), batch.qual]); far.qual_off = batch.qual_off + np.uint64(pad_q)
+    params = fuzzgen.make_params(over, contig_len)
+    got_far, _ = run_both(far, params, reference)
+    got, _ = run_both(batch, params, reference)
+    assert np.array_equal(got_far.out_flag, got.out_flag)
+
+
 @pytest.mark.parametrize("seed,umi_mode,period", [(100, "duplex", 10000), (101, "duplex", 11), (102, "prefix", 5), (103, "colon", 3),
                                                     (104, "none", 2), (105, "duplex", 1), (106, "prefix", 10000)])
 def test_fuzz_umi_modes(built, seed, umi_mode, period):
