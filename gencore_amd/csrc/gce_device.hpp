@@ -468,6 +468,18 @@ __device__ __forceinline__ int wave_min(int v) {
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
     return v;
 }
+// inclusive scan over the 64 lanes of a fully active wave in six DPP adds (row shifts 1, 2, 4, 8 inside the rows of 16, then lane 15 /
+// lane 31 broadcast into the following rows): __shfl_up is a ds_bpermute round trip per step, and the scans sit in the single-wave phases
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // The same reductions on the DPP path, for fully active waves: rotations inside the rows of 16 lanes (one VALU op a step, no LDS
 // crossbar round trip), the four row results read back as scalars.  The result is wave-uniform (an SGPR).
 template <int CTRL> __device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }

@@ -145,33 +145,37 @@ __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, W
 
 // single-block exclusive scan of the chunk counts
 __global__ __launch_bounds__(1024) void k_scan_chunks(Work w, DevParams p) {
-    __shared__ unsigned int s_w[16];
-    __shared__ unsigned int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
+    __shared__ unsigned int s_w[2][16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // eight consecutive counts per thread and step: 8192 chunks between two barriers instead of 1024
-    for (int64_t base = 0; base < w.n_chunks; base += 8192) {
-        const int64_t i0 = base + 8 * (int64_t)threadIdx.x;
-        unsigned int c[8], v = 0;
+    // sixteen consecutive counts per thread and step (four 16-byte loads), wave scans on the DPP path, ONE barrier per 16384 chunks:
+    // the wave totals are double-buffered and every thread sums them for the carry itself
+    unsigned int carry = 0;
+    int it = 0;
+    for (int64_t base = 0; base < w.n_chunks; base += 16384, it ^= 1) {
+        const int64_t i0 = base + 16 * (int64_t)threadIdx.x;
+        unsigned int c[16], v = 0;
+        if (i0 + 16 <= w.n_chunks) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) { c[k] = i0 + k < w.n_chunks ? w.chunk_cnt[i0 + k] : 0; v += c[k]; }
-        unsigned int x = v;
-        for (int o = 1; o < 64; o <<= 1) { unsigned int t = __shfl_up(x, o); if (lane >= o) x += t; }
-        if (lane == 63) s_w[wv] = x;
+            for (int q = 0; q < 4; q++) { const uint4 t = reinterpret_cast<const uint4 *>(w.chunk_cnt + i0)[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) c[k] = i0 + k < w.n_chunks ? w.chunk_cnt[i0 + k] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) v += c[k];
+        const unsigned int x = (unsigned int)wave_scan_incl((int)v);
+        if (lane == 63) s_w[it][wv] = x;
         __syncthreads();
-        unsigned int woff = 0;
-        for (int k = 0; k < wv; k++) woff += s_w[k];
-        const unsigned int carry = s_carry;
+        unsigned int woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const unsigned int t = s_w[it][k]; tot += t; woff += k < wv ? t : 0u; }
         unsigned int run = carry + woff + x - v;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { if (i0 + k < w.n_chunks) w.chunk_base[i0 + k] = run; run += c[k]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + x;
-        __syncthreads();
+        for (int k = 0; k < 16; k++) { if (i0 + k < w.n_chunks) w.chunk_base[i0 + k] = run; run += c[k]; }
+        carry += tot;
     }
     if (threadIdx.x == 0) {
-        unsigned long long total = s_carry;
+        unsigned long long total = carry;
         w.si->n_clustered = total;
         long long per = p.period;
         long long e = (p.tick_offset + (long long)total) / per - p.tick_offset / per;

@@ -111,18 +111,6 @@ __global__ __launch_bounds__(256) void k_vote_batches(Work w, const unsigned lon
     }
 }
 
-// inclusive scan over the 64 lanes of a fully active wave in six DPP adds (row shifts 1, 2, 4, 8 inside the rows of 16, then lane 15 /
-// lane 31 broadcast into the following rows): __shfl_up is a ds_bpermute round trip per step, and the scans sit in the single-wave phases
-__device__ __forceinline__ int wave_scan_incl(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
 __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {       // largest s < n with pre[s] <= it  (pre ascending, pre[0] = 0)
     int lo = 0, hi = n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)pre[mid] <= it) lo = mid; else hi = mid - 1; }
