@@ -505,7 +505,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
         if (!e->have_tick) {
             hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
-            hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, 256)), dim3(256), 0, s, b, p, w);
+            hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, EV_T / 64)), dim3(EV_T), 0, s, b, p, w);
         }
     }
     HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
