@@ -556,27 +556,31 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *cnt, uint64
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
+// exclusive scan of the tile totals, one block: eight consecutive values per thread and step, one barrier per 8192 values (the wave
+// totals are double-buffered and every thread adds them up for the carry itself)
 __global__ __launch_bounds__(1024) void k_scan_partials(uint64_t *part, uint64_t nparts, unsigned long long *total_hi, unsigned long long *total_lo) {
-    __shared__ uint64_t s_w[16];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
+    __shared__ uint64_t s_w[2][16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    for (uint64_t base = 0; base < nparts; base += 1024) {
-        uint64_t i = base + threadIdx.x;
-        uint64_t v = i < nparts ? part[i] : 0, x = v;
+    uint64_t carry = 0;
+    int it = 0;
+    for (uint64_t base = 0; base < nparts; base += 8192, it ^= 1) {
+        const uint64_t i0 = base + 8 * (uint64_t)threadIdx.x;
+        uint64_t c[8], v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { c[k] = i0 + k < nparts ? part[i0 + k] : 0; v += c[k]; }
+        uint64_t x = v;
         for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
-        if (lane == 63) s_w[wv] = x;
+        if (lane == 63) s_w[it][wv] = x;
         __syncthreads();
-        uint64_t woff = 0;
-        for (int k = 0; k < wv; k++) woff += s_w[k];
-        uint64_t carry = s_carry;
-        if (i < nparts) part[i] = carry + woff + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + x;
-        __syncthreads();
+        uint64_t woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const uint64_t t = s_w[it][k]; tot += t; woff += k < wv ? t : 0ull; }
+        uint64_t run = carry + woff + x - v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (i0 + k < nparts) part[i0 + k] = run; run += c[k]; }
+        carry += tot;
     }
-    if (threadIdx.x == 0) { *total_hi = s_carry >> 32; if (total_lo) *total_lo = s_carry & 0xFFFFFFFFull; }
+    if (threadIdx.x == 0) { *total_hi = carry >> 32; if (total_lo) *total_lo = carry & 0xFFFFFFFFull; }
 }
 __global__ __launch_bounds__(256) void k_own_apply(Work w, uint64_t n) {
     __shared__ uint64_t s_w[4];
