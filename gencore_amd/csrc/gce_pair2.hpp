@@ -214,10 +214,13 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             while (__any(todo != 0)) {
                 const bool open = todo != 0;
                 const int q = open ? __ffs((int)todo) - 1 : hl;
-                const uint64_t a0 = shfl64(uw[0], hb + q); const int al = __shfl(ulen, hb + q);
+                const uint64_t a0 = shfl64(uw[0], hb + q);
                 bool eq, lt;
-                if (one_word) { eq = a0 == uw[0] && al == ulen; lt = a0 != uw[0] ? a0 < uw[0] : al < ulen; }
+                // (UMI characters are [ATCG_], never NUL: zero-padded big-endian words order and separate UMIs of different lengths
+                //  by themselves -- "AC" < "ACG", and equal words mean equal lengths; no length broadcast in the usual one-word case)
+                if (one_word) { eq = a0 == uw[0]; lt = a0 < uw[0]; }
                 else {
+                    const int al = __shfl(ulen, hb + q);
                     const uint64_t a1 = shfl64(uw[1], hb + q), a2 = shfl64(uw[2], hb + q);
                     eq = a0 == uw[0] && a1 == uw[1] && a2 == uw[2] && al == ulen;
                     lt = a0 != uw[0] ? a0 < uw[0] : (a1 != uw[1] ? a1 < uw[1] : (a2 != uw[2] ? a2 < uw[2] : al < ulen));
