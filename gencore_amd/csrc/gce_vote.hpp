@@ -4,11 +4,12 @@
 // The per-group kernels of round 1 (one wave per group, k_score2 in front) were bound by their own instruction stream: ~1800 wave
 // instructions per group, most of them bookkeeping executed with 6-19 of 64 lanes busy.  Here a workgroup of 256 threads takes a
 // batch of ~9 groups (<= 16 groups, <= 95 pairs, weight 64) through a few FLAT phases, every phase with one lane per independent item:
-//   P1  lane = pair            the two reads' descriptors into LDS; the pair's mate-overlap window (pair.cpp:108-120)
-//   P2  lane = (group, side)   consensusMergeBam for the sides this kernel covers: one class of reads with the same CIGAR and length
-//                              -- and position, when the right reads start at different positions (right-aligned mode) --
-//                              (+ a provably unrelated minority), template = first read of the class, voters = the class
-//   P3  lane = pair            mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
+//   P1  lane = pair            the two reads' descriptors into LDS; the pair's mate-overlap window (pair.cpp:108-120); what the sides'
+//                              template choice needs of their reads (masks, position range) by LDS atomics
+//   P3  (the same lanes, no barrier)  mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
+//   P2  lane = (pair, side), then lane = (group, side)   consensusMergeBam for the sides this kernel covers: one class of reads with the
+//                              same CIGAR and length -- and position, when the right reads start at different positions (right-aligned
+//                              mode) -- (+ a provably unrelated minority), template = first read of the class, voters = the class
 //   P4  lane = (side, 16 columns)  "pass A": OR / AND of the voters' packed bases (unanimity), packed max of their quals; a column
 //                              all voters agree on with top quality >= moderate takes group.cpp:421-428 (base kept, qual = max qual)
 //   P5  lane = (side, voter, contested column)  "pass B": the voter's base, quality and exact score (pair.cpp:132-169 computed on the fly,
