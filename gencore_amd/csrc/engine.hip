@@ -376,6 +376,7 @@ static int upload(gce_engine *e) {
 static int read_si(gce_engine *e) {
     HIPCHK(hipMemcpyAsync(&e->h_si, e->si.p, sizeof(StreamInfo), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) e->h_si.pre[k] += e->h_si.pre_slot[q][k];    // k_prescan's spread counters
     if (e->h_si.err_key != ~0ull) { e->dev_error = -(int)(e->h_si.err_key & 0xFF); e->dev_error_read = (uint32_t)(e->h_si.err_key >> 8); }
     return GCE_OK;
 }
@@ -501,7 +502,10 @@ int gce_process(gce_engine *e) {
     HIPCHK(hipMemsetAsync(e->chunk_cnt.p, 0, (size_t)(n_chunks + 1) * 4, s));
     if (N > 0) {
         // ---- prescan + tick scan + flush events (the latter two come with the batch for key-range shards)
-        int cpb = (int)((n_chunks + 32767) / 32768); if (cpb < 1) cpb = 1;
+#ifndef GCE_PRESCAN_BLOCKS
+#define GCE_PRESCAN_BLOCKS 32768        // at most this many blocks: their Stats partial sums end in six global atomics each
+#endif
+        int cpb = (int)((n_chunks + GCE_PRESCAN_BLOCKS - 1) / GCE_PRESCAN_BLOCKS); if (cpb < 1) cpb = 1;
         hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
         if (!e->have_tick) {
             hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);

@@ -52,6 +52,7 @@ struct DevParams {
 };
 
 // stream-level scalars produced by the prescan (device resident)
+#define GCE_PRE_SLOTS 64
 struct StreamInfo {
     unsigned long long n_clustered;      // number of clustered reads (ticks)
     unsigned int first_unmapped;         // index of the first unmapped read (U) or NONE32
@@ -73,6 +74,8 @@ struct StreamInfo {
     unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
+    long long pre_slot[GCE_PRE_SLOTS][8];   // k_prescan's six addRead counters, spread over GCE_PRE_SLOTS address sets (block & mask) and added
+                                           // up by the host: tens of thousands of blocks adding to SIX words queued behind each other
 };
 
 // Fatal conditions of the path: the reference exits on the first one it meets; the engine reports the one on the EARLIEST read

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, W
     __syncthreads();
     if (threadIdx.x < 6) {
         long long v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];
-        if (v) atomicAdd((unsigned long long *)&w.si->pre[threadIdx.x], (unsigned long long)v);
+        if (v) atomicAdd((unsigned long long *)&w.si->pre_slot[blockIdx.x & (GCE_PRE_SLOTS - 1)][threadIdx.x], (unsigned long long)v);
     }
     if (threadIdx.x == 0) {
         unsigned int u = min(min(s_unm[0], s_unm[1]), min(s_unm[2], s_unm[3]));
