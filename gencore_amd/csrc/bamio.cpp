@@ -54,6 +54,66 @@ template <class F> void parallel_for(int threads, int64_t n, F f) {          // 
     for (auto &x : th) x.join();
 }
 
+// ---- CRC-32 (gzip polynomial, reflected) by carry-less multiplication: "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ"
+// (Gopal et al., Intel 2009) -- fold four 128-bit lanes over 64 input bytes a step, fold the lanes together, reduce 128 -> 64 -> 32
+// bits (Barrett).  zlib 1.2.11's table-driven crc32 runs at 1.0 GB/s per thread, which made the checksum 45 % of a BGZF block's
+// inflate time (zlib inflates BAM data at ~0.8 GB/s).  Used only when the CPU has PCLMULQDQ and a self-check against zlib passes;
+// tails and short buffers stay with zlib.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc_fold(__m128i acc, __m128i k, __m128i next) {   // acc * x^distance mod P, plus the next 16 bytes
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(acc, k, 0x00), _mm_clmulepi64_si128(acc, k, 0x11)), next);
+}
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul_state(const uint8_t *buf, size_t len /* >= 64, multiple of 16 */, uint32_t state) {
+    // x^(n) mod P constants of the paper for the bit-reflected gzip polynomial: fold distances 4 x 128 (+-32), 128 (+-32), 64, and P / mu
+    const __m128i k_fold4 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll), k_fold1 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k_64 = _mm_set_epi64x(0, 0x0163cd6124ll), k_poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    const __m128i *p = reinterpret_cast<const __m128i *>(buf);
+    __m128i a0 = _mm_xor_si128(_mm_loadu_si128(p), _mm_cvtsi32_si128((int)state)), a1 = _mm_loadu_si128(p + 1), a2 = _mm_loadu_si128(p + 2), a3 = _mm_loadu_si128(p + 3);
+    p += 4; len -= 64;
+    for (; len >= 64; p += 4, len -= 64) {
+        a0 = crc_fold(a0, k_fold4, _mm_loadu_si128(p)); a1 = crc_fold(a1, k_fold4, _mm_loadu_si128(p + 1));
+        a2 = crc_fold(a2, k_fold4, _mm_loadu_si128(p + 2)); a3 = crc_fold(a3, k_fold4, _mm_loadu_si128(p + 3));
+    }
+    a0 = crc_fold(a0, k_fold1, a1); a0 = crc_fold(a0, k_fold1, a2); a0 = crc_fold(a0, k_fold1, a3);
+    for (; len >= 16; p += 1, len -= 16) a0 = crc_fold(a0, k_fold1, _mm_loadu_si128(p));
+    // 128 -> 64 bits
+    const __m128i low32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_xor_si128(_mm_srli_si128(a0, 8), _mm_clmulepi64_si128(a0, k_fold1, 0x10));
+    t = _mm_xor_si128(_mm_srli_si128(t, 4), _mm_clmulepi64_si128(_mm_and_si128(t, low32), k_64, 0x00));
+    // Barrett reduction 64 -> 32 bits
+    __m128i q = _mm_clmulepi64_si128(_mm_and_si128(t, low32), k_poly, 0x10);
+    q = _mm_clmulepi64_si128(_mm_and_si128(q, low32), k_poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(t, q), 1);
+}
+bool crc32_clmul_usable() {
+    static const bool ok = [] {
+        if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+        uint8_t tmp[1024 + 16];
+        uint32_t x = 0x9E3779B9u;
+        for (size_t i = 0; i < sizeof tmp; i++) { x = x * 1664525u + 1013904223u; tmp[i] = (uint8_t)(x >> 24); }
+        for (size_t off = 0; off < 3; off++)
+            for (size_t n : {(size_t)64, (size_t)80, (size_t)128, (size_t)1008, (size_t)1024}) {
+                const uint32_t want = (uint32_t)crc32(crc32(0L, Z_NULL, 0), tmp + off, (uInt)n);
+                if ((uint32_t)~crc32_clmul_state(tmp + off, n, 0xFFFFFFFFu) != want) return false;
+            }
+        return true;
+    }();
+    return ok;
+}
+#else
+bool crc32_clmul_usable() { return false; }
+uint32_t crc32_clmul_state(const uint8_t *, size_t, uint32_t s) { return s; }
+#endif
+// CRC-32 of a whole buffer (what a gzip member stores)
+uint32_t crc32_buf(const uint8_t *buf, size_t n) {
+    uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+    size_t done = 0;
+    if (n >= 64 && crc32_clmul_usable()) { done = n & ~(size_t)15; c = ~crc32_clmul_state(buf, done, 0xFFFFFFFFu); }
+    while (done < n) { const size_t m = std::min<size_t>(n - done, 1u << 30); c = (uint32_t)crc32(c, buf + done, (uInt)m); done += m; }
+    return c;
+}
+
 template <class V> bool read_file(const char *path, V &out) {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
@@ -77,7 +137,7 @@ bool inflate_block(const uint8_t *src, const Block &b, uint8_t *dst) {
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     if (rc != Z_STREAM_END || zs.total_out != b.usize) return false;
-    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.usize) == rd32(src + b.csize - 8);
+    return crc32_buf(dst, b.usize) == rd32(src + b.csize - 8);
 }
 
 // one BGZF member from `n` (<= 0xff00) bytes; returns its size
@@ -99,7 +159,7 @@ size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* 
     const size_t total = 18 + clen + 8;
     const uint16_t bsize = (uint16_t)(total - 1);
     memcpy(dst + 16, &bsize, 2);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, n);
+    const uint32_t crc = crc32_buf(src, n);
     memcpy(dst + 18 + clen, &crc, 4); memcpy(dst + 18 + clen + 4, &n, 4);
     return total;
 }

@@ -108,6 +108,36 @@ def test_bad_files_are_rejected(built, tmp_path):
         BamFile(str(bad))
 
 
+def test_checksum_of_large_blocks_is_verified(built, tmp_path):
+    """BGZF members of 64 KB go through the carry-less-multiply CRC-32 (bamio.cpp): a file written by the pure-Python writer must
+    open, and one flipped bit -- in a stored CRC, or in the payload of a stored (uncompressed) member -- must be rejected."""
+    import struct
+    import zlib
+    from gencore_amd.bamio import BamFile
+    from gencore_amd.capi import GceError
+    rng = np.random.default_rng(5)
+    recs = [dict(qname="r%05d" % i, flag=4, tid=-1, pos=-1, cigar="*", mtid=-1, mpos=-1, isize=0,
+                 seq="".join(rng.choice(list("ACGT"), 150)), qual=[int(q) for q in rng.integers(2, 41, 150)], nm=None) for i in range(3000)]
+    good = tmp_path / "g.bam"
+    pybam.write_bam(str(good), recs, [("c", 1000)])
+    f = BamFile(str(good), threads=2); assert f.info.n_records == len(recs); f.close()
+    raw = bytearray(good.read_bytes())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1              # first member (> 64 bytes of payload)
+    assert struct.unpack_from("<I", raw, bsize - 4)[0] > 4096
+    flipped = bytearray(raw); flipped[bsize - 8] ^= 0x01          # its stored CRC
+    bad = tmp_path / "b.bam"; bad.write_bytes(bytes(flipped))
+    with pytest.raises(GceError):
+        BamFile(str(bad))
+    # a member holding one stored deflate block: a payload bit flips without upsetting the deflate stream itself
+    payload = bytes(rng.integers(0, 256, 5000, dtype=np.uint8))
+    co = zlib.compressobj(0, zlib.DEFLATED, -15); cd = co.compress(payload) + co.flush()
+    member = bytearray(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(cd) + 8 - 1) + cd + struct.pack("<II", zlib.crc32(payload), len(payload)))
+    member[18 + 5 + 2000] ^= 0x10                                 # inside the stored bytes (5-byte stored-block header)
+    bad2 = tmp_path / "b2.bam"; bad2.write_bytes(bytes(member) + bytes(raw))
+    with pytest.raises(GceError):
+        BamFile(str(bad2))
+
+
 @pytest.mark.parametrize("seed", [4, 22])
 def test_writer_against_python_reader(built, oracle, tmp_path, seed):
     """gce_bam_write fed with the ORACLE's result table (as gce_result rows): the file, parsed by pybam, holds exactly the records
