@@ -126,11 +126,194 @@ template <class V> bool read_file(const char *path, V &out) {
     return got == (size_t)std::max(0l, sz);
 }
 
+// ---- raw-deflate decoder for BGZF members (RFC 1951), used in front of zlib: 64-bit bit buffer refilled eight bytes at a time, one
+// table look-up per symbol (11-bit primary table + subtables for literals/lengths, 8-bit + subtables for distances), matches copied
+// in 8-byte words.  A BGZF member is self-contained (empty window at its start, <= 64 KB out), every output byte is bounds-checked,
+// and the caller verifies the member's CRC-32 -- whatever this decoder does not handle (incomplete Huffman codes, damaged streams)
+// or gets wrong falls back to zlib's inflate, which stays the arbiter of what a valid stream is.
+namespace fastinf {
+enum : uint32_t { K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_DIST = 5 };
+constexpr int LIT_BITS = 11, DIST_BITS = 8, LIT_CAP = (1 << LIT_BITS) + 1024, DIST_CAP = (1 << DIST_BITS) + 512;
+// entry: bits 0..7 code bits to consume | 8..11 kind | 12..15 extra bits (K_SUB: subtable bits) | 16..31 value (literal, base, subtable start)
+inline uint32_t mk(uint32_t kind, uint32_t bits, uint32_t extra, uint32_t value) { return bits | kind << 8 | extra << 12 | value << 16; }
+const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+inline uint32_t sym_entry_litlen(int sym, uint32_t bits) {
+    if (sym < 256) return mk(K_LIT, bits, 0, (uint32_t)sym);
+    if (sym == 256) return mk(K_EOB, bits, 0, 0);
+    if (sym <= 285) return mk(K_LEN, bits, LEN_EXTRA[sym - 257], LEN_BASE[sym - 257]);
+    return mk(K_INVALID, bits, 0, 0);
+}
+inline uint32_t sym_entry_dist(int sym, uint32_t bits) {
+    if (sym < 30) return mk(K_DIST, bits, DIST_EXTRA[sym], DIST_BASE[sym]);
+    return mk(K_INVALID, bits, 0, 0);
+}
+inline uint32_t rev_bits(uint32_t code, int len) { uint32_t r = 0; for (int i = 0; i < len; i++) { r = r << 1 | (code & 1); code >>= 1; } return r; }
+
+// canonical Huffman code of `lens` -> look-up table.  Only COMPLETE codes are taken (Kraft sum exactly 1); returns false otherwise.
+template <class EntryOf> bool build_table(const uint8_t *lens, int nsym, int primary, uint32_t *table, int cap, EntryOf entry_of) {
+    int count[16] = {0};
+    for (int s = 0; s < nsym; s++) count[lens[s]]++;
+    count[0] = 0;
+    uint32_t kraft = 0;
+    for (int l = 1; l <= 15; l++) kraft += (uint32_t)count[l] << (15 - l);
+    if (kraft != (1u << 15)) return false;
+    uint32_t next_code[16]; { uint32_t code = 0; for (int l = 1; l <= 15; l++) { code = (code + (uint32_t)count[l - 1]) << 1; next_code[l] = code; } }
+    // reversed code of every coded symbol; the longest code behind every primary prefix
+    uint16_t rcode[288]; uint8_t sub_bits[1 << LIT_BITS];
+    const int np = 1 << primary;
+    memset(sub_bits, 0, (size_t)np);
+    for (int s = 0; s < nsym; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t r = rev_bits(next_code[l]++, l);
+        rcode[s] = (uint16_t)r;
+        if (l > primary) { uint8_t &b = sub_bits[r & (uint32_t)(np - 1)]; b = (uint8_t)std::max<int>(b, l - primary); }
+    }
+    int used = np;
+    for (int i = 0; i < np; i++) {
+        if (!sub_bits[i]) continue;
+        if (used + (1 << sub_bits[i]) > cap) return false;
+        table[i] = mk(K_SUB, (uint32_t)primary, sub_bits[i], (uint32_t)used);
+        used += 1 << sub_bits[i];
+    }
+    for (int s = 0; s < nsym; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t r = rcode[s];
+        if (l <= primary) { const uint32_t e = entry_of(s, (uint32_t)l); for (uint32_t i = r; i < (uint32_t)np; i += 1u << l) table[i] = e; }
+        else {
+            const uint32_t pi = r & (uint32_t)(np - 1), sb = sub_bits[pi], start = table[pi] >> 16, e = entry_of(s, (uint32_t)(l - primary));
+            for (uint32_t i = r >> primary; i < (1u << sb); i += 1u << (l - primary)) table[start + i] = e;
+        }
+    }
+    return true;
+}
+
+struct Tables { uint32_t lit[LIT_CAP], dist[DIST_CAP]; };
+const Tables *fixed_tables() {
+    static const Tables *t = [] {
+        Tables *x = new Tables;
+        uint8_t l[288]; for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+        uint8_t d[32]; for (int i = 0; i < 32; i++) d[i] = 5;
+        build_table(l, 288, LIT_BITS, x->lit, LIT_CAP, sym_entry_litlen); build_table(d, 32, DIST_BITS, x->dist, DIST_CAP, sym_entry_dist);
+        return x;
+    }();
+    return t;
+}
+
+// src[0, n): raw deflate; dst[0, want): exactly `want` bytes must come out.  src must be readable up to src + n + 8 (a BGZF member's
+// CRC-32 and ISIZE follow its deflate data).  false = not handled (the caller runs zlib).
+bool inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t want) {
+    const uint8_t *in = src, *const in_end = src + n;
+    uint8_t *out = dst, *const out_end = dst + want;
+    uint64_t bb = 0; int nb = 0;                                              // bit buffer, valid bits
+    const uint8_t *const lim = in_end + 8;                                    // readable up to here (the member's CRC-32 and ISIZE)
+    auto refill = [&]() -> bool {                                             // >= 56 valid bits afterwards; bits past the deflate data are whatever follows
+        uint64_t w = 0;                                                       // it (or zeros) -- a stream that needs them fails the position check at the end
+        if (in + 8 <= lim) memcpy(&w, in, 8);
+        else { if (in > lim) return false; for (int i = 0; in + i < lim; i++) w |= (uint64_t)in[i] << (8 * i); }
+        bb |= w << nb; in += (63 - nb) >> 3; nb |= 56;
+        return true;
+    };
+    Tables dyn;
+    for (bool last = false; !last;) {
+        if (!refill()) return false;
+        last = bb & 1; const uint32_t type = (uint32_t)(bb >> 1) & 3; bb >>= 3; nb -= 3;
+        if (type == 0) {                                                      // stored
+            const int drop = nb & 7; bb >>= drop; nb -= drop;
+            if (!refill()) return false;
+            const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF; bb >>= 32; nb -= 32;
+            if ((len ^ nlen) != 0xFFFF) return false;
+            const uint8_t *p = in - (nb >> 3);                                // first byte not yet consumed (nb is a multiple of 8 here)
+            if ((size_t)(in_end - p) < len || p > in_end || (size_t)(out_end - out) < len) return false;
+            memcpy(out, p, len); out += len; in = p + len; bb = 0; nb = 0;
+            continue;
+        }
+        const uint32_t *lit, *dist;
+        if (type == 1) { const Tables *f = fixed_tables(); lit = f->lit; dist = f->dist; }
+        else if (type == 2) {
+            const int hlit = (int)(bb & 31) + 257, hdist = (int)(bb >> 5 & 31) + 1, hclen = (int)(bb >> 10 & 15) + 4; bb >>= 14; nb -= 14;
+            if (hlit > 286 || hdist > 30) return false;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < hclen; i++) { if (nb < 3 && !refill()) return false; cl[order[i]] = (uint8_t)(bb & 7); bb >>= 3; nb -= 3; }
+            uint32_t clt[1 << 7];
+            if (!build_table(cl, 19, 7, clt, 1 << 7, [](int s, uint32_t bits) { return mk(K_LIT, bits, 0, (uint32_t)s); })) return false;
+            uint8_t lens[288 + 32]; int k = 0;
+            memset(lens, 0, sizeof lens);
+            while (k < hlit + hdist) {
+                if (!refill()) return false;
+                const uint32_t e = clt[bb & 127]; const int s = (int)(e >> 16); bb >>= (e & 0xFF); nb -= (int)(e & 0xFF);
+                if (s < 16) { lens[k++] = (uint8_t)s; continue; }
+                int rep; uint8_t v = 0;
+                if (s == 16) { if (k == 0) return false; v = lens[k - 1]; rep = 3 + (int)(bb & 3); bb >>= 2; nb -= 2; }
+                else if (s == 17) { rep = 3 + (int)(bb & 7); bb >>= 3; nb -= 3; }
+                else { rep = 11 + (int)(bb & 127); bb >>= 7; nb -= 7; }
+                if (k + rep > hlit + hdist) return false;
+                memset(lens + k, v, (size_t)rep); k += rep;
+            }
+            if (lens[256] == 0) return false;                                 // no end-of-block code
+            uint8_t dl[32]; memset(dl, 0, sizeof dl); memcpy(dl, lens + hlit, (size_t)hdist);
+            memset(lens + hlit, 0, (size_t)(288 - hlit));
+            if (!build_table(lens, 288, LIT_BITS, dyn.lit, LIT_CAP, sym_entry_litlen)) return false;
+            if (!build_table(dl, 32, DIST_BITS, dyn.dist, DIST_CAP, sym_entry_dist)) return false;      // (a lone distance code: zlib's business)
+            lit = dyn.lit; dist = dyn.dist;
+        } else return false;
+        for (;;) {                                                            // symbols of the block
+            if (!refill()) return false;                                      // >= 56 bits: a length/distance pair needs at most 15 + 5 + 15 + 13 = 48
+            uint32_t e = lit[bb & ((1u << LIT_BITS) - 1)];
+            if (((e >> 8) & 15) == K_SUB) { bb >>= LIT_BITS; nb -= LIT_BITS; e = lit[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 12) & 15)) - 1))]; }
+            bb >>= (e & 0xFF); nb -= (int)(e & 0xFF);
+            uint32_t kind = (e >> 8) & 15;
+            if (kind == K_LIT) {
+                if (out >= out_end) return false;
+                *out++ = (uint8_t)(e >> 16);
+                // a second and third literal from the same refill (<= 15 bits each, 56 were there)
+                e = lit[bb & ((1u << LIT_BITS) - 1)];
+                if (((e >> 8) & 15) != K_LIT) continue;
+                if (out >= out_end) return false;
+                bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
+                e = lit[bb & ((1u << LIT_BITS) - 1)];
+                if (((e >> 8) & 15) != K_LIT) continue;
+                if (out >= out_end) return false;
+                bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
+                continue;
+            }
+            if (kind == K_EOB) break;
+            if (kind != K_LEN) return false;
+            const uint32_t xl = (e >> 12) & 15, length = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1)); bb >>= xl; nb -= (int)xl;
+            uint32_t d = dist[bb & ((1u << DIST_BITS) - 1)];
+            if (((d >> 8) & 15) == K_SUB) { bb >>= DIST_BITS; nb -= DIST_BITS; d = dist[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 12) & 15)) - 1))]; }
+            bb >>= (d & 0xFF); nb -= (int)(d & 0xFF);
+            if (((d >> 8) & 15) != K_DIST) return false;
+            const uint32_t xd = (d >> 12) & 15, distance = (d >> 16) + (uint32_t)(bb & ((1u << xd) - 1)); bb >>= xd; nb -= (int)xd;
+            if (nb < 0) return false;                                         // ran past what the refill provided
+            if (distance > (size_t)(out - dst) || length > (size_t)(out_end - out)) return false;
+            const uint8_t *from = out - distance;
+            if (distance >= 8 && (size_t)(out_end - out) >= length + 8) {     // whole words (may run up to 7 bytes over the match, inside the member)
+                uint8_t *o = out; const uint8_t *f = from;
+                for (uint32_t c = 0; c < length; c += 8) { uint64_t w; memcpy(&w, f + c, 8); memcpy(o + c, &w, 8); }
+            } else for (uint32_t c = 0; c < length; c++) out[c] = from[c];
+            out += length;
+        }
+        if (nb < 0) return false;
+    }
+    if ((size_t)(in - src) * 8 - (size_t)nb > n * 8) return false;            // consumed bits past the end of the deflate data
+    return out == out_end;
+}
+}  // namespace fastinf
+
 // one raw-deflate BGZF member -> dst (usize bytes); checks the CRC
 bool inflate_block(const uint8_t *src, const Block &b, uint8_t *dst) {
     const uint16_t xlen = rd16(src + 10);
     const uint8_t *cdata = src + 12 + xlen;
     const uint32_t clen = b.csize - 12 - xlen - 8;
+    static const bool zlib_only = getenv("GCE_BAM_ZLIB_ONLY") != nullptr;     // (A/B and tests)
+    if (!zlib_only && fastinf::inflate_raw(cdata, clen, dst, b.usize) && crc32_buf(dst, b.usize) == rd32(src + b.csize - 8)) return true;
     z_stream zs; memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = clen; zs.next_out = dst; zs.avail_out = b.usize;

@@ -7,8 +7,8 @@ import zlib
 from gencore_amd.batch import pack_seq, parse_cigar  # noqa: F401 (parse_cigar re-exported for the tests)
 
 
-def bgzf_block(data):
-    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+def bgzf_block(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
     comp = co.compress(data) + co.flush()
     bsize = 18 + len(comp) + 8 - 1
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
@@ -45,7 +45,7 @@ def record_bytes(r):
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, records, targets, text="@HD\tVN:1.6\tSO:coordinate\n", block=0xff00):
+def write_bam(path, records, targets, text="@HD\tVN:1.6\tSO:coordinate\n", block=0xff00, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     """targets: list of (name, length)."""
     stream = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets))
     for nm, ln in targets:
@@ -53,7 +53,7 @@ def write_bam(path, records, targets, text="@HD\tVN:1.6\tSO:coordinate\n", block
     stream += b"".join(record_bytes(r) for r in records)
     with open(path, "wb") as f:
         for o in range(0, len(stream), block):
-            f.write(bgzf_block(stream[o:o + block]))
+            f.write(bgzf_block(stream[o:o + block], level, strategy))
         f.write(EOF_BLOCK)
 
 

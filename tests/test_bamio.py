@@ -108,6 +108,33 @@ def test_bad_files_are_rejected(built, tmp_path):
         BamFile(str(bad))
 
 
+@pytest.mark.parametrize("level,strategy", [(0, "default"), (1, "default"), (9, "default"), (6, "fixed"), (6, "huffman"), (6, "rle"), (1, "filtered")])
+def test_reader_on_every_deflate_block_type(built, tmp_path, level, strategy):
+    """bamio.cpp decodes BGZF members with its own raw-deflate decoder in front of zlib: stored, fixed-Huffman and dynamic blocks,
+    literal-only and run-length streams, short and long codes -- the batch must be the one a zlib-only pass gives, and the records
+    the ones that were written."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    strat = dict(default=zlib.Z_DEFAULT_STRATEGY, fixed=zlib.Z_FIXED, huffman=zlib.Z_HUFFMAN_ONLY, rle=zlib.Z_RLE, filtered=zlib.Z_FILTERED)[strategy]
+    batch, _, _, contig_len = fuzzgen.make_case(900 + level, n_mol=120)
+    recs = records_of(batch)
+    path = str(tmp_path / "t.bam")
+    pybam.write_bam(path, recs, [("c%d" % i, int(l)) for i, l in enumerate(contig_len)], block=0xff00 if level else 0x8000, level=level, strategy=strat)
+    from gencore_amd.bamio import BamFile
+    f = BamFile(path, threads=3)
+    got = f.batch()
+    same_batch(got, batch)
+    f.close()
+    # the same file through zlib alone (the switch is read once per process: a child)
+    code = ("import sys; sys.path[:0] = [%r, %r]\nfrom gencore_amd.bamio import BamFile\nimport numpy as np\n"
+            "f = BamFile(%r, threads=2); b = f.batch(); print(b.n, int(b.seq.astype(np.uint64).sum()), int(b.qual.astype(np.uint64).sum()))" % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), path))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, GCE_BAM_ZLIB_ONLY="1")).split()
+    assert [int(x) for x in out[-3:]] == [got.n, int(got.seq.astype(np.uint64).sum()), int(got.qual.astype(np.uint64).sum())]
+
+
 def test_checksum_of_large_blocks_is_verified(built, tmp_path):
     """BGZF members of 64 KB go through the carry-less-multiply CRC-32 (bamio.cpp): a file written by the pure-Python writer must
     open, and one flipped bit -- in a stored CRC, or in the payload of a stored (uncompressed) member -- must be rejected."""
