@@ -323,10 +323,100 @@ bool inflate_block(const uint8_t *src, const Block &b, uint8_t *dst) {
     return crc32_buf(dst, b.usize) == rd32(src + b.csize - 8);
 }
 
+// ---- "level 1" raw-deflate encoder for BGZF members: greedy LZ77 over a 2^13-entry hash of 4-byte strings (the member is its own
+// window: positions fit 16 bits), ONE fixed-Huffman block (RFC 1951 3.2.6) -- no code construction, a 64-bit bit accumulator.  Gives
+// up (returns 0) when the result would not fit a BGZF member; the caller then takes zlib as before.
+namespace fastdef {
+struct Codes {
+    uint16_t lit[286]; uint8_t lit_bits[286];              // literal / end-of-block codes, bit-reversed for the LSB-first stream
+    uint32_t len[259]; uint8_t len_bits[259];              // match length 3..258: code + extra bits in one word
+    uint8_t dcode[512];                                    // distance - 1 -> distance code (zlib's two-level index)
+};
+inline uint32_t rev(uint32_t code, int len) { uint32_t r = 0; for (int i = 0; i < len; i++) { r = r << 1 | (code & 1); code >>= 1; } return r; }
+const Codes &codes() {
+    static const Codes c = [] {
+        Codes x; memset(&x, 0, sizeof x);
+        auto fixed = [](int s, uint32_t &code, int &bits) {
+            if (s < 144) { code = 0x30 + (uint32_t)s; bits = 8; } else if (s < 256) { code = 0x190 + (uint32_t)(s - 144); bits = 9; }
+            else if (s < 280) { code = (uint32_t)(s - 256); bits = 7; } else { code = 0xC0 + (uint32_t)(s - 280); bits = 8; }
+        };
+        for (int s = 0; s <= 256; s++) { uint32_t code; int bits; fixed(s, code, bits); x.lit[s] = (uint16_t)rev(code, bits); x.lit_bits[s] = (uint8_t)bits; }
+        for (int L = 3; L <= 258; L++) {
+            int idx = 28; while (fastinf::LEN_BASE[idx] > L) idx--;
+            if (L == 258) idx = 28;
+            uint32_t code; int bits; fixed(257 + idx, code, bits);
+            x.len[L] = rev(code, bits) | (uint32_t)(L - fastinf::LEN_BASE[idx]) << bits; x.len_bits[L] = (uint8_t)(bits + fastinf::LEN_EXTRA[idx]);
+        }
+        for (int d = 1; d <= 32768; d++) {
+            int dc = 29; while (fastinf::DIST_BASE[dc] > d) dc--;
+            const int k = d - 1;
+            x.dcode[k < 256 ? k : 256 + (k >> 7)] = (uint8_t)dc;           // (all distances that share an index share a code)
+        }
+        return x;
+    }();
+    return c;
+}
+// src[0, n), n <= 65535 -> dst[0, cap); returns the size or 0
+size_t deflate_fixed(const uint8_t *src, uint32_t n, uint8_t *dst, size_t cap) {
+    const Codes &c = codes();
+    uint16_t head[1 << 13];
+    memset(head, 0, sizeof head);
+    uint8_t *out = dst, *const out_end = dst + cap;
+    uint64_t acc = 0; int nacc = 0;
+    auto put = [&](uint64_t v, int bits) -> bool {                            // bits <= 31 per call
+        acc |= v << nacc; nacc += bits;
+        if (nacc >= 32) { if (out + 4 > out_end) return false; const uint32_t w = (uint32_t)acc; memcpy(out, &w, 4); out += 4; acc >>= 32; nacc -= 32; }
+        return true;
+    };
+    if (!put(1 | 1 << 1, 3)) return 0;                                        // BFINAL = 1, BTYPE = 01
+    uint32_t i = 0;
+    while (i + 4 <= n) {
+        uint32_t cur; memcpy(&cur, src + i, 4);
+        const uint32_t h = (cur * 2654435761u) >> 19;
+        const uint32_t cand = head[h];
+        head[h] = (uint16_t)(i + 1);
+        uint32_t at;
+        if (cand && (memcpy(&at, src + cand - 1, 4), at == cur) && i - (cand - 1) <= 32768u) {
+            const uint8_t *a = src + i, *b = src + cand - 1;
+            const uint32_t maxlen = std::min<uint32_t>(258u, n - i);
+            uint32_t len = 4;
+            while (len + 8 <= maxlen) { uint64_t x, y; memcpy(&x, a + len, 8); memcpy(&y, b + len, 8); if (x != y) { len += (uint32_t)__builtin_ctzll(x ^ y) >> 3; goto done; } len += 8; }
+            while (len < maxlen && a[len] == b[len]) len++;
+        done:
+            const uint32_t d = i - (cand - 1), dc = c.dcode[d - 1 < 256 ? d - 1 : 256 + ((d - 1) >> 7)];
+            if (!put(c.len[len], c.len_bits[len])) return 0;
+            if (!put(rev(dc, 5) | (uint64_t)(d - fastinf::DIST_BASE[dc]) << 5, 5 + fastinf::DIST_EXTRA[dc])) return 0;
+            i += len;
+        } else {
+            if (!put(c.lit[src[i]], c.lit_bits[src[i]])) return 0;
+            i++;
+        }
+    }
+    for (; i < n; i++) if (!put(c.lit[src[i]], c.lit_bits[src[i]])) return 0;
+    if (!put(c.lit[256], c.lit_bits[256])) return 0;
+    while (nacc > 0) { if (out >= out_end) return 0; *out++ = (uint8_t)acc; acc >>= 8; nacc -= 8; }
+    return (size_t)(out - dst);
+}
+}  // namespace fastdef
+
 // one BGZF member from `n` (<= 0xff00) bytes; returns its size
 size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* >= 0x10000 + 64 */) {
     static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     memcpy(dst, head, 16);
+    static const bool zlib_only = getenv("GCE_BAM_ZLIB_ONLY") != nullptr;
+    if (level < 0 && !zlib_only) {                                            // level -1, "fastest": the fixed-Huffman encoder above
+        const size_t clen = fastdef::deflate_fixed(src, n, dst + 18, 0x10000 - 18 - 8);
+        if (clen) {
+            const size_t total = 18 + clen + 8;
+            const uint16_t bsize = (uint16_t)(total - 1);
+            memcpy(dst + 16, &bsize, 2);
+            const uint32_t crc = crc32_buf(src, n);
+            memcpy(dst + 18 + clen, &crc, 4); memcpy(dst + 18 + clen + 4, &n, 4);
+            return total;
+        }
+    }
+    if (level < 0) level = 1;
+    if (level > 9) level = 9;
     z_stream zs; memset(&zs, 0, sizeof zs);
     deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
     zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = n; zs.next_out = dst + 18; zs.avail_out = 0x10000 - 18 - 8;

@@ -165,8 +165,8 @@ def test_checksum_of_large_blocks_is_verified(built, tmp_path):
         BamFile(str(bad2))
 
 
-@pytest.mark.parametrize("seed", [4, 22])
-def test_writer_against_python_reader(built, oracle, tmp_path, seed):
+@pytest.mark.parametrize("seed,level", [(4, 6), (22, 1), (23, -1), (4, 0)])
+def test_writer_against_python_reader(built, oracle, tmp_path, seed, level):
     """gce_bam_write fed with the ORACLE's result table (as gce_result rows): the file, parsed by pybam, holds exactly the records
     the oracle emits -- name copies, NM patches, FR / RR appended behind the untouched aux fields."""
     import ctypes as C
@@ -194,7 +194,7 @@ def test_writer_against_python_reader(built, oracle, tmp_path, seed):
         setattr(r, name, keep[name].ctypes.data)
     r.seq_bytes, r.qual_bytes = keep["seq"].size, keep["qual"].size
     out = str(tmp_path / "out.bam")
-    assert f.lib.gce_bam_write(out.encode(), f._h, C.byref(r), 3, 6) == 0
+    assert f.lib.gce_bam_write(out.encode(), f._h, C.byref(r), 3, level) == 0      # (-1: the library's own fixed-Huffman encoder)
     text, tg, got = pybam.read_bam(out)
     assert text == "@HD\tVN:1.6\n@CO\tkeep me\n" and tg == targets
     exp = {x["src"]: x for x in want.records(batch)}
