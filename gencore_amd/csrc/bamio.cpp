@@ -1,4 +1,6 @@
-// bamio.cpp — BGZF/BAM reader and writer over zlib + FASTA loader behind the C-ABI (include/gencore_amd.h, "files" section).
+// bamio.cpp — BGZF/BAM reader and writer + FASTA loader behind the C-ABI (include/gencore_amd.h, "files" section).  BGZF members are
+// decoded by the raw-deflate decoder below with zlib as fallback and arbiter, their CRC-32 by carry-less multiplication (zlib where the
+// CPU has no PCLMULQDQ); the writer deflates with zlib (levels 0..9) or the fixed-Huffman encoder below (level -1).
 //
 // Replaces on the host what the reference does through htslib and FastaReader around the hot path:
 //   sam_open / sam_hdr_read / sam_read1        src/gencore.cpp:164-205      -> gce_bam_open (+ gce_bam_chunk: records -> gce_batch)
