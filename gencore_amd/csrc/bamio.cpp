@@ -507,10 +507,11 @@ inline AuxInfo scan_aux(const uint8_t *p, const uint8_t *end) {
 }
 
 // body -> BGZF blocks of 0xff00 bytes + the EOF marker block
-int write_bgzf(const char *path, const std::vector<uint8_t> &body, int T, int level) {
+int write_bgzf(const char *path, const Raw<uint8_t> &body, int T, int level) {
     const uint64_t BS = 0xff00;
     const int64_t nb = (int64_t)((body.size() + BS - 1) / BS);
-    std::vector<uint8_t> z((size_t)nb * 0x10000 + 64);
+    Raw<uint8_t> z; z.resize((size_t)nb * 0x10000 + 64);                      // (not a std::vector: its zero fill of these 400 MB, and of the body's, on one
+                                                                              //  thread was most of the write stage)
     std::vector<uint32_t> zs((size_t)nb, 0);
     parallel_for(T, nb, [&](int, int64_t a, int64_t e) {
         for (int64_t k = a; k < e; k++) {
@@ -786,7 +787,7 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
         }
     });
     for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
-    std::vector<uint8_t> body(hdr.size() + roff[n]);
+    Raw<uint8_t> body; body.resize(hdr.size() + roff[n]);
     memcpy(body.data(), hdr.data(), hdr.size());
     uint8_t *rb = body.data() + hdr.size();
     parallel_for(T, n, [&](int, int64_t a, int64_t e) {
@@ -851,7 +852,7 @@ int gce_bam_from_batch(const char *path, const gce_batch *b, int32_t n_targets, 
         }
     });
     for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
-    std::vector<uint8_t> body(hdr.size() + roff[n]);
+    Raw<uint8_t> body; body.resize(hdr.size() + roff[n]);
     memcpy(body.data(), hdr.data(), hdr.size());
     uint8_t *rb = body.data() + hdr.size();
     parallel_for(T, n, [&](int, int64_t a, int64_t e) {
