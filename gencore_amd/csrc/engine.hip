@@ -37,6 +37,16 @@ enum { EV_START = 0, EV_PRESCAN, EV_CLUSTER, EV_CSR, EV_PAIRING, EV_SCORE, EV_CO
 
 }  // namespace
 
+// host buffer that is NOT value-initialised: the drained bases / qualities are hundreds of MB that the copy from the device overwrites
+struct HostRaw {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    ~HostRaw() { free(p); }
+    void resize(size_t k) { if (k > cap) { free(p); p = (uint8_t *)malloc(k ? k : 1); cap = p ? k : 0; } n = p ? k : 0; }
+    uint8_t *data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+
 struct gce_engine {
     gce_params prm{};
     std::vector<uint32_t> target_len;
@@ -72,7 +82,7 @@ struct gce_engine {
     DevBuf dp_binoff, dp_regoff, dp_rs, dp_re, dp_pmax, dp_sorted, dp_depth, dp_bed;
     std::vector<int64_t> h_binoff, h_depth_pre, h_depth_post, h_bed_pre, h_bed_post;
     // host result copies
-    std::vector<uint8_t> r_kind, r_seq, r_qual; std::vector<uint32_t> r_src, r_qsrc, r_mate; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
+    std::vector<uint8_t> r_kind; HostRaw r_seq, r_qual; std::vector<uint32_t> r_src, r_qsrc, r_mate; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
     std::vector<uint64_t> r_soff, r_qoff;
 };
 
@@ -702,6 +712,7 @@ int gce_drain(gce_engine *e, gce_result *out) {
     const size_t n = (size_t)e->n_out;
     e->r_src.resize(n); e->r_kind.resize(n); e->r_qsrc.resize(n); e->r_nm.resize(n); e->r_fr.resize(n); e->r_rr.resize(n); e->r_mate.resize(n);
     e->r_soff.resize(n); e->r_qoff.resize(n); e->r_seq.resize(e->out_seq_bytes); e->r_qual.resize(e->out_qual_bytes);
+    if (e->r_seq.size() != e->out_seq_bytes || e->r_qual.size() != e->out_qual_bytes) return GCE_ERR_OOM;
     hipStream_t s = e->stream;
     if (n) {
         HIPCHK(hipMemcpyAsync(e->r_src.data(), e->o_src.p, n * 4, hipMemcpyDeviceToHost, s));
