@@ -129,13 +129,13 @@ template <class V> bool read_file(const char *path, V &out) {
 }
 
 // ---- raw-deflate decoder for BGZF members (RFC 1951), used in front of zlib: 64-bit bit buffer refilled eight bytes at a time, one
-// table look-up per symbol (11-bit primary table + subtables for literals/lengths, 8-bit + subtables for distances), matches copied
+// table look-up per symbol (10-bit primary table + subtables for literals/lengths, 8-bit + subtables for distances), matches copied
 // in 8-byte words.  A BGZF member is self-contained (empty window at its start, <= 64 KB out), every output byte is bounds-checked,
 // and the caller verifies the member's CRC-32 -- whatever this decoder does not handle (incomplete Huffman codes, damaged streams)
 // or gets wrong falls back to zlib's inflate, which stays the arbiter of what a valid stream is.
 namespace fastinf {
 enum : uint32_t { K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_DIST = 5 };
-constexpr int LIT_BITS = 11, DIST_BITS = 8, LIT_CAP = (1 << LIT_BITS) + 1024, DIST_CAP = (1 << DIST_BITS) + 512;
+constexpr int LIT_BITS = 10, DIST_BITS = 8, LIT_CAP = (1 << LIT_BITS) + 1024, DIST_CAP = (1 << DIST_BITS) + 512;
 // entry: bits 0..7 code bits to consume | 8..11 kind | 12..15 extra bits (K_SUB: subtable bits) | 16..31 value (literal, base, subtable start)
 inline uint32_t mk(uint32_t kind, uint32_t bits, uint32_t extra, uint32_t value) { return bits | kind << 8 | extra << 12 | value << 16; }
 const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
