@@ -12,6 +12,9 @@
 // per record range, record rebuild + deflate per output block.  No GPU code in this file.
 #include <zlib.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <sched.h>
 #include <algorithm>
 #include <atomic>
@@ -463,6 +466,27 @@ template <class T> struct Raw {
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
 };
+
+// the whole file into an uninitialised buffer, every thread pulling its own range (one thread copies out of the page cache at ~10 GB/s:
+// 60 ms for the 572 MB of the benchmark's file)
+bool read_file_parallel(const char *path, Raw<uint8_t> &out, int threads) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return false; }
+    const int64_t sz = (int64_t)st.st_size;
+    out.resize((size_t)sz);
+    std::atomic<int> bad{0};
+    const int64_t piece = 8 << 20;
+    parallel_for(threads, (sz + piece - 1) / piece, [&](int, int64_t a, int64_t e) {
+        for (int64_t k = a; k < e; k++) {
+            int64_t off = k * piece; const int64_t end = std::min(sz, off + piece);
+            while (off < end) { const ssize_t got = pread(fd, out.data() + off, (size_t)(end - off), (off_t)off); if (got <= 0) { bad = 1; return; } off += got; }
+        }
+    });
+    close(fd);
+    return !bad;
+}
 struct Slot {                                     // struct-of-arrays buffers of one chunk
     Raw<gce_core> core; Raw<uint64_t> qoff, coff, soff, loff, mioff;
     Raw<char> qname, mi; Raw<uint32_t> cigar; Raw<uint8_t> seq, qual, nmt; Raw<int32_t> nm;
@@ -552,7 +576,7 @@ int gce_bam_open(const char *path, int threads, gce_bam **out) {
     *out = f;
     double t0 = now_s();
     Raw<uint8_t> z;
-    if (!read_file(path, z)) { f->err = std::string("cannot read ") + path; return GCE_ERR_INVALID; }
+    if (!read_file_parallel(path, z, f->threads)) { f->err = std::string("cannot read ") + path; return GCE_ERR_INVALID; }
     f->t_read = now_s() - t0; t0 = now_s();
     // ---- BGZF members
     std::vector<Block> blocks;
