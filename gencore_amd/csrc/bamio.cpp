@@ -137,7 +137,7 @@ template <class V> bool read_file(const char *path, V &out) {
 // and the caller verifies the member's CRC-32 -- whatever this decoder does not handle (incomplete Huffman codes, damaged streams)
 // or gets wrong falls back to zlib's inflate, which stays the arbiter of what a valid stream is.
 namespace fastinf {
-enum : uint32_t { K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_DIST = 5 };
+enum : uint32_t { K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 4, K_SUB = 8, K_DIST = 6 };   // (K_LIT and K_SUB are single bits: tested with one AND)
 constexpr int LIT_BITS = 10, DIST_BITS = 8, LIT_CAP = (1 << LIT_BITS) + 1024, DIST_CAP = (1 << DIST_BITS) + 512;
 // entry: bits 0..7 code bits to consume | 8..11 kind | 12..15 extra bits (K_SUB: subtable bits) | 16..31 value (literal, base, subtable start)
 inline uint32_t mk(uint32_t kind, uint32_t bits, uint32_t extra, uint32_t value) { return bits | kind << 8 | extra << 12 | value << 16; }
@@ -271,28 +271,29 @@ bool inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t want) {
         for (;;) {                                                            // symbols of the block
             if (!refill()) return false;                                      // >= 56 bits: a length/distance pair needs at most 15 + 5 + 15 + 13 = 48
             uint32_t e = lit[bb & ((1u << LIT_BITS) - 1)];
-            if (((e >> 8) & 15) == K_SUB) { bb >>= LIT_BITS; nb -= LIT_BITS; e = lit[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 12) & 15)) - 1))]; }
-            bb >>= (e & 0xFF); nb -= (int)(e & 0xFF);
-            uint32_t kind = (e >> 8) & 15;
-            if (kind == K_LIT) {
-                if (out >= out_end) return false;
-                *out++ = (uint8_t)(e >> 16);
-                // a second and third literal from the same refill (<= 15 bits each, 56 were there)
-                e = lit[bb & ((1u << LIT_BITS) - 1)];
-                if (((e >> 8) & 15) != K_LIT) continue;
-                if (out >= out_end) return false;
+            if (e & (K_LIT << 8)) {                                           // literals first: up to four from one refill (<= 10 + 3 x 10 + ... bits of the 56)
+                if (out_end - out < 4) { if (out >= out_end) return false; bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16); continue; }
                 bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
                 e = lit[bb & ((1u << LIT_BITS) - 1)];
-                if (((e >> 8) & 15) != K_LIT) continue;
-                if (out >= out_end) return false;
+                if (!(e & (K_LIT << 8))) continue;
+                bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
+                e = lit[bb & ((1u << LIT_BITS) - 1)];
+                if (!(e & (K_LIT << 8))) continue;
+                bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
+                e = lit[bb & ((1u << LIT_BITS) - 1)];
+                if (!(e & (K_LIT << 8))) continue;
                 bb >>= (e & 0xFF); nb -= (int)(e & 0xFF); *out++ = (uint8_t)(e >> 16);
                 continue;
             }
+            if (e & (K_SUB << 8)) { bb >>= LIT_BITS; nb -= LIT_BITS; e = lit[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 12) & 15)) - 1))]; }
+            bb >>= (e & 0xFF); nb -= (int)(e & 0xFF);
+            const uint32_t kind = (e >> 8) & 15;
+            if (kind == K_LIT) { if (out >= out_end) return false; *out++ = (uint8_t)(e >> 16); continue; }      // (a literal with a long code)
             if (kind == K_EOB) break;
             if (kind != K_LEN) return false;
             const uint32_t xl = (e >> 12) & 15, length = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1)); bb >>= xl; nb -= (int)xl;
             uint32_t d = dist[bb & ((1u << DIST_BITS) - 1)];
-            if (((d >> 8) & 15) == K_SUB) { bb >>= DIST_BITS; nb -= DIST_BITS; d = dist[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 12) & 15)) - 1))]; }
+            if (d & (K_SUB << 8)) { bb >>= DIST_BITS; nb -= DIST_BITS; d = dist[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 12) & 15)) - 1))]; }
             bb >>= (d & 0xFF); nb -= (int)(d & 0xFF);
             if (((d >> 8) & 15) != K_DIST) return false;
             const uint32_t xd = (d >> 12) & 15, distance = (d >> 16) + (uint32_t)(bb & ((1u << xd) - 1)); bb >>= xd; nb -= (int)xd;
@@ -302,7 +303,8 @@ bool inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t want) {
             if (distance >= 8 && (size_t)(out_end - out) >= length + 8) {     // whole words (may run up to 7 bytes over the match, inside the member)
                 uint8_t *o = out; const uint8_t *f = from;
                 for (uint32_t c = 0; c < length; c += 8) { uint64_t w; memcpy(&w, f + c, 8); memcpy(o + c, &w, 8); }
-            } else for (uint32_t c = 0; c < length; c++) out[c] = from[c];
+            } else if (distance == 1) memset(out, from[0], length);           // a run of one byte (quality strings are full of them)
+            else for (uint32_t c = 0; c < length; c++) out[c] = from[c];
             out += length;
         }
         if (nb < 0) return false;
