@@ -235,12 +235,12 @@ def main():
     kernels = {
         "cluster": dict(ms=avg["cluster_ms"], algorithmic_bytes=cluster_bytes),
         "consensus": dict(ms=avg["score_ms"] + avg["consensus_ms"], algorithmic_bytes=consensus_bytes),
-        "cluster_formation": dict(ms=avg["prescan_ms"] + avg["cluster_ms"] + avg["csr_ms"], algorithmic_bytes=cluster_bytes),
+        "cluster_formation": dict(ms=avg["cluster_ms"] + avg["csr_ms"], algorithmic_bytes=cluster_bytes),
     }
     for v in kernels.values():
         v["achieved_gbs"] = v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
         v["frac"] = v["achieved_gbs"] / HBM_PEAK_GBS
-    phase_ms = {k: avg[k] for k in ("prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms", "total_ms")}
+    phase_ms = {k: avg[k] for k in ("cluster_ms", "csr_ms", "describe_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms", "total_ms")}
     dom = "consensus" if kernels["consensus"]["ms"] >= kernels["cluster"]["ms"] else "cluster"
     # HBM traffic of the dominant phase from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # same command: profiles/hbm_traffic.json, tools/hbm_summary.py): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -260,7 +260,7 @@ def main():
                     clustering_scan=dict(achieved=round(kernels["cluster"]["achieved_gbs"], 2), frac=round(kernels["cluster"]["frac"], 5),
                                          ms=round(kernels["cluster"]["ms"], 4), algorithmic_bytes=round(cluster_bytes),
                                          traffic=(round(traffic["cluster"]) if traffic and traffic["cluster"] else None)),
-                    cluster_formation=dict(what="k_prescan + table clear + k_cluster + cluster/member lists against the same 40 B/read",
+                    cluster_formation=dict(what="everything that forms the clusters (SURVEY 8 A1-A3): k_cluster + tick scan + flush events + leader table + cluster/member lists, against the same 40 B/read; the bucket table is wiped by its users, no memset",
                                            ms=round(kernels["cluster_formation"]["ms"], 4), frac=round(kernels["cluster_formation"]["frac"], 5)),
                     phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3))
 

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-GCE_ABI_VERSION = 2
+GCE_ABI_VERSION = 3
 GCE_NONE = 0xFFFFFFFF
 GCE_MAX_SUPPORTING_READS = 100
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
@@ -85,7 +85,7 @@ class GceResult(C.Structure):
 
 class GceTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
-        "total_ms", "prescan_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms")] + [
+        "total_ms", "describe_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms")] + [
         ("n_clusters", C.c_int64), ("n_groups", C.c_int64), ("n_pairs", C.c_int64)]
 
     def as_dict(self):

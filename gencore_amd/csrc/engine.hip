@@ -33,7 +33,7 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
-enum { EV_START = 0, EV_PRESCAN, EV_CLUSTER, EV_CSR, EV_PAIRING, EV_SCORE, EV_CONSENSUS, EV_FINISH, EV_OUTPUT, EV_COUNT };
+enum { EV_START = 0, EV_CLUSTER, EV_CSR, EV_DESCRIBE, EV_PAIRING, EV_SCORE, EV_CONSENSUS, EV_FINISH, EV_OUTPUT, EV_COUNT };
 
 }  // namespace
 
@@ -67,12 +67,13 @@ struct gce_engine {
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
-    DevBuf cls, umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, orec, out_index;
+    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, orec, out_index;
     // output table (gce_result): device arrays + host copies
     DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_rowof, o_units, o_soff, o_qoff, o_seq, o_qual, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
-    DevBuf chunk_cnt, chunk_base, ev_tid, ev_pos, ev_read, table, toff;
-    DevBuf cl_slot, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
+    DevBuf lrec, lout, ldst, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
+    bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_ldst wipes what a step used)
+    DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
     DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
@@ -147,10 +148,10 @@ void gce_destroy(gce_engine *e) {
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
-                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->cls, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
+                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
                      &e->slot, &e->rank, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
-                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->chunk_cnt,
-                     &e->chunk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_slot, &e->cl_start, &e->cl_n,
+                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->ldst, &e->bhdr,
+                     &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
@@ -386,7 +387,7 @@ static int upload(gce_engine *e) {
 static int read_si(gce_engine *e) {
     HIPCHK(hipMemcpyAsync(&e->h_si, e->si.p, sizeof(StreamInfo), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) e->h_si.pre[k] += e->h_si.pre_slot[q][k];    // k_prescan's spread counters
+    for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) e->h_si.pre[k] += e->h_si.pre_slot[q][k];    // k_describe's spread counters
     if (e->h_si.err_key != ~0ull) { e->dev_error = -(int)(e->h_si.err_key & 0xFF); e->dev_error_read = (uint32_t)(e->h_si.err_key >> 8); }
     return GCE_OK;
 }
@@ -466,37 +467,40 @@ int gce_process(gce_engine *e) {
 
     // ---- allocations that only depend on N
     Work w{};
-    const int64_t n_chunks = (N + CHUNK - 1) / CHUNK;
-    w.n_chunks = n_chunks;
+    const int64_t n_sblk = (N + SB_READS - 1) / SB_READS;
+    w.n_sblk = n_sblk;
     const int64_t max_events = e->have_tick ? (int64_t)e->h_ev_tid.size() + 2 : (p.tick_offset % p.period + N) / p.period + 2;
     w.max_events = (int)max_events;
     // buckets: 1.25 x reads (worst case, every read its own cluster, still probes at load 0.8; typical load is a few percent).
-    // The per-step clear is proportional to T, so T is not rounded to a power of two.
     uint64_t T = ((uint64_t)n1 + (uint64_t)n1 / 4 + 2 * SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
     w.tsize = T; w.tinv = 1.0 / (double)T;
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
+    const size_t nsb1 = (size_t)(n_sblk > 0 ? n_sblk : 1);
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
-    ENS(cls, n1); ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4); ENS(rank, n1 * 4); ENS(score, qual_bytes + 64);
+    ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(rank, n1 * 4 + 16); ENS(score, qual_bytes + 64);
     ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
-    ENS(chunk_cnt, (size_t)(n_chunks + 1) * 4); ENS(chunk_base, (size_t)(n_chunks + 1) * 4);
+    ENS(lrec, nsb1 * SB_READS * sizeof(LeadRec)); ENS(lout, nsb1 * SB_READS * sizeof(LeadOut)); ENS(ldst, nsb1 * SB_READS * 4);
+    ENS(bhdr, nsb1 * sizeof(BlkHdr)); ENS(blk_base, nsb1 * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
     ENS(table, T * sizeof(TabEntry)); ENS(toff, T * 4);
     ENS(k64, n1 * 24); ENS(members, n1 * 4); ENS(sorted, n1 * 4); ENS(pl, n1 * 4); ENS(pr, n1 * 4); ENS(pu, n1 * 4); ENS(pg, n1 * 4); ENS(gpl, n1 * 4); ENS(gpr, n1 * 4);
     ENS(grp_begin, n1 * 4); ENS(grp_n, n1 * 4); ENS(slow_list, n1 * 4 + 64);
     w.slow_list = e->slow_list.as<uint32_t>();
     ENS(deep_list, (n1 / 64 + 64) * 16); w.deep_list = e->deep_list.p;
-    const unsigned nblk_T = cdiv(T, SCAN_TILE), nblk_N = cdiv(n1, SCAN_TILE);
-    ENS(scan_part, (size_t)(nblk_T > 2 * nblk_N ? nblk_T : 2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
-    w.cls = e->cls.as<uint8_t>(); w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
+    const unsigned nblk_N = cdiv(n1, SCAN_TILE);
+    ENS(scan_part, std::max<size_t>(nsb1, (size_t)2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
+    w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
-    w.chunk_cnt = e->chunk_cnt.as<uint32_t>(); w.chunk_base = e->chunk_base.as<uint32_t>();
+    w.lrec = e->lrec.as<LeadRec>(); w.lout = e->lout.as<LeadOut>(); w.ldst = e->ldst.as<uint32_t>(); w.bhdr = e->bhdr.as<BlkHdr>(); w.blk_base = e->blk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
     w.tab = e->table.as<TabEntry>(); w.toff = e->toff.as<uint32_t>();
     w.k64 = e->k64.as<uint64_t>(); w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
     w.pu = e->pu.as<uint32_t>(); w.pg = e->pg.as<uint32_t>(); w.gpl = e->gpl.as<uint32_t>(); w.gpr = e->gpr.as<uint32_t>();
     w.grp_begin = e->grp_begin.as<uint32_t>(); w.grp_n = e->grp_n.as<uint32_t>();
     w.scan_part = e->scan_part.as<uint64_t>(); w.si = e->si.as<StreamInfo>();
+    ENS(cl_ikey, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);      // cl_* arrays are sized by N (a cluster has >= 1 read)
+    w.cl_ikey = e->cl_ikey.as<uint32_t>(); w.cl_start = e->cl_start.as<uint32_t>(); w.cl_n = e->cl_n.as<uint32_t>();
 
     StreamInfo init{}; init.first_unmapped = NONE32; init.err_key = ~0ull;
     if (e->have_tick) { init.n_events = init.n_events_a = (int)e->h_ev_tid.size(); }
@@ -506,45 +510,54 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemcpyAsync(e->ev_pos.p, e->h_ev_pos.data(), e->h_ev_pos.size() * 4, hipMemcpyHostToDevice, e->stream));
     }
     hipStream_t s = e->stream;
-    HIPCHK(hipEventRecord(e->ev[EV_START], s));
-    HIPCHK(hipMemsetAsync(e->table.p, 0, T * sizeof(TabEntry), s));
-    HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
-    HIPCHK(hipMemsetAsync(e->chunk_cnt.p, 0, (size_t)(n_chunks + 1) * 4, s));
-    if (N > 0) {
-        // ---- prescan + tick scan + flush events (the latter two come with the batch for key-range shards)
-#ifndef GCE_PRESCAN_BLOCKS
-#define GCE_PRESCAN_BLOCKS 32768        // at most this many blocks: their Stats partial sums end in six global atomics each
-#endif
-        int cpb = (int)((n_chunks + GCE_PRESCAN_BLOCKS - 1) / GCE_PRESCAN_BLOCKS); if (cpb < 1) cpb = 1;
-        hipLaunchKernelGGL(k_prescan, dim3(cdiv(n_chunks, cpb)), dim3(CHUNK), 0, s, b, p, w, cpb);
-        if (!e->have_tick) {
-            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, w, p);
-            hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, EV_T / 64)), dim3(EV_T), 0, s, b, p, w);
-        }
+    // The bucket table is cleared by its users (k_ldst): a memset only for a new allocation or after a step that did not get that far.
+    if (!e->tab_clean || e->tab_clean_ptr != e->table.p) {
+        HIPCHK(hipMemsetAsync(e->table.p, 0, e->table.cap, s));
+        e->tab_clean_ptr = e->table.p;
     }
-    HIPCHK(hipEventRecord(e->ev[EV_PRESCAN], s));
-    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)cdiv(n_chunks, CL_U)), dim3(CHUNK), 0, s, b, p, w);
+    e->tab_clean = false;
+    HIPCHK(hipEventRecord(e->ev[EV_START], s));
+    HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
+    // ---- cluster formation (gce_cluster.hpp): the scan, then the leaders (ticks + flush events come with the batch for key-range shards)
+    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, b, p, w);
 #ifdef CL_PROF
     if (N > 0) {
         StreamInfo hs; (void)hipStreamSynchronize(s); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
-        static const char *nm[6] = {"key records", "events + instance", "LDS leaders", "first CAS", "probe + count", "stores"};
+        static const char *nm[3] = {"key records + keys", "LDS leaders", "stores"};
         const double blocks = (double)hs.prof[15];
         fprintf(stderr, "k_cluster phases, mean per block (us), %.0f blocks:", blocks);
-        for (int k = 0; k < 6; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
+        for (int k = 0; k < 3; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
         fprintf(stderr, "\n");
     }
 #endif
     HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
-    // ---- bucket offsets + compact cluster list.  cl_* arrays are sized by N (a cluster has >= 1 read).
-    ENS(cl_slot, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);
-    w.cl_slot = e->cl_slot.as<uint32_t>(); w.cl_start = e->cl_start.as<uint32_t>(); w.cl_n = e->cl_n.as<uint32_t>();
-    hipLaunchKernelGGL(k_own_reduce, dim3(nblk_N), dim3(256), 0, s, w, (uint64_t)N);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_clusters, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(k_own_apply, dim3(nblk_N), dim3(256), 0, s, w, (uint64_t)N);
-    if (N > 0) hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 256)), dim3(256), 0, s, N, w);
+    if (N > 0) {
+        if (!e->have_tick) {
+            hipLaunchKernelGGL(k_blk_scan, dim3(1), dim3(1024), 0, s, w, p);
+            hipLaunchKernelGGL(k_events, dim3(cdiv(max_events, EV_T / 64)), dim3(EV_T), 0, s, b, p, w);
+        }
+        const unsigned nb4 = cdiv(n_sblk, 4);
+        hipLaunchKernelGGL(k_leaders, dim3(nb4), dim3(256), 0, s, b, p, w);
+        hipLaunchKernelGGL(k_num_reduce, dim3(nb4), dim3(256), 0, s, w);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)n_sblk, &w.si->n_clusters, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_num_apply, dim3(nb4), dim3(256), 0, s, w);
+        hipLaunchKernelGGL(k_ldst, dim3(nb4), dim3(256), 0, s, w);
+        hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 512)), dim3(256), 0, s, N, w);
+    }
     HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
+    // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote
+    if (N > 0) {
+#ifndef GCE_DESCRIBE_BLOCKS
+#define GCE_DESCRIBE_BLOCKS 32768        // at most this many blocks: their Stats partial sums end in six global atomics each
+#endif
+        const int64_t n_tiles = (N + 255) / 256;
+        int tpb = (int)((n_tiles + GCE_DESCRIBE_BLOCKS - 1) / GCE_DESCRIBE_BLOCKS); if (tpb < 1) tpb = 1;
+        hipLaunchKernelGGL(k_describe, dim3(cdiv(n_tiles, tpb)), dim3(256), 0, s, b, p, w, tpb);
+    }
+    HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
+    e->tab_clean = true;                          // k_ldst ran to the end
     const uint32_t C = (uint32_t)e->h_si.n_clusters;
     const size_t c1 = C ? C : 1;
     ENS(cl_npairs, c1 * 4); ENS(cl_ngroups, c1 * 4); ENS(cl_gbase, c1 * 4); ENS(cl_nresult, c1 * 4); ENS(cl_hasumi, c1);
@@ -677,8 +690,8 @@ int gce_process(gce_engine *e) {
     float ms = 0;
     auto el = [&](int a, int c) { ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[c]); return (double)ms; };
     e->timing.total_ms = el(EV_START, EV_OUTPUT);
-    e->timing.prescan_ms = el(EV_START, EV_PRESCAN); e->timing.cluster_ms = el(EV_PRESCAN, EV_CLUSTER); e->timing.csr_ms = el(EV_CLUSTER, EV_CSR);
-    e->timing.pairing_ms = el(EV_CSR, EV_PAIRING); e->timing.score_ms = el(EV_PAIRING, EV_SCORE); e->timing.consensus_ms = el(EV_SCORE, EV_CONSENSUS);
+    e->timing.cluster_ms = el(EV_START, EV_CLUSTER); e->timing.csr_ms = el(EV_CLUSTER, EV_CSR); e->timing.describe_ms = el(EV_CSR, EV_DESCRIBE);
+    e->timing.pairing_ms = el(EV_DESCRIBE, EV_PAIRING); e->timing.score_ms = el(EV_PAIRING, EV_SCORE); e->timing.consensus_ms = el(EV_SCORE, EV_CONSENSUS);
     e->timing.finish_ms = el(EV_CONSENSUS, EV_FINISH); e->timing.output_ms = el(EV_FINISH, EV_OUTPUT);
     e->timing.n_clusters = C; e->timing.n_groups = NG;
     if (e->dev_error != 0) {

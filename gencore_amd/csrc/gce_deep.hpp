@@ -300,7 +300,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         }
         __syncthreads();
         if (!take || s_flag) { if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }
-        const uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
+        const uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
         if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } continue; }
 #ifdef VB_PROF
         unsigned long long pd_prev_ = wall_clock64();

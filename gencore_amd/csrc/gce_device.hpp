@@ -68,6 +68,7 @@ struct StreamInfo {
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     unsigned long long n_pairs_total;    // pairs over all processed clusters
     unsigned long long vote_weight;      // sum of the group weights: k_vote runs vote_weight / VB_W + 1 batches
+    unsigned long long n_leaders;        // (cluster, scan block) runs of the clustering scan
     unsigned long long out_units;        // size of the compact output blobs in 16-byte units: bases << 32 | qualities
     unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one

@@ -1,11 +1,11 @@
 // gce_kernels.hpp — HIP kernels of the MI355X consensus engine (gfx950, wave64).
 //
 // Pipeline (one gce_process call, everything resident in HBM; engine.hip launches them in this order):
-//   k_prescan        read classification, sortedness check, UMI slice, pre-Stats, per-chunk clustered counts, the 32-byte ReadDesc
-//   k_scan_chunks    exclusive scan of the chunk counts -> tick of every clustered read
-//   k_events         locate the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
-//   k_cluster        THE CLUSTERING SCAN: key (tid,left,right,instance) -> bucket table -> (slot, rank) per read
-//   k_own_* k_scatter  cluster list (one claiming read per cluster) + CSR fill: members[] per cluster
+//   k_cluster        THE CLUSTERING SCAN (gce_cluster.hpp): class, key (tid,left,right), block-level leaders -> (leader, rank) per read
+//   k_blk_scan, k_events   ticks of the scan blocks; the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
+//   k_leaders        one lane per leader: instance from the flush events, bucket table -> cluster of every leader run
+//   k_num_* k_ldst k_scatter  cluster list (one claiming leader per cluster) + CSR fill: members[] per cluster
+//   k_describe       per read: the 32-byte ReadDesc, UMI slice, pre-Stats
 //   k_pairing_sub<16|32> (gce_pair2.hpp), k_pairing_fast, k_pairing_deep (gce_deep.hpp), k_pairing_slow
 //                    per cluster: qname order, mate pairing (cluster.cpp:260-273), greedy UMI grouping (cluster.cpp:55-100)
 //   k_group_fill, k_vote_batches   compact (cluster, group) list, batches of groups
@@ -28,7 +28,6 @@ static_assert(sizeof(OutRec) == 16, "OutRec must stay 16 bytes");
 
 struct Work {
     // per read
-    uint8_t *cls;
     const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
     ReadDescP *rdesc;
     uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
@@ -37,14 +36,15 @@ struct Work {
     // outputs per read: out_flag for every read (0 = not emitted, 1 = outputPair, 2 = pass-through); orec only where out_flag == 1
     uint8_t *out_flag; OutRec *orec;
     uint32_t *out_index;                 // emitted reads, ascending
-    // tick scan
-    uint32_t *chunk_cnt, *chunk_base; int64_t n_chunks;
+    // scan blocks (gce_cluster.hpp): leaders of every block, what k_leaders made of them, where their runs start in members[]
+    struct LeadRec *lrec; struct LeadOut *lout; uint32_t *ldst;
+    struct BlkHdr *bhdr; uint32_t *blk_base; int64_t n_sblk;   // per scan block: leaders + clustered reads; clustered reads in front of the block
     // events
     int32_t *ev_tid, *ev_pos; uint32_t *ev_read; int max_events;
     // hash table
     struct TabEntry *tab; uint32_t *toff; uint64_t tsize; double tinv;   // tsize buckets (any size, not a power of two); toff is written sparsely
     // clusters
-    uint32_t *cl_slot, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
+    uint32_t *cl_ikey, *cl_start, *cl_n, *cl_npairs, *cl_ngroups, *cl_gbase, *cl_nresult; uint8_t *cl_hasumi;
     // cluster-local arrays (indexed by cl_start + k)
     uint32_t *members, *sorted, *pl, *pr, *pu, *pg, *gpl, *gpr, *grp_begin, *grp_n;
     uint64_t *k64;                       // generic pairing scratch: 3 words per read (name window / UMI words)
@@ -81,541 +81,7 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
     return v;
 }
 
-// ===================================================================================================== prescan
-__global__ __launch_bounds__(CHUNK, 8) void k_prescan(DevBatch b, DevParams p, Work w, int chunks_per_block) {
-    __shared__ long long s_stat[WAVES_PER_BLOCK][6];
-    __shared__ unsigned int s_unm[WAVES_PER_BLOCK];
-    long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
-    unsigned int first_unm = NONE32;
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    for (int cb = 0; cb < chunks_per_block; cb++) {
-        int64_t chunk = (int64_t)blockIdx.x * chunks_per_block + cb;
-        if (chunk >= w.n_chunks) break;
-        int64_t i = chunk * CHUNK + threadIdx.x;
-        uint8_t c = CLS_DROP;
-        if (i < b.n) {
-            gce_core k = b.core[i];
-            c = d_classify(k);
-            if (i > 0) {                                                       // gencore.cpp:233-241
-                int ptid = b.core[i - 1].tid, ppos = b.core[i - 1].pos;
-                if ((k.tid < ptid || (k.tid == ptid && k.pos < ppos)) && k.tid >= 0 && k.pos >= 0) raise_error(w.si, GCE_ERR_UNSORTED, (uint32_t)i);
-            }
-            bool mapped = k.tid >= 0;                                          // Stats::addRead, stats.cpp:101-121
-            int mism = (mapped && b.nm_type[i]) ? b.nm[i] : 0;
-            st[0] += 1; st[1] += k.l_qseq; st[4] += mism;
-            if (!mapped) { st[2] += 1; st[3] += k.l_qseq; }
-            if (mism > 0) st[5] += 1;
-            if (k.tid < 0 || k.pos < 0) { if ((unsigned)i < first_unm) first_unm = (unsigned)i; }
-            w.cls[i] = c;
-            if (c == CLS_BYPASS) w.out_flag[i] = 2;                            // (out_flag is cleared by a memset; nothing else is initialised per read)
-            if (c == CLS_CLUSTERED) {
-                const uint32_t *cg = b.cigar + b.cigar_off[i];
-                const uint32_t c0w = k.n_cigar ? cg[0] : 0;
-                int mo_ = 0, ml_ = 0;
-                if (k.n_cigar == 1) ml_ = cig_op(c0w) == 0 ? cig_len(c0w) : 0;
-                else d_first_m(cg, k.n_cigar, mo_, ml_);
-                if (k.l_qseq > 65535) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)i);      // the 16-bit fields of the descriptor (and of the overlap patches)
-                store_desc(w.rdesc, (uint64_t)i, b.seq_off[i], b.qual_off[i], c0w, k.pos, k.isize != 0, k.l_qseq, mo_, ml_, k.n_cigar, k.tid, k.n_cigar > 1 ? cg[k.n_cigar - 1] : c0w);
-            }
-            if (c == CLS_CLUSTERED) {                                          // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38
-                const char *src; uint8_t hm = 0;
-                if (b.mi && b.mi_off[i] != 0xFFFFFFFFFFFFFFFFull) { src = b.mi + b.mi_off[i]; hm = 1; }
-                else src = b.qname + b.qname_off[i];
-                int s0, l0;
-                if (!d_umi_slice(src, p, s0, l0, hm ? -1 : (int)k.l_qname - 1)) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); s0 = 0; l0 = 0; }
-                w.umi_ptr[i] = src + s0; w.umi_len[i] = (uint16_t)l0; w.has_mi[i] = hm;
-            }
-        }
-        unsigned long long m = __ballot(c == CLS_CLUSTERED);
-        if (lane == 0 && m) atomicAdd(&w.chunk_cnt[chunk], (unsigned int)__popcll(m));   // (cleared by a memset: no barrier between the chunks of a block)
-    }
-    for (int k = 0; k < 6; k++) { long long v = wave_sum64(st[k]); if (lane == 0) s_stat[wv][k] = v; }
-    unsigned int fu = (unsigned)wave_min((int)(first_unm ^ 0x80000000u)) ^ 0x80000000u;   // unsigned min via signed flip
-    if (lane == 0) s_unm[wv] = fu;
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        long long v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];
-        if (v) atomicAdd((unsigned long long *)&w.si->pre_slot[blockIdx.x & (GCE_PRE_SLOTS - 1)][threadIdx.x], (unsigned long long)v);
-    }
-    if (threadIdx.x == 0) {
-        unsigned int u = min(min(s_unm[0], s_unm[1]), min(s_unm[2], s_unm[3]));
-        if (u != NONE32) atomicMin(&w.si->first_unmapped, u);
-    }
-}
-
-// single-block exclusive scan of the chunk counts
-__global__ __launch_bounds__(1024) void k_scan_chunks(Work w, DevParams p) {
-    __shared__ unsigned int s_w[2][16];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // sixteen consecutive counts per thread and step (four 16-byte loads), wave scans on the DPP path, ONE barrier per 16384 chunks:
-    // the wave totals are double-buffered and every thread sums them for the carry itself
-    unsigned int carry = 0;
-    int it = 0;
-    for (int64_t base = 0; base < w.n_chunks; base += 16384, it ^= 1) {
-        const int64_t i0 = base + 16 * (int64_t)threadIdx.x;
-        unsigned int c[16], v = 0;
-        if (i0 + 16 <= w.n_chunks) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const uint4 t = reinterpret_cast<const uint4 *>(w.chunk_cnt + i0)[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) c[k] = i0 + k < w.n_chunks ? w.chunk_cnt[i0 + k] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) v += c[k];
-        const unsigned int x = (unsigned int)wave_scan_incl((int)v);
-        if (lane == 63) s_w[it][wv] = x;
-        __syncthreads();
-        unsigned int woff = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const unsigned int t = s_w[it][k]; tot += t; woff += k < wv ? t : 0u; }
-        unsigned int run = carry + woff + x - v;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { if (i0 + k < w.n_chunks) w.chunk_base[i0 + k] = run; run += c[k]; }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) {
-        unsigned long long total = carry;
-        w.si->n_clustered = total;
-        long long per = p.period;
-        long long e = (p.tick_offset + (long long)total) / per - p.tick_offset / per;
-        w.si->n_events = (int)(e < w.max_events ? e : w.max_events);
-        if (e > w.max_events) raise_error(w.si, GCE_ERR_INVALID, 0);
-    }
-}
-
-// one WAVE per flush event: find the read on which tick % period == 0 (gencore.cpp:319-322) -- the chunk by a 64-ary search over the
-// chunk bases, the read inside it by ballots over the chunk's classes (one thread walking the 256 reads: 47 us for 2000 events)
-#define EV_T 1024                                                     // 16 events per block: one global atomic per block for the segment count
-__global__ __launch_bounds__(EV_T) void k_events(DevBatch b, DevParams p, Work w) {
-    __shared__ int s_a;
-    if (threadIdx.x == 0) s_a = 0;
-    __syncthreads();
-    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();      // event j+1
-    const int E = w.si->n_events;
-    if (j < E) {
-        const long long per = p.period;
-        const long long gt = (p.tick_offset / per + (j + 1)) * per;      // global tick of this event
-        const unsigned int t = (unsigned int)(gt - p.tick_offset);       // local inclusive count, >= 1
-        int64_t lo = 0, hi = w.n_chunks - 1;                             // last chunk with chunk_base < t (chunk_base[0] = 0 < t):
-        while (lo < hi) {                                                // 64-ary search, three dependent round trips instead of seventeen
-            const int64_t step = (hi - lo + 63) / 64, probe = lo + (int64_t)(lane + 1) * step;
-            const bool below = probe <= hi && w.chunk_base[probe] < t;   // true for a prefix of the lanes (the bases do not decrease)
-            const int k = __popcll(__ballot(below));
-            hi = min(hi, lo + (int64_t)(k + 1) * step - 1);
-            lo = lo + (int64_t)k * step;
-        }
-        unsigned int need = t - w.chunk_base[lo];                        // the need-th clustered read of the chunk
-        const int64_t i0 = lo * CHUNK, end = min(b.n, i0 + CHUNK);
-        int64_t i = end;
-        bool clq[CHUNK / 64];                                            // (all of the chunk's classes in one round trip)
-#pragma unroll
-        for (int q = 0; q < CHUNK / 64; q++) { const int64_t idx = i0 + 64 * q + lane; clq[q] = idx < end && w.cls[idx] == CLS_CLUSTERED; }
-#pragma unroll
-        for (int q = 0; q < CHUNK / 64; q++) {
-            const bool cl = clq[q];
-            const unsigned long long m = __ballot(cl);
-            const unsigned int cnt = (unsigned int)__popcll(m);
-            if (need <= cnt) {
-                const unsigned long long hit = __ballot(cl && (unsigned int)__popcll(m & ((1ull << lane) - 1ull)) + 1u == need);
-                i = i0 + 64 * q + (__ffsll((long long)hit) - 1);
-                break;
-            }
-            need -= cnt;
-        }
-        if (lane == 0) {
-            w.ev_read[j] = (uint32_t)i;
-            w.ev_tid[j] = b.core[i].tid;
-            w.ev_pos[j] = b.core[i].pos;
-            if ((uint32_t)i < w.si->first_unmapped) atomicAdd(&s_a, 1);  // (2000 adds to one global word were 24 of the kernel's 47 us)
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_a) atomicAdd(&w.si->n_events_a, s_a);
-}
-
-// ===================================================================================================== clustering scan
-// thr_mode of an instance (see DESIGN.md "flush rule in closed form")
-__device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *si, const DevParams &p) {
-    uint32_t inst = ikey & 0x7FFFFFFFu, seg_b = ikey >> 31;
-    if (!seg_b) {
-        if ((int)(inst + 1) <= si->n_events_a) return THR_PROPER;
-        if (si->first_unmapped != NONE32) return THR_UNPROPER;
-        return p.trailing_flush ? THR_PROPER : THR_UNPROPER;
-    }
-    return ((int)(inst + 1) <= si->n_events) ? THR_PROPER : THR_NEVER;
-}
-
-// The bucket table: 16 bytes per bucket, the cluster's whole identity in the CAS word itself so that nobody ever has to WAIT for a
-// claimer to publish something (a wait on a lane of one's own wave deadlocks as soon as the compiler schedules the divergent blocks
-// the other way round -- it did).
-//   key   bit 63 = occupied (0 = empty: the table is cleared with one memset), bit 62 = EXOTIC
-//         normal : tid | left << bt | (right - left + 1) << (bt + bl)  -- an injective packing of the cluster key (bt / bl = bits of
-//                  the largest tid / contig length of the header).  The instance is NOT part of it: a read whose instance is the one
-//                  its key implies (inst = f(k) - 1, the overwhelming case: it arrives before the first flush that can take its
-//                  cluster) shares it with every other such read of the key.  Equal word <=> same cluster, no second load.
-//         exotic : instance (29 bits) | segment << 29 in bits 32..61, the CLAIMING READ's index in bits 0..31 -- for everything else:
-//                  cross-contig keys (negative right), fields that overflow the packing, reads that arrive after their key was
-//                  flushed (instance = own epoch), reads behind an unmapped read.  A follower compares the upper half, then the
-//                  cluster key of the claiming read (one dependent load of its key record; rare).
-//   ic    low half: reads of the cluster so far -- one 64-bit atomicAdd per (cluster, block) gives the in-cluster ranks; high half:
-//         instance | segment << 31 of the cluster (read by the per-cluster kernels for the UMI threshold, quirk Q1), added in by the
-//         claimer with the same atomic (a separate store to the entry in front of the atomic cost more than the whole rest)
-struct __attribute__((aligned(16))) TabEntry { unsigned long long key; unsigned long long ic; };   // ic = ikey << 32 | count
-static_assert(sizeof(TabEntry) == 16, "TabEntry must stay 16 bytes");
-#define TAB_OCC (1ull << 63)
-#define TAB_EXO (1ull << 62)
-#define RANK_OWNER 0x80000000u          // bit 31 of rank[]: this read claimed its cluster's bucket (exactly one per cluster)
-
-// Bucket of a cluster key.  The stream is coordinate sorted, so consecutive reads carry neighbouring `left` values: a
-// LOCALITY-PRESERVING bucket index (genome-linear left, TAB_WAYS buckets per position, the way from right / instance) makes the
-// table accesses of the scan a sliding window that lives in L2 instead of 64-byte random HBM touches.  Capture panels stack
-// hundreds of clusters on a few hundred positions: 8 ways keep the local load low there.  Collisions fall through to linear probing.
-#define TAB_WAYS 8
-__device__ __forceinline__ uint64_t d_tab_index(const ClusterKey &k, uint32_t ikey, const DevParams &p) {
-    uint64_t g = (k.tid >= 0 && k.tid < p.n_targets && p.target_cum) ? p.target_cum[k.tid] : (uint64_t)(uint32_t)k.tid * 0x9E3779B97F4A7C15ull;
-    uint64_t m = ((uint64_t)k.right * 0x165667B19E3779F9ull) ^ ((uint64_t)ikey * 0xD6E8FEB86659FD93ull);
-    m ^= m >> 29;
-    return (((g + (uint64_t)(uint32_t)k.left) & 0x0000FFFFFFFFFFFFull) * TAB_WAYS) | (m & (TAB_WAYS - 1));
-}
-__device__ __forceinline__ unsigned long long d_tab_key(const ClusterKey &k, uint32_t ikey, bool implied_instance, uint32_t read, const DevParams &p) {
-    const long long delta1 = k.right - (long long)k.left + 1;                     // |isize| for a nearby pair
-    const int bd = 62 - p.key_bt - p.key_bl;
-    if (implied_instance && !(ikey >> 31) && k.tid >= 0 && ((uint64_t)(uint32_t)k.tid >> p.key_bt) == 0 && k.left >= 0 && ((uint64_t)(uint32_t)k.left >> p.key_bl) == 0 &&
-        delta1 >= 0 && bd > 0 && ((uint64_t)delta1 >> bd) == 0)
-        return TAB_OCC | (uint64_t)(uint32_t)k.tid | ((uint64_t)(uint32_t)k.left << p.key_bt) | ((uint64_t)delta1 << (p.key_bt + p.key_bl));
-    return TAB_OCC | TAB_EXO | ((uint64_t)((ikey & 0x1FFFFFFFu) | ((ikey >> 31) << 29)) << 32) | read;
-}
-
-// CL_U consecutive 256-read chunks per block, one read of each per thread, written stage by stage so that the CL_U
-// dependent chains (key record -> flush events -> bucket probe -> CAS -> rank atomic) overlap their
-// memory round trips: the scan is bound by latency x occupancy, not by issue.
-#define CL_U 2
-#ifdef CL_PROF
-#define CL_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
-#else
-#define CL_TICK(k) do { } while (0)
-#endif
-#define CL_LDS_SLOTS 1024          // LDS hash slots for the <= 512 distinct keys of a block
-__global__ __launch_bounds__(CHUNK, 8) void k_cluster(DevBatch b, DevParams p, Work w) {
-    __shared__ uint32_t s_slot[CL_LDS_SLOTS], s_cnt[CL_U * CHUNK], s_ik[CL_U * CHUNK], s_h[CL_U * CHUNK], s_base[CL_U * CHUNK];
-    unsigned int (*s_wcnt)[WAVES_PER_BLOCK] = reinterpret_cast<unsigned int (*)[WAVES_PER_BLOCK]>(s_h);      // (s_h is written long after the last read of s_wcnt; 20 KB of LDS = 8 blocks per CU)
-    __shared__ int4 s_key[CL_U * CHUNK];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const StreamInfo *si = w.si;
-    const unsigned int first_unm = si->first_unmapped;
-    const int n_ev_a = si->n_events_a, n_ev = si->n_events;
-    const long long per = p.period;
-#ifdef CL_PROF
-    unsigned long long t_prev_ = wall_clock64();
-    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) atomicAdd(&w.si->prof[15], 1ull);
-#endif
-    int64_t idx[CL_U]; bool cl[CL_U]; gce_core k[CL_U]; unsigned long long m[CL_U];
-    unsigned int cb = 0u;                                         // first of all loads: the event window below hangs on it
-    if (threadIdx.x < 8 * CL_U) { const int64_t ch = (int64_t)blockIdx.x * CL_U + (threadIdx.x >> 3); cb = (!b.tick && ch < w.n_chunks) ? w.chunk_base[ch] : 0u; }
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        idx[u] = ((int64_t)blockIdx.x * CL_U + u) * CHUNK + threadIdx.x;
-        union { gce_core c; uint4 q[2]; } t;                     // the 32-byte key record as two 16-byte loads (core[] is 16-byte aligned)
-        t.q[0] = make_uint4(0, 0, 0, 0); t.q[1] = t.q[0];
-        if (idx[u] < b.n) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + idx[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
-        k[u] = t.c;
-    }
-    // The flush events a chunk's reads can ask for, fetched NOW by 16 lanes of the first wave (in flight together with the key
-    // records) and handed over in LDS: the 256 reads of a chunk carry consecutive ticks, so their own epochs are E or E + 1 and
-    // the three probes of every read fall into the four events [jb, jb + 3].  Fetched per read after the key record, chunk base ->
-    // tick -> event was two more dependent round trips (4.8 of the 18.5 us a block lives).  Reads the window misses (the segment
-    // behind the first unmapped read, periods shorter than a chunk, ticks handed in with the batch) load their events themselves.
-    int *s_win = reinterpret_cast<int *>(s_base);                // [CL_U][8]: ev_tid[jb..jb+3], ev_pos[jb..jb+3]  (s_base is written at the very end)
-    int *s_jb = s_win + 8 * CL_U;                                // [CL_U][3]: jb; epoch of the chunk's first tick (relative to the stream's first); its remainder
-    const int ev_last = max(n_ev - 1, 0);
-    if (threadIdx.x < 8 * CL_U) {
-        const int u = threadIdx.x >> 3, q = threadIdx.x & 3;
-        const unsigned long long t0 = (unsigned long long)(unsigned int)p.tick_rem0 + cb;      // ticks in front of the chunk, from the epoch boundary
-        const unsigned int uper = (unsigned int)per;
-        unsigned int E, r;
-        if ((t0 >> 32) == 0) { E = (unsigned int)t0 / uper; r = (unsigned int)t0 - E * uper; }
-        else { E = (unsigned int)(t0 / uper); r = (unsigned int)(t0 - (unsigned long long)E * uper); }
-        const int jb = max(min((int)E, n_ev_a) - 1, 0), j = min(jb + q, ev_last);
-        s_win[threadIdx.x] = (threadIdx.x & 4) ? w.ev_pos[j] : w.ev_tid[j];
-        if ((threadIdx.x & 7) == 0) { s_jb[3 * u] = jb; s_jb[3 * u + 1] = (int)E; s_jb[3 * u + 2] = (int)r; }
-    }
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        cl[u] = idx[u] < b.n && d_classify(k[u]) == CLS_CLUSTERED;
-        m[u] = __ballot(cl[u]);
-        if (lane == 0) s_wcnt[u][wv] = __popcll(m[u]);
-    }
-    __syncthreads();
-    CL_TICK(0);
-    // ---- instance of each read: events before it (own epoch) vs. the first event whose walk takes its key
-    ClusterKey key[CL_U]; uint32_t ikey[CL_U]; int e_[CL_U], lo[CL_U], hi[CL_U], g[CL_U];
-    int T0[CL_U], P0[CL_U], T1[CL_U], P1[CL_U], T2[CL_U], P2[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        key[u].tid = -1; key[u].left = -1; key[u].right = 0; ikey[u] = 0xFFFFFFFFu; e_[u] = 0; lo[u] = hi[u] = g[u] = 0;
-        T0[u] = P0[u] = T1[u] = P1[u] = T2[u] = P2[u] = 0;
-        if (cl[u]) {
-            unsigned int inblock = lanes_below(m[u]) + 1;
-            for (int q = 0; q < wv; q++) inblock += s_wcnt[u][q];
-            // the reference's `tick` after ++ (gencore.cpp:319-320) -> flush events before this read, (tick - 1) / period: counted here
-            // from the chunk's epoch and remainder, or from the tick handed in with the batch (key-range shards)
-            if (b.tick) e_[u] = (int)(((long long)b.tick[idx[u]] - 1) / per - p.tick_epoch0);
-            else {
-                const unsigned int x = (unsigned int)s_jb[3 * u + 2] + (inblock - 1u), uper = (unsigned int)per;   // < 2^31 + 256
-                e_[u] = s_jb[3 * u + 1] + (int)(uper > (unsigned int)CHUNK ? (x >= uper ? 1u : 0u) : x / uper);
-            }
-            const bool seg_b = (first_unm != NONE32) && ((unsigned)idx[u] > first_unm);
-            key[u] = d_key(k[u], p);
-            lo[u] = seg_b ? n_ev_a : 0; hi[u] = seg_b ? n_ev : n_ev_a;                      // events [lo, hi) 0-based
-            g[u] = min(max(e_[u], lo[u]), hi[u]);
-            ikey[u] = seg_b ? 0x80000000u : 0u;
-            // the answer is almost always the read's own epoch or the next one: fetch the three probes at once
-            const int j0 = min(max(g[u] - 1, 0), ev_last), j1 = min(g[u], ev_last), j2 = min(g[u] + 1, ev_last);
-            const int jbu = s_jb[3 * u];
-            const unsigned k0 = (unsigned)(j0 - jbu), k1 = (unsigned)(j1 - jbu), k2 = (unsigned)(j2 - jbu);
-            if (!b.tick && k0 < 4u && k2 < 4u) {
-                const int *wn = s_win + 8 * u;
-                T0[u] = wn[k0]; P0[u] = wn[4 + k0]; T1[u] = wn[k1]; P1[u] = wn[4 + k1]; T2[u] = wn[k2]; P2[u] = wn[4 + k2];
-            } else { T0[u] = w.ev_tid[j0]; P0[u] = w.ev_pos[j0]; T1[u] = w.ev_tid[j1]; P1[u] = w.ev_pos[j1]; T2[u] = w.ev_tid[j2]; P2[u] = w.ev_pos[j2]; }
-        }
-    }
-    bool implied[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        implied[u] = false;
-        if (cl[u]) {
-            // first event of this segment whose walk takes the key (gencore.cpp:333-354):
-            //   tid < T  ||  (tid == T && left < P && right < P)           -- monotone in the event index
-            const ClusterKey ky = key[u];
-            auto takes = [&](int T, int P) { return ky.tid < T || (ky.tid == T && ky.left < P && ky.right < (long long)P); };
-            int a, z;
-            const int gg = g[u], l_ = lo[u], h_ = hi[u];
-            if (gg > l_ && takes(T0[u], P0[u])) { a = l_; z = gg - 1; }                    // already flushable before its own epoch (odd isize)
-            else if (gg >= h_ || takes(T1[u], P1[u])) a = z = gg;
-            else if (gg + 1 >= h_ || takes(T2[u], P2[u])) a = z = gg + 1;
-            else { a = gg + 2; z = h_; }
-            while (a < z) {
-                const int mid = (a + z) >> 1;
-                if (takes(w.ev_tid[mid], w.ev_pos[mid])) z = mid; else a = mid + 1;
-            }
-            const int f = a + 1;                                                            // 1-based; hi+1 if none
-            implied[u] = e_[u] <= f - 1;                                                    // the instance every early read of the key gets
-            ikey[u] |= (uint32_t)max(e_[u], f - 1);
-        }
-    }
-    // ---- block-level aggregation.  The stream is sorted, so the reads of a cluster sit close together -- but a capture panel stacks
-    //      several clusters on every position and their reads interleave, so neighbouring lanes rarely share a key.  The block's
-    //      512 reads first meet in a small LDS hash table: the first read of every distinct (key, instance) becomes its LEADER,
-    //      the others compare their key with the leader's (kept in LDS) and draw a block-local rank from the leader's LDS
-    //      counter.  Only leaders go to the bucket table in HBM: one probe and one atomicAdd per cluster and block instead of
-    //      one per read.
-    const int id0 = threadIdx.x;                                                           // read id inside the block: u * CHUNK + threadIdx.x
-    for (int k = threadIdx.x; k < CL_LDS_SLOTS; k += CHUNK) s_slot[k] = 0;
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        const int id = u * CHUNK + id0;
-        s_cnt[id] = 0;
-        s_key[id] = make_int4(key[u].tid, key[u].left, (int)(uint32_t)key[u].right, (int)(uint32_t)((uint64_t)key[u].right >> 32));
-        s_ik[id] = ikey[u];
-    }
-    __syncthreads();
-    CL_TICK(1);
-    int leader[CL_U]; uint32_t lrank[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        leader[u] = -1; lrank[u] = 0;
-        if (cl[u]) {
-            const int id = u * CHUNK + id0;
-            uint32_t hs = ((uint32_t)key[u].left * 0x9E3779B1u) ^ ((uint32_t)key[u].right * 0x85EBCA77u) ^ (ikey[u] * 0xC2B2AE3Du) ^ ((uint32_t)key[u].tid * 0x27D4EB2Fu);
-            hs = (hs ^ (hs >> 15)) & (CL_LDS_SLOTS - 1);
-            for (;;) {                                                                      // (no waiting: a claimed slot's key was stored before the barrier)
-                const uint32_t old = atomicCAS(&s_slot[hs], 0u, (uint32_t)id + 1u);
-                if (old == 0u) { leader[u] = id; break; }
-                const int L = (int)old - 1;
-                const int4 lk = s_key[L];
-                if (lk.x == key[u].tid && lk.y == key[u].left && lk.z == (int)(uint32_t)key[u].right && lk.w == (int)(uint32_t)((uint64_t)key[u].right >> 32) && s_ik[L] == ikey[u]) { leader[u] = L; break; }
-                hs = (hs + 1) & (CL_LDS_SLOTS - 1);
-            }
-            lrank[u] = atomicAdd(&s_cnt[leader[u]], 1u);
-        }
-    }
-    __syncthreads();
-    CL_TICK(2);
-    // ---- leaders: the bucket table
-    bool khead[CL_U]; uint64_t h[CL_U]; unsigned long long tk[CL_U], cur[CL_U]; int runlen[CL_U]; uint32_t rbase[CL_U]; bool owner[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        khead[u] = cl[u] && leader[u] == u * CHUNK + id0;
-        h[u] = 0; tk[u] = 0; cur[u] = 0; rbase[u] = 0; owner[u] = false; runlen[u] = 0;
-        if (khead[u]) {
-            runlen[u] = (int)s_cnt[u * CHUNK + id0];
-            tk[u] = d_tab_key(key[u], ikey[u], implied[u], (uint32_t)idx[u], p);
-            if ((tk[u] & TAB_EXO) && (ikey[u] & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)idx[u]);   // > 2^29 flush events
-            h[u] = d_bucket(d_tab_index(key[u], ikey[u], p), w.tsize, w.tinv);
-        }
-    }
-    bool done[CL_U];
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {                                                       // first probe: claim an empty bucket
-        done[u] = !khead[u];
-        if (khead[u]) {                                                                    // (no load first: the CAS returns what is there)
-            cur[u] = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
-            if (cur[u] == 0ull) { owner[u] = true; cur[u] = tk[u]; }
-        }
-    }
-#ifdef CL_PROF
-    { unsigned long long z_ = 0; for (int u = 0; u < CL_U; u++) z_ += cur[u]; if (z_ == 0x123456789ull) w.si->prof[14] = 1; }
-#endif
-    CL_TICK(3);
-    gce_core oc[CL_U];                                                                     // exotic followers: the claiming read's key record
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        union { gce_core c; uint4 q[2]; } t;
-        t.q[0] = make_uint4(0, 0, 0, 0); t.q[1] = t.q[0];
-        if (!done[u] && !owner[u] && (tk[u] & TAB_EXO) && (cur[u] >> 32) == (tk[u] >> 32)) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + (uint32_t)cur[u]); t.q[0] = src[0]; t.q[1] = src[1]; }
-        oc[u] = t.c;
-    }
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        // in the usual case the first bucket is the cluster's (claimed just now, or found occupied by the same word) and this
-        // settles it; collisions walk on (linear probing, rare)
-        if (!done[u]) {
-            bool mine = owner[u];
-            if (!mine && (cur[u] >> 32) == (tk[u] >> 32)) {
-                if (!(tk[u] & TAB_EXO)) mine = (uint32_t)cur[u] == (uint32_t)tk[u];
-                else { const ClusterKey ok = d_key(oc[u], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
-            }
-            bool first_miss = true;
-            while (!mine) {
-                // collision: leave the neighbourhood.  A deep amplicon stacks thousands of clusters on a few hundred positions; their
-                // buckets are full, and walking on linearly would crawl through the whole pile.  The probe sequence continues at a
-                // hashed place of the table (load there: a few percent), linearly from then on.
-                if (first_miss) {
-                    uint64_t x = ((uint64_t)(uint32_t)key[u].tid * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)key[u].left * 0xC2B2AE3D27D4EB4Full) ^ ((uint64_t)key[u].right * 0x165667B19E3779F9ull) ^ ((uint64_t)ikey[u] * 0xD6E8FEB86659FD93ull);
-                    x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
-                    h[u] = d_bucket(x >> 14, w.tsize, w.tinv);
-                    first_miss = false;
-                } else h[u] = h[u] + 1 == w.tsize ? 0 : h[u] + 1;
-                const unsigned long long c = atomicCAS(&w.tab[h[u]].key, 0ull, tk[u]);
-                if (c == 0ull) { owner[u] = true; break; }
-                if ((c >> 32) == (tk[u] >> 32)) {
-                    if (!(tk[u] & TAB_EXO)) mine = (uint32_t)c == (uint32_t)tk[u];
-                    else { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key[u].tid && ok.left == key[u].left && ok.right == key[u].right; }
-                }
-            }
-            rbase[u] = (uint32_t)atomicAdd(&w.tab[h[u]].ic, (unsigned long long)(unsigned)runlen[u] | (owner[u] ? (unsigned long long)ikey[u] << 32 : 0ull));
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < CL_U; u++)
-        if (khead[u]) { s_h[u * CHUNK + id0] = (uint32_t)h[u]; s_base[u * CHUNK + id0] = rbase[u]; }
-    __syncthreads();
-    CL_TICK(4);
-#pragma unroll
-    for (int u = 0; u < CL_U; u++) {
-        if (idx[u] < b.n) {
-            if (cl[u]) { w.slot[idx[u]] = s_h[leader[u]]; w.rank[idx[u]] = (s_base[leader[u]] + lrank[u]) | (owner[u] ? RANK_OWNER : 0u); }
-            else w.slot[idx[u]] = NONE32;
-        }
-    }
-    CL_TICK(5);
-}
-
-// ===================================================================================================== cluster list + member lists
-// Every cluster has exactly one claiming read (RANK_OWNER): the clusters are numbered in the order of those reads, and an
-// exclusive scan of (1 << 32 | reads of the cluster) over them gives (cluster id, first member slot).  The scans run over the
-// READS (4 bytes each), not over the bucket table (16 bytes x 1.25 per read).
-#define SCAN_TILE 2048
-__device__ __forceinline__ uint64_t own_elem(const Work &w, uint64_t i, uint64_t n) {
-    if (i >= n) return 0;
-    if (w.slot[i] == NONE32 || !(w.rank[i] & RANK_OWNER)) return 0;
-    return (1ull << 32) | (uint32_t)w.tab[w.slot[i]].ic;
-}
-__global__ __launch_bounds__(256) void k_own_reduce(Work w, uint64_t n) {
-    __shared__ uint64_t s[4];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE, v = 0;
-    for (int k = 0; k < SCAN_TILE / 256; k++) v += own_elem(w, base + k * 256 + threadIdx.x, n);
-    v = (uint64_t)wave_sum64((long long)v);
-    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) w.scan_part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-// element(h) = (count>0) << 32 | count ; used by the small per-cluster scans below
-__device__ __forceinline__ uint64_t tab_elem(const uint32_t *cnt, uint64_t h, uint64_t n) {
-    if (h >= n) return 0;
-    uint32_t c = cnt[h];
-    return ((uint64_t)(c > 0) << 32) | c;
-}
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *cnt, uint64_t n, uint64_t *part) {
-    __shared__ uint64_t s[4];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE, v = 0;
-    for (int k = 0; k < SCAN_TILE / 256; k++) v += tab_elem(cnt, base + k * 256 + threadIdx.x, n);
-    v = (uint64_t)wave_sum64((long long)v);
-    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-// exclusive scan of the tile totals, one block: eight consecutive values per thread and step, one barrier per 8192 values (the wave
-// totals are double-buffered and every thread adds them up for the carry itself)
-__global__ __launch_bounds__(1024) void k_scan_partials(uint64_t *part, uint64_t nparts, unsigned long long *total_hi, unsigned long long *total_lo) {
-    __shared__ uint64_t s_w[2][16];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint64_t carry = 0;
-    int it = 0;
-    for (uint64_t base = 0; base < nparts; base += 8192, it ^= 1) {
-        const uint64_t i0 = base + 8 * (uint64_t)threadIdx.x;
-        uint64_t c[8], v = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) { c[k] = i0 + k < nparts ? part[i0 + k] : 0; v += c[k]; }
-        uint64_t x = v;
-        for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
-        if (lane == 63) s_w[it][wv] = x;
-        __syncthreads();
-        uint64_t woff = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const uint64_t t = s_w[it][k]; tot += t; woff += k < wv ? t : 0ull; }
-        uint64_t run = carry + woff + x - v;
-#pragma unroll
-        for (int k = 0; k < 8; k++) { if (i0 + k < nparts) part[i0 + k] = run; run += c[k]; }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) { *total_hi = carry >> 32; if (total_lo) *total_lo = carry & 0xFFFFFFFFull; }
-}
-__global__ __launch_bounds__(256) void k_own_apply(Work w, uint64_t n) {
-    __shared__ uint64_t s_w[4];
-    __shared__ uint64_t s_carry;
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = w.scan_part[blockIdx.x];
-    __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
-    for (int k = 0; k < SCAN_TILE / 256; k++) {
-        uint64_t i = base + k * 256 + threadIdx.x;
-        uint64_t v = own_elem(w, i, n), x = v;
-        for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
-        if (lane == 63) s_w[wv] = x;
-        __syncthreads();
-        uint64_t woff = 0;
-        for (int q = 0; q < wv; q++) woff += s_w[q];
-        uint64_t carry = s_carry;
-        uint64_t ex = carry + woff + x - v;
-        if (v) {
-            const uint32_t cid = (uint32_t)(ex >> 32), sl = w.slot[i];
-            w.cl_slot[cid] = sl; w.cl_start[cid] = (uint32_t)ex; w.cl_n[cid] = (uint32_t)v; w.toff[sl] = (uint32_t)ex;
-        }
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = carry + woff + x;
-        __syncthreads();
-    }
-}
-
-__global__ void k_scatter(int64_t n, Work w) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s = w.slot[i];
-    if (s == NONE32) return;
-    w.members[w.toff[s] + (w.rank[i] & ~RANK_OWNER)] = (uint32_t)i;
-}
+#include "gce_cluster.hpp"
 
 // ===================================================================================================== pairing + UMI grouping
 __device__ __forceinline__ const char *d_qname(const DevBatch &b, uint32_t r) { return b.qname + b.qname_off[r]; }
@@ -645,7 +111,7 @@ __device__ __forceinline__ void load_be_words(const char *s, int len, uint64_t (
 template <int PHASE>
 __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane, uint32_t ib0 = 0, uint32_t ibstep = 1) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
+    uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
     if (mode == THR_NEVER) {                      // pending after an early finishConsensus: never processed (gencore.cpp:23)
         if (PHASE == 2 && lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; }
         return;
@@ -842,7 +308,7 @@ __device__ __forceinline__ int popc_nonzero_bytes(uint64_t x) {
 // One wave per cluster, <= 64 reads, names <= 64 bytes, UMIs <= 24 bytes: everything in registers.
 __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-    uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
+    uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
     if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     bool defer = n > 64;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     uint32_t start = 0, n = 0; int thr = 0;
     if (live) {
         start = w.cl_start[c]; n = w.cl_n[c];
-        const uint32_t mode = d_thr_mode((uint32_t)(w.tab[w.cl_slot[c]].ic >> 32), w.si, p);
+        const uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
         if (mode == THR_NEVER) { if (hl == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } live = false; }   // gencore.cpp:23
         thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCE_ABI_VERSION 2
+#define GCE_ABI_VERSION 3
 #define GCE_NONE 0xFFFFFFFFu           /* "no record" marker in uint32 index arrays */
 #define GCE_MAX_SUPPORTING_READS 100   /* src/stats.h:15 MAX_SUPPORTING_READS */
 
@@ -186,9 +186,9 @@ typedef struct gce_result {
 /* Kernel timing of the last gce_process(), HIP events on the engine's stream. */
 typedef struct gce_timing {
     double total_ms;             /* first kernel start -> last kernel end */
-    double prescan_ms;           /* read classification + tick scan + table clear */
-    double cluster_ms;           /* clustering scan (key + hash partition), the roofline kernel  */
-    double csr_ms;               /* cluster list + member lists */
+    double describe_ms;          /* per-read descriptors, UMI slices, pre-Stats (consumed by pairing and the vote; not cluster formation) */
+    double cluster_ms;           /* clustering scan (class, key, block-level leaders), the roofline kernel  */
+    double csr_ms;               /* rest of cluster formation: tick scan, flush events, leader table, cluster list + member lists */
     double pairing_ms;           /* mate pairing + UMI grouping per cluster */
     double score_ms;             /* Pair::computeScore launches of the fallback path (0 when every group takes the fused vote) */
     double consensus_ms;         /* template pick + column vote (fused kernel + fallbacks) */
