@@ -262,7 +262,7 @@ def main():
                                          traffic=(round(traffic["cluster"]) if traffic and traffic["cluster"] else None)),
                     cluster_formation=dict(what="everything that forms the clusters (SURVEY 8 A1-A3): k_cluster + tick scan + flush events + leader table + cluster/member lists, against the same 40 B/read; the bucket table is wiped by its users, no memset",
                                            ms=round(kernels["cluster_formation"]["ms"], 4), frac=round(kernels["cluster_formation"]["frac"], 5)),
-                    phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3))
+                    phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3), leader_runs=round(avg["n_leaders"]))
 
     # ------------------------------------------------------------------ CPU baseline (oracle port) + parity of the timed entry points
     cpu, parity = None, None

@@ -86,7 +86,7 @@ class GceResult(C.Structure):
 class GceTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "total_ms", "describe_ms", "cluster_ms", "csr_ms", "pairing_ms", "score_ms", "consensus_ms", "finish_ms", "output_ms")] + [
-        ("n_clusters", C.c_int64), ("n_groups", C.c_int64), ("n_pairs", C.c_int64)]
+        ("n_clusters", C.c_int64), ("n_groups", C.c_int64), ("n_pairs", C.c_int64), ("n_leaders", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -67,12 +67,12 @@ struct gce_engine {
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
-    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, rank, score, out_flag, orec, out_index;
+    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, score, out_flag, orec, out_index;
     // output table (gce_result): device arrays + host copies
     DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_rowof, o_units, o_soff, o_qoff, o_seq, o_qual, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
-    DevBuf lrec, lout, ldst, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
-    bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_ldst wipes what a step used)
+    DevBuf lrec, lout, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
+    bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
     DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
@@ -149,8 +149,8 @@ void gce_destroy(gce_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
                      &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
-                     &e->slot, &e->rank, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
-                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->ldst, &e->bhdr,
+                     &e->slot, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
+                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
@@ -409,7 +409,7 @@ int gce_process(gce_engine *e) {
     e->processed = true;
     memset(&e->timing, 0, sizeof e->timing);
     memset(&e->h_si, 0, sizeof e->h_si);
-    if (N >= (int64_t)0xFFFFFFF0ll) return fail(e, GCE_ERR_INVALID, "more than 2^32 reads in one engine");
+    if (N >= (int64_t)0xFFFFFC00ll) return fail(e, GCE_ERR_INVALID, "more than 2^32 reads in one engine");
     const size_t n1 = (size_t)(N > 0 ? N : 1);
 
     DevBatch b{}; b.n = N; b.core = hb.core; b.qname_off = hb.qname_off; b.qname = hb.qname; b.cigar_off = hb.cigar_off; b.cigar = hb.cigar;
@@ -474,12 +474,20 @@ int gce_process(gce_engine *e) {
     // buckets: 1.25 x reads (worst case, every read its own cluster, still probes at load 0.8; typical load is a few percent).
     uint64_t T = ((uint64_t)n1 + (uint64_t)n1 / 4 + 2 * SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
     w.tsize = T; w.tinv = 1.0 / (double)T;
+    {   // normal bucket words: OCC | x div T | right - left + 1 | reads (gce_cluster.hpp, k_leaders)
+        uint64_t genome = 0; for (uint32_t v : e->target_len) genome += v;
+        const uint64_t qmax = (genome * TAB_WAYS + TAB_WAYS) / T + 1;
+        int cb = 1; while (cb < 33 && (1ull << cb) <= (uint64_t)N + 1024) cb++;
+        int qb = 1; while (qb < 52 && (1ull << qb) <= qmax) qb++;
+        p.nw_cb = cb; p.nw_bd = 62 - cb - qb; p.nw_ok = !e->target_len.empty() && p.nw_bd >= 1;
+        if (p.nw_bd > 40) p.nw_bd = 40;
+    }
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
     const size_t nsb1 = (size_t)(n_sblk > 0 ? n_sblk : 1);
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
-    ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(rank, n1 * 4 + 16); ENS(score, qual_bytes + 64);
+    ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(score, qual_bytes + 64);
     ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
-    ENS(lrec, nsb1 * SB_READS * sizeof(LeadRec)); ENS(lout, nsb1 * SB_READS * sizeof(LeadOut)); ENS(ldst, nsb1 * SB_READS * 4);
+    ENS(lrec, nsb1 * SB_READS * sizeof(LeadRec)); ENS(lout, nsb1 * SB_READS * sizeof(LeadOut));
     ENS(bhdr, nsb1 * sizeof(BlkHdr)); ENS(blk_base, nsb1 * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
     ENS(table, T * sizeof(TabEntry)); ENS(toff, T * 4);
@@ -490,9 +498,9 @@ int gce_process(gce_engine *e) {
     const unsigned nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, std::max<size_t>(nsb1, (size_t)2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
     w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
-    w.slot = e->slot.as<uint32_t>(); w.rank = e->rank.as<uint32_t>(); w.score = e->score.as<int8_t>();
+    w.slot = e->slot.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
-    w.lrec = e->lrec.as<LeadRec>(); w.lout = e->lout.as<LeadOut>(); w.ldst = e->ldst.as<uint32_t>(); w.bhdr = e->bhdr.as<BlkHdr>(); w.blk_base = e->blk_base.as<uint32_t>();
+    w.lrec = e->lrec.as<LeadRec>(); w.lout = e->lout.as<LeadOut>(); w.bhdr = e->bhdr.as<BlkHdr>(); w.blk_base = e->blk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
     w.tab = e->table.as<TabEntry>(); w.toff = e->toff.as<uint32_t>();
     w.k64 = e->k64.as<uint64_t>(); w.members = e->members.as<uint32_t>(); w.sorted = e->sorted.as<uint32_t>(); w.pl = e->pl.as<uint32_t>(); w.pr = e->pr.as<uint32_t>();
@@ -510,7 +518,7 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemcpyAsync(e->ev_pos.p, e->h_ev_pos.data(), e->h_ev_pos.size() * 4, hipMemcpyHostToDevice, e->stream));
     }
     hipStream_t s = e->stream;
-    // The bucket table is cleared by its users (k_ldst): a memset only for a new allocation or after a step that did not get that far.
+    // The bucket table is cleared by its users (k_scatter): a memset only for a new allocation or after a step that did not get that far.
     if (!e->tab_clean || e->tab_clean_ptr != e->table.p) {
         HIPCHK(hipMemsetAsync(e->table.p, 0, e->table.cap, s));
         e->tab_clean_ptr = e->table.p;
@@ -538,11 +546,10 @@ int gce_process(gce_engine *e) {
         }
         const unsigned nb4 = cdiv(n_sblk, 4);
         hipLaunchKernelGGL(k_leaders, dim3(nb4), dim3(256), 0, s, b, p, w);
-        hipLaunchKernelGGL(k_num_reduce, dim3(nb4), dim3(256), 0, s, w);
+        hipLaunchKernelGGL(k_num_reduce, dim3(nb4), dim3(256), 0, s, w, p.nw_cb);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)n_sblk, &w.si->n_clusters, (unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_num_apply, dim3(nb4), dim3(256), 0, s, w);
-        hipLaunchKernelGGL(k_ldst, dim3(nb4), dim3(256), 0, s, w);
-        hipLaunchKernelGGL(k_scatter, dim3(cdiv(N, 512)), dim3(256), 0, s, N, w);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, N, w);
     }
     HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
     // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote
@@ -557,7 +564,7 @@ int gce_process(gce_engine *e) {
     HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
-    e->tab_clean = true;                          // k_ldst ran to the end
+    e->tab_clean = true;                          // k_scatter ran to the end
     const uint32_t C = (uint32_t)e->h_si.n_clusters;
     const size_t c1 = C ? C : 1;
     ENS(cl_npairs, c1 * 4); ENS(cl_ngroups, c1 * 4); ENS(cl_gbase, c1 * 4); ENS(cl_nresult, c1 * 4); ENS(cl_hasumi, c1);
@@ -700,7 +707,7 @@ int gce_process(gce_engine *e) {
     }
     e->n_out = (int64_t)e->h_si.n_out;
     e->out_seq_bytes = (size_t)(e->h_si.out_units >> 32) * 16; e->out_qual_bytes = (size_t)(e->h_si.out_units & 0xFFFFFFFFull) * 16;
-    e->timing.n_pairs = (int64_t)e->h_si.n_pairs_total;
+    e->timing.n_pairs = (int64_t)e->h_si.n_pairs_total; e->timing.n_leaders = (int64_t)e->h_si.n_leaders;
     return GCE_OK;
 }
 

@@ -17,9 +17,8 @@
 //                  table -- one CAS + one 64-bit add per (cluster, block) as before, but issued by full waves of a latency-tolerant kernel
 //   k_num_*        clusters numbered in the order of their claiming leaders, exclusive scan of (1 << 32 | reads) -> (cluster id, first
 //                  member slot); runs over the leaders, not over the reads
-//   k_ldst         per leader: where its run starts in members[]; the claiming leader wipes its bucket (the table is all-zero again
-//                  when the step ends: no 16 B x 1.25 N memset per step)
-//   k_scatter      members[] (CSR) from (leader, rank): the second and last pass over per-read data
+//   k_scatter      members[] (CSR) from (leader, rank): the second and last pass over per-read data; the claiming leaders wipe their buckets
+//                  on the way (the table is all-zero again when the step ends: no 16 B x 1.25 N memset per step)
 //   k_describe     NOT part of cluster formation: per read the 32-byte ReadDesc, BamUtil::getUMI (bamutil.cpp:23-112) and the
 //                  pre-Stats counters (stats.cpp:101-121) that pairing and the vote consume; independent of everything above
 #pragma once
@@ -53,15 +52,15 @@ __device__ __forceinline__ uint32_t d_thr_mode(uint32_t ikey, const StreamInfo *
 // The bucket table: 16 bytes per bucket, the cluster's whole identity in the CAS word itself so that nobody ever has to WAIT for a
 // claimer to publish something.
 //   key   bit 63 = occupied (0 = empty), bit 62 = EXOTIC
-//         normal : tid | left << bt | (right - left + 1) << (bt + bl)  -- an injective packing of the cluster key (bt / bl = bits of
-//                  the largest tid / contig length of the header).  The instance is NOT part of it: a read whose instance is the one
-//                  its key implies (the overwhelming case) shares it with every other such read of the key.
+//         normal : (x div T) | (right - left + 1) | reads of the cluster so far, in the cluster's HOME bucket x mod T only (x = genome-linear
+//                  left * 8 + way): identity and count in ONE word, see k_leaders.  The instance is NOT part of it: a read whose instance
+//                  is the one its key implies (the overwhelming case) shares it with every other such read of the key.
 //         exotic : instance (29 bits) | segment << 29 in bits 32..61, the CLAIMING READ's index in bits 0..31 -- for everything else:
 //                  cross-contig keys (negative right), fields that overflow the packing, reads that arrive after their key was
 //                  flushed (instance = own epoch), reads behind an unmapped read.  A follower compares the upper half, then the
 //                  cluster key of the claiming read (one dependent load of its key record; rare).
-//   ic    low half: reads of the cluster so far -- one 64-bit atomicAdd per (cluster, block) gives the in-cluster ranks; high half:
-//         instance | segment << 31 of the cluster (the UMI threshold of quirk Q1 follows from it), added in by the claimer
+//   ic    exotic entries only.  Low half: reads of the cluster so far -- one 64-bit atomicAdd per run gives the in-cluster ranks; high
+//         half: instance | segment << 31 of the cluster (the UMI threshold of quirk Q1 follows from it), added in by the claimer
 struct __attribute__((aligned(16))) TabEntry { unsigned long long key; unsigned long long ic; };   // ic = ikey << 32 | count
 static_assert(sizeof(TabEntry) == 16, "TabEntry must stay 16 bytes");
 #define TAB_OCC (1ull << 63)
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
         if (cl[u]) {
             const ClusterKey key = d_key(k[u], p);
             odd[u] = key.right < (long long)k[u].pos;
-            if (!odd[u]) kw[u] = d_pack_key(key, p);
+            kw[u] = d_pack_key(key, p);
         }
         const int id = u * SB_T + threadIdx.x;
         s_kw[id] = kw[u]; s_cnt[id] = 0u;
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
         if (cl[u]) {
             const int id = u * SB_T + threadIdx.x;
             leader[u] = id;
-            if (kw[u] != 0ull && !any_unm) {
+            if (kw[u] != 0ull && !odd[u] && !any_unm) {
                 uint32_t hs = ((uint32_t)kw[u] ^ (uint32_t)(kw[u] >> 29)) * 0x9E3779B1u;
                 hs = (hs ^ (hs >> 15)) & (SB_LDS_SLOTS - 1);
                 for (;;) {                                                                  // (no waiting: a claimed slot's key was stored before the barrier)
@@ -199,8 +198,7 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
         for (int q = 0; q < SB_T / 64; q++) { const uint32_t c = s_wcnt[u][q]; inblock += q < wv ? c : 0u; front += c; }
         if (idx[u] < b.n) {
             if (cl[u]) {
-                w.slot[idx[u]] = blockIdx.x * (uint32_t)SB_READS + s_num[leader[u]];
-                w.rank[idx[u]] = lrank[u];
+                w.slot[idx[u]] = (uint32_t)s_num[leader[u]] | lrank[u] << 16;                 // (leader of the block, rank in its run): 9 + 9 bits, the block is idx / 512
                 if (leader[u] == id) {
                     union { LeadRec r; uint4 q; } o;
                     o.r.kw = kw[u]; o.r.info = (uint32_t)id | inblock << 9 | (odd[u] ? LI_ODD : 0u); o.r.runlen = s_cnt[id];
@@ -213,42 +211,47 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
     CL_TICK(2);
 }
 
-// single-block exclusive scan of the blocks' clustered counts -> blk_base; the stream's totals
+// single-block exclusive scan of the blocks' clustered counts -> blk_base; the stream's totals.  Every WAVE owns one contiguous range
+// of blocks and walks it twice, 256 blocks (four per lane, coalesced) per trip: sums first, one barrier for the sixteen wave totals,
+// then the prefixes with the carry in a register -- no block barrier inside the loops (rounds of 8192 blocks with a barrier each
+// were 34 us for 39 k blocks).
 __global__ __launch_bounds__(1024) void k_blk_scan(Work w, DevParams p) {
-    __shared__ unsigned int s_w[2][16];
-    __shared__ unsigned int s_l[2][16];
+    __shared__ unsigned int s_w[16], s_l[16];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    // eight consecutive blocks per thread and step, wave scans on the DPP path, ONE barrier per 8192 blocks: the wave totals are
-    // double-buffered and every thread sums them for the carry itself
-    unsigned int carry = 0; unsigned long long leaders = 0;
-    int it = 0;
-    for (int64_t base = 0; base < w.n_sblk; base += 8192, it ^= 1) {
-        const int64_t i0 = base + 8 * (int64_t)threadIdx.x;
-        unsigned int c[8], v = 0, nl = 0;
+    const int64_t per_w = ((w.n_sblk + 15) / 16 + 255) / 256 * 256, w0 = per_w * wv, w1 = min(w0 + per_w, w.n_sblk);
+    auto load4 = [&](int64_t i, unsigned int (&c)[4], unsigned int &nl) {
+        if (i + 3 < w1) {
+            const uint4 q0 = reinterpret_cast<const uint4 *>(w.bhdr + i)[0], q1 = reinterpret_cast<const uint4 *>(w.bhdr + i)[1];     // (i is a multiple of 4: 32-byte aligned)
+            c[0] = q0.y; c[1] = q0.w; c[2] = q1.y; c[3] = q1.w; nl += q0.x + q0.z + q1.x + q1.z;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            BlkHdr h; h.n_lead = 0; h.n_clu = 0;
-            if (i0 + k < w.n_sblk) h = w.bhdr[i0 + k];
-            c[k] = h.n_clu; v += h.n_clu; nl += h.n_lead;
+            for (int k = 0; k < 4; k++) { c[k] = 0; if (i + k < w1) { const BlkHdr h = w.bhdr[i + k]; c[k] = h.n_clu; nl += h.n_lead; } }
         }
-        const unsigned int x = (unsigned int)wave_scan_incl((int)v);
-        const unsigned int xl = (unsigned int)wave_sum((int)nl);
-        if (lane == 63) { s_w[it][wv] = x; s_l[it][wv] = xl; }
-        __syncthreads();
-        unsigned int woff = 0, tot = 0;
+    };
+    unsigned int v = 0, nl = 0;
+    for (int64_t i = w0 + 4 * lane; i < w1; i += 256) { unsigned int c[4]; load4(i, c, nl); v += c[0] + c[1] + c[2] + c[3]; }
+    v = (unsigned int)wave_sum((int)v); nl = (unsigned int)wave_sum((int)nl);
+    if (lane == 0) { s_w[wv] = v; s_l[wv] = nl; }
+    __syncthreads();
+    unsigned int carry = 0, tot = 0; unsigned long long leaders = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { const unsigned int t = s_w[it][k]; tot += t; woff += k < wv ? t : 0u; leaders += s_l[it][k]; }
-        unsigned int run = carry + woff + x - v;
+    for (int k = 0; k < 16; k++) { const unsigned int t = s_w[k]; tot += t; carry += k < wv ? t : 0u; leaders += s_l[k]; }
+    for (int64_t i0 = w0; i0 < w1; i0 += 256) {                                   // (wave-uniform trips: the scan is a wave operation)
+        const int64_t i = i0 + 4 * lane;
+        unsigned int c[4], dummy = 0; load4(i, c, dummy);
+        const unsigned int sum = c[0] + c[1] + c[2] + c[3];
+        const unsigned int x = (unsigned int)wave_scan_incl((int)sum);
+        unsigned int run = carry + x - sum;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { if (i0 + k < w.n_sblk) w.blk_base[i0 + k] = run; run += c[k]; }
-        carry += tot;
+        for (int k = 0; k < 4; k++) { if (i + k < w1) w.blk_base[i + k] = run; run += c[k]; }
+        carry += (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
     }
     if (threadIdx.x == 0) {
-        unsigned long long total = carry;
+        unsigned long long total = tot;
         w.si->n_clustered = total;
         w.si->n_leaders = leaders;
-        long long per = p.period;
-        long long e = (p.tick_offset + (long long)total) / per - p.tick_offset / per;
+        long long per_ = p.period;
+        long long e = (p.tick_offset + (long long)total) / per_ - p.tick_offset / per_;
         w.si->n_events = (int)(e < w.max_events ? e : w.max_events);
         if (e > w.max_events) raise_error(w.si, GCE_ERR_INVALID, 0);
     }
@@ -354,6 +357,26 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
         // the answer is almost always the read's own epoch or the next one
         const int j0 = min(max(g - 1, 0), ev_last), j1 = min(g, ev_last), j2 = min(g + 1, ev_last);
         const int T0 = w.ev_tid[j0], P0 = w.ev_pos[j0], T1 = w.ev_tid[j1], P1 = w.ev_pos[j1], T2 = w.ev_tid[j2], P2 = w.ev_pos[j2];
+        // NORMAL clusters (implied instance, first segment, key inside the header's contigs): the bucket word in the cluster's HOME
+        // bucket identifies it by itself.  x = genome-linear left * 8 + way(right) is injective in (tid, left) up to the way, home = x mod T,
+        // so (x div T, right - left + 1) is all that is left of the key: word = OCC | x div T | delta1 | reads so far (field widths from the
+        // stream's size, DevParams.nw_*).  ONE read-modify-write per leader run: a CAS from 0 claims the bucket, a CAS from (word) to
+        // (word + run length) joins it and returns the run's first rank in the same trip; no second word, no look at anybody's record.
+        // A cluster that finds its home taken by another identity goes the exotic way (below) -- every one of its runs sees the same, the
+        // first claimer of a bucket stays.  tools/mb/atomics.hip: the L2 atomic unit bounds this kernel (17 G/s on lines it has to fetch,
+        // 32 G/s on lines a load brought in, whatever the scope), so the first look is a load, issued for fast leaders behind the event
+        // loads (answers come back in order) while the instance is still being worked out.
+        const int cb = p.nw_cb, bd = p.nw_bd;
+        const long long delta1 = key.right - (long long)key.left + 1;
+        bool fits = false; uint64_t h = 0; unsigned long long id_w = 0, cur = 0;
+        if (p.nw_ok && in.r.kw != 0ull && !seg_b && key.tid < p.n_targets) {
+            uint64_t q;
+            d_divmod(d_tab_index(key, 0u, p), w.tsize, w.tinv, q, h);
+            fits = (q >> (62 - cb - bd)) == 0 && ((uint64_t)delta1 >> bd) == 0;
+            id_w = TAB_OCC | (q << (cb + bd)) | ((uint64_t)delta1 << cb);
+        }
+        const bool early = fits && !odd;
+        if (early) cur = __hip_atomic_load(&w.tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int a, z;
         if (odd && g > lo && takes(T0, P0)) { a = lo; z = g - 1; }                          // already flushable before its own epoch
         else if (g >= hi || takes(T1, P1)) a = z = g;
@@ -365,22 +388,9 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
         }
         const bool implied = e <= a;                                                        // (f = a + 1, 1-based: the instance every early read of the key gets)
         const uint32_t ikey = (seg_b ? 0x80000000u : 0u) | (uint32_t)max(e, a);
-        unsigned long long tk = (implied && !seg_b) ? (in.r.kw ? in.r.kw : d_pack_key(key, p)) : 0ull;
-        if (!tk) {
-            tk = d_exotic_key(ikey, idx);
-            if ((ikey & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, idx);                // > 2^29 flush events
-        }
-        uint64_t h = d_bucket(d_tab_index(key, ikey, p), w.tsize, w.tinv);
-        bool owner = false;
-        unsigned long long cur = atomicCAS(&w.tab[h].key, 0ull, tk);                        // (no load first: the CAS returns what is there)
-        if (cur == 0ull) { owner = true; cur = tk; }
-        bool mine = owner;
-        if (!mine && (cur >> 32) == (tk >> 32)) {
-            if (!(tk & TAB_EXO)) mine = (uint32_t)cur == (uint32_t)tk;
-            else { const ClusterKey ok = d_key(b.core[(uint32_t)cur], p); mine = ok.tid == key.tid && ok.left == key.left && ok.right == key.right; }
-        }
-        bool first_miss = true;
-        while (!mine) {
+        const bool normal = fits && implied;
+        bool owner = false, exotic = !normal, first_miss = true; uint32_t rbase = 0;
+        auto next_probe = [&]() {
             // collision: leave the neighbourhood.  A deep amplicon stacks thousands of clusters on a few hundred positions; their
             // buckets are full, and walking on linearly would crawl through the whole pile.  The probe sequence continues at a
             // hashed place of the table (load there: a few percent), linearly from then on.
@@ -390,14 +400,39 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
                 h = d_bucket(x >> 14, w.tsize, w.tinv);
                 first_miss = false;
             } else h = h + 1 == w.tsize ? 0 : h + 1;
-            const unsigned long long c = atomicCAS(&w.tab[h].key, 0ull, tk);
-            if (c == 0ull) { owner = true; break; }
-            if ((c >> 32) == (tk >> 32)) {
-                if (!(tk & TAB_EXO)) mine = (uint32_t)c == (uint32_t)tk;
-                else { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key.tid && ok.left == key.left && ok.right == key.right; }
+        };
+        if (normal) {
+            const unsigned long long cmask = (1ull << cb) - 1ull;
+            if (!early) cur = __hip_atomic_load(&w.tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (cur == 0ull) {
+                    const unsigned long long o = atomicCAS(&w.tab[h].key, 0ull, id_w | in.r.runlen);
+                    if (o == 0ull) { owner = true; break; }
+                    cur = o;
+                }
+                if ((cur >> cb) != (id_w >> cb)) { exotic = true; break; }                  // (an exotic word differs in bit 62)
+                if ((cur & cmask) + in.r.runlen > cmask) { raise_error(w.si, GCE_ERR_INVALID, idx); break; }   // cannot happen: the field holds the stream's read count
+                const unsigned long long o = atomicCAS(&w.tab[h].key, cur, cur + in.r.runlen);
+                if (o == cur) { rbase = (uint32_t)(cur & cmask); break; }
+                cur = o;                                                                    // (the count moved on; the identity bits never change)
             }
+            if (owner) w.lrec[LR].runlen = ikey;                                            // the cluster's instance, for k_num_reduce (the run length is spent; info tells the phases apart)
+            if (exotic) next_probe();                                                       // home is somebody else's: on to the hashed probe
+        } else h = d_bucket(d_tab_index(key, ikey, p), w.tsize, w.tinv);
+        if (exotic) {
+            // EXOTIC: instance + claiming read in the word, the count in the entry's second word (CAS, then a 64-bit add)
+            const unsigned long long tk = d_exotic_key(ikey, idx);
+            if ((ikey & 0x7FFFFFFFu) >= (1u << 29)) raise_error(w.si, GCE_ERR_INVALID, idx);                // > 2^29 flush events
+            for (;;) {
+                const unsigned long long c = atomicCAS(&w.tab[h].key, 0ull, tk);
+                if (c == 0ull) { owner = true; break; }
+                bool mine = false;
+                if ((c >> 32) == (tk >> 32)) { const ClusterKey ok = d_key(b.core[(uint32_t)c], p); mine = ok.tid == key.tid && ok.left == key.left && ok.right == key.right; }
+                if (mine) break;
+                next_probe();
+            }
+            rbase = (uint32_t)atomicAdd(&w.tab[h].ic, (unsigned long long)in.r.runlen | (owner ? (unsigned long long)ikey << 32 : 0ull));
         }
-        const uint32_t rbase = (uint32_t)atomicAdd(&w.tab[h].ic, (unsigned long long)in.r.runlen | (owner ? (unsigned long long)ikey << 32 : 0ull));
         LeadOut o; o.h = (uint32_t)h; o.rb = rbase | (owner ? LO_OWNER : 0u);
         w.lout[LR] = o;
     }
@@ -407,15 +442,21 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
 // Every cluster has exactly one claiming leader (LO_OWNER): the clusters are numbered in the order of those leaders, and an
 // exclusive scan of (1 << 32 | reads of the cluster) over them gives (cluster id, first member slot).  One wave per scan block.
 #define SCAN_TILE 2048
-__global__ __launch_bounds__(256) void k_num_reduce(Work w) {
+__global__ __launch_bounds__(256) void k_num_reduce(Work w, int p_cb) {
     const int lane = lane_id();
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blk >= w.n_sblk) return;
     const uint32_t nl = w.bhdr[blk].n_lead;
     uint64_t v = 0;
     for (uint32_t kq = (uint32_t)lane; kq < nl; kq += 64) {
-        const LeadOut o = w.lout[(size_t)blk * SB_READS + kq];
-        if (o.rb & LO_OWNER) v += (1ull << 32) | (uint32_t)w.tab[o.h].ic;
+        const size_t LR = (size_t)blk * SB_READS + kq;
+        const LeadOut o = w.lout[LR];
+        if (o.rb & LO_OWNER) {
+            const TabEntry t = w.tab[o.h];
+            const unsigned long long ic = (t.key & TAB_EXO) ? t.ic : (((unsigned long long)w.lrec[LR].runlen << 32) | (t.key & ((1ull << p_cb) - 1ull)));   // instance << 32 | reads
+            w.lrec[LR].kw = ic;                                                             // (the leader record is spent: it keeps that for k_num_apply)
+            v += (1ull << 32) | (uint32_t)ic;
+        }
     }
     v = (uint64_t)wave_sum64((long long)v);
     if (lane == 0) w.scan_part[blk] = v;
@@ -471,8 +512,9 @@ __global__ __launch_bounds__(256) void k_num_apply(Work w) {
         const uint32_t kq = k0 + (uint32_t)lane;
         uint64_t v = 0, ic = 0; uint32_t h = 0;
         if (kq < nl) {
-            const LeadOut o = w.lout[(size_t)blk * SB_READS + kq];
-            if (o.rb & LO_OWNER) { h = o.h; ic = w.tab[h].ic; v = (1ull << 32) | (uint32_t)ic; }
+            const size_t LR = (size_t)blk * SB_READS + kq;
+            const LeadOut o = w.lout[LR];
+            if (o.rb & LO_OWNER) { h = o.h; ic = w.lrec[LR].kw; v = (1ull << 32) | (uint32_t)ic; }
         }
         uint64_t x = v;
         for (int o = 1; o < 64; o <<= 1) { uint64_t t = (uint64_t)__shfl_up((long long)x, o); if (lane >= o) x += t; }
@@ -484,30 +526,26 @@ __global__ __launch_bounds__(256) void k_num_apply(Work w) {
         carry += rl64(x, 63);
     }
 }
-// where a leader's run starts in members[]; the claiming leader clears its bucket for the next step
-__global__ __launch_bounds__(256) void k_ldst(Work w) {
-    const int lane = lane_id();
-    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (blk >= w.n_sblk) return;
+// members[] (CSR) from (leader, rank).  One block per scan block: where its leaders' runs start in members[] (cluster start + the run's
+// first rank) goes through LDS -- a read's leader is a leader of its own block --, and the claiming leaders wipe their buckets on the way: the
+// table is all-zero again when the step ends.
+__global__ __launch_bounds__(SB_T) void k_scatter(int64_t n, Work w) {
+    __shared__ uint32_t s_dst[SB_READS];
+    const int64_t blk = blockIdx.x;
     const uint32_t nl = w.bhdr[blk].n_lead;
-    for (uint32_t kq = (uint32_t)lane; kq < nl; kq += 64) {
-        const size_t LR = (size_t)blk * SB_READS + kq;
-        const LeadOut o = w.lout[LR];
-        w.ldst[LR] = w.toff[o.h] + (o.rb & ~LO_OWNER);
-        if (o.rb & LO_OWNER) *reinterpret_cast<uint4 *>(&w.tab[o.h]) = make_uint4(0, 0, 0, 0);
+    uint32_t v[SB_U];
+#pragma unroll
+    for (int u = 0; u < SB_U; u++) { const int64_t i = (blk * SB_U + u) * SB_T + threadIdx.x; v[u] = i < n ? w.slot[i] : NONE32; }
+    for (uint32_t kq = threadIdx.x; kq < nl; kq += SB_T) {
+        const LeadOut o = w.lout[(size_t)blk * SB_READS + kq];
+        s_dst[kq] = w.toff[o.h] + (o.rb & ~LO_OWNER);
+        if (o.rb & LO_OWNER) *reinterpret_cast<uint4 *>(&w.tab[o.h]) = make_uint4(0, 0, 0, 0);    // (in k_num_reduce, next to the bucket's last read, the same stores cost twice as much: +33 us there, -17 here)
     }
-}
-__global__ __launch_bounds__(256) void k_scatter(int64_t n, Work w) {
-    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (i0 >= n) return;
-    if (i0 + 1 < n) {
-        const uint2 s = *reinterpret_cast<const uint2 *>(w.slot + i0), r = *reinterpret_cast<const uint2 *>(w.rank + i0);
-        const uint32_t d0 = s.x != NONE32 ? w.ldst[s.x] : 0u, d1 = s.y != NONE32 ? w.ldst[s.y] : 0u;
-        if (s.x != NONE32) w.members[d0 + r.x] = (uint32_t)i0;
-        if (s.y != NONE32) w.members[d1 + r.y] = (uint32_t)(i0 + 1);
-    } else {
-        const uint32_t s = w.slot[i0];
-        if (s != NONE32) w.members[w.ldst[s] + w.rank[i0]] = (uint32_t)i0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SB_U; u++) {
+        const int64_t i = (blk * SB_U + u) * SB_T + threadIdx.x;
+        if (v[u] != NONE32) w.members[s_dst[v[u] & 0xFFFFu] + (v[u] >> 16)] = (uint32_t)i;
     }
 }
 

@@ -41,7 +41,8 @@ struct DevParams {
     int32_t n_targets;
     const uint32_t *target_len;
     const uint64_t *target_cum;       // exclusive prefix sum of target_len (genome-linear coordinate of each contig)
-    int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the bucket table
+    int32_t key_bt, key_bl;           // bits of the largest tid / contig length: the packed cluster key of the clustering scan
+    int32_t nw_ok, nw_cb, nw_bd;      // normal bucket words (gce_cluster.hpp): usable at all; bits of the read count; bits of right - left + 1
     int32_t vote_ok, vote_accept_by_qual, s_min_lb;   // gce_vote.hpp: score constants in range; "top quality >= moderate" implies "score sum >= baseScoreReq"; smallest score
     int64_t tick_offset;
     int64_t tick_epoch0; int32_t tick_rem0;   // tick_offset / period, tick_offset % period (host side: no 64-bit division in the scan)
@@ -447,6 +448,14 @@ __device__ __forceinline__ ClusterKey d_key(const gce_core &c, const DevParams &
 }
 // x mod T for a table size that is not a power of two: double-reciprocal quotient estimate (exact after one correction
 // step while x < 2^52, which covers every genome-linear bucket index); anything larger takes the 64-bit remainder.
+__device__ __forceinline__ void d_divmod(uint64_t x, uint64_t T, double tinv, uint64_t &q, uint64_t &r) {
+    if (x >> 52) { q = x / T; r = x - q * T; return; }
+    uint64_t qq = (uint64_t)((double)x * tinv);
+    long long rr = (long long)(x - qq * T);
+    while (rr < 0) { rr += (long long)T; qq--; }
+    while (rr >= (long long)T) { rr -= (long long)T; qq++; }
+    q = qq; r = (uint64_t)rr;
+}
 __device__ __forceinline__ uint64_t d_bucket(uint64_t x, uint64_t T, double tinv) {
     if (x >> 52) return x % T;
     const uint64_t q = (uint64_t)((double)x * tinv);

@@ -4,7 +4,7 @@
 //   k_cluster        THE CLUSTERING SCAN (gce_cluster.hpp): class, key (tid,left,right), block-level leaders -> (leader, rank) per read
 //   k_blk_scan, k_events   ticks of the scan blocks; the reads on which the reference's periodic flush fires (gencore.cpp:319-322)
 //   k_leaders        one lane per leader: instance from the flush events, bucket table -> cluster of every leader run
-//   k_num_* k_ldst k_scatter  cluster list (one claiming leader per cluster) + CSR fill: members[] per cluster
+//   k_num_* k_scatter  cluster list (one claiming leader per cluster) + CSR fill: members[] per cluster
 //   k_describe       per read: the 32-byte ReadDesc, UMI slice, pre-Stats
 //   k_pairing_sub<16|32> (gce_pair2.hpp), k_pairing_fast, k_pairing_deep (gce_deep.hpp), k_pairing_slow
 //                    per cluster: qname order, mate pairing (cluster.cpp:260-273), greedy UMI grouping (cluster.cpp:55-100)
@@ -31,13 +31,13 @@ struct Work {
     const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
     ReadDescP *rdesc;
     uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
-    uint32_t *slot, *rank;
+    uint32_t *slot;                      // per clustered read: leader of its scan block | rank in the leader's run << 16 (gce_cluster.hpp)
     int8_t *score;                       // parallel to qual
     // outputs per read: out_flag for every read (0 = not emitted, 1 = outputPair, 2 = pass-through); orec only where out_flag == 1
     uint8_t *out_flag; OutRec *orec;
     uint32_t *out_index;                 // emitted reads, ascending
     // scan blocks (gce_cluster.hpp): leaders of every block, what k_leaders made of them, where their runs start in members[]
-    struct LeadRec *lrec; struct LeadOut *lout; uint32_t *ldst;
+    struct LeadRec *lrec; struct LeadOut *lout;
     struct BlkHdr *bhdr; uint32_t *blk_base; int64_t n_sblk;   // per scan block: leaders + clustered reads; clustered reads in front of the block
     // events
     int32_t *ev_tid, *ev_pos; uint32_t *ev_read; int max_events;

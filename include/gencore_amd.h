@@ -195,6 +195,7 @@ typedef struct gce_timing {
     double finish_ms;            /* duplex merge, filter, tags, stats */
     double output_ms;            /* output order + compaction of the emitted records */
     int64_t n_clusters, n_groups, n_pairs;
+    int64_t n_leaders;           /* (cluster, scan block) runs the clustering scan handed to the bucket table (0 when ticks come with the batch) */
 } gce_timing;
 
 /* Fill *p with the reference defaults (src/options.cpp:4-40). */

@@ -7,5 +7,5 @@ import csv,glob
 f=glob.glob('gpurun_out/qt/**/*kernel_stats.csv',recursive=True)
 for r in csv.DictReader(open(f[0])):
     n=r['Name'].split('(')[0]
-    if n.startswith('k_') or 'k_group' in n: print('%-28s calls=%s avg_us=%.1f' % (n[:28], r['Calls'], float(r['AverageNs'])/1e3))
+    if 'k_' in n: print('%-28s calls=%s avg_us=%.1f' % (n[:28], r['Calls'], float(r['AverageNs'])/1e3))
 P
