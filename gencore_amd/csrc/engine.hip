@@ -67,9 +67,9 @@ struct gce_engine {
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
-    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, score, out_flag, orec, out_index;
+    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, score, out_flag, orec, out_index, nmx;
     // output table (gce_result): device arrays + host copies
-    DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_rowof, o_units, o_soff, o_qoff, o_seq, o_qual, ref_ascii;
+    DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_soff, o_qoff, o_seq, o_qual, o_key, o_rec, o_ksoff, o_kqoff, o_krow, o_part3, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
     DevBuf lrec, lout, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
@@ -149,8 +149,8 @@ void gce_destroy(gce_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
                      &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
-                     &e->slot, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
-                     &e->o_rowof, &e->o_units, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
+                     &e->slot, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->nmx, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
+                     &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
@@ -387,7 +387,7 @@ static int upload(gce_engine *e) {
 static int read_si(gce_engine *e) {
     HIPCHK(hipMemcpyAsync(&e->h_si, e->si.p, sizeof(StreamInfo), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) e->h_si.pre[k] += e->h_si.pre_slot[q][k];    // k_describe's spread counters
+    for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) { e->h_si.pre[k] += e->h_si.pre_slot[q][k]; e->h_si.post[k] += e->h_si.post_slot[q][k]; }    // k_describe's spread counters
     if (e->h_si.err_key != ~0ull) { e->dev_error = -(int)(e->h_si.err_key & 0xFF); e->dev_error_read = (uint32_t)(e->h_si.err_key >> 8); }
     return GCE_OK;
 }
@@ -486,7 +486,7 @@ int gce_process(gce_engine *e) {
     const size_t nsb1 = (size_t)(n_sblk > 0 ? n_sblk : 1);
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
     ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(score, qual_bytes + 64);
-    ENS(out_flag, n1); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
+    ENS(out_flag, n1 + 16); ENS(nmx, n1 * 4); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
     ENS(lrec, nsb1 * SB_READS * sizeof(LeadRec)); ENS(lout, nsb1 * SB_READS * sizeof(LeadOut));
     ENS(bhdr, nsb1 * sizeof(BlkHdr)); ENS(blk_base, nsb1 * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
@@ -499,7 +499,7 @@ int gce_process(gce_engine *e) {
     ENS(scan_part, std::max<size_t>(nsb1, (size_t)2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
     w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.score = e->score.as<int8_t>();
-    w.out_flag = e->out_flag.as<uint8_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
+    w.out_flag = e->out_flag.as<uint8_t>(); w.nmx = e->nmx.as<uint32_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
     w.lrec = e->lrec.as<LeadRec>(); w.lout = e->lout.as<LeadOut>(); w.bhdr = e->bhdr.as<BlkHdr>(); w.blk_base = e->blk_base.as<uint32_t>();
     w.ev_tid = e->ev_tid.as<int32_t>(); w.ev_pos = e->ev_pos.as<int32_t>(); w.ev_read = e->ev_read.as<uint32_t>();
     w.tab = e->table.as<TabEntry>(); w.toff = e->toff.as<uint32_t>();
@@ -510,7 +510,7 @@ int gce_process(gce_engine *e) {
     ENS(cl_ikey, n1 * 4); ENS(cl_start, n1 * 4); ENS(cl_n, n1 * 4);      // cl_* arrays are sized by N (a cluster has >= 1 read)
     w.cl_ikey = e->cl_ikey.as<uint32_t>(); w.cl_start = e->cl_start.as<uint32_t>(); w.cl_n = e->cl_n.as<uint32_t>();
 
-    StreamInfo init{}; init.first_unmapped = NONE32; init.err_key = ~0ull;
+    StreamInfo init{}; init.first_unmapped = NONE32; init.err_key = ~0ull; init.lq_min = 0x7FFFFFFF; init.lq_max = -1;
     if (e->have_tick) { init.n_events = init.n_events_a = (int)e->h_ev_tid.size(); }
     HIPCHK(hipMemcpyAsync(e->si.p, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
     if (e->have_tick && !e->h_ev_tid.empty()) {
@@ -628,6 +628,14 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
         HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
         const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
+#ifdef VB_STOP
+        {   // experiment builds (tools/vote_stop.sh): time the truncated k_vote alone and stop -- it leaves garbage behind
+            hipEvent_t a_, b_; (void)hipEventCreate(&a_); (void)hipEventCreate(&b_);
+            (void)hipEventRecord(a_, s); hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG); (void)hipEventRecord(b_, s); (void)hipEventSynchronize(b_);
+            float ms_ = 0; (void)hipEventElapsedTime(&ms_, a_, b_); fprintf(stderr, "k_vote up to tick %d: %.3f ms\n", VB_STOP, ms_);
+            return fail(e, GCE_ERR_INVALID, "experiment build");
+        }
+#endif
         hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
         HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
@@ -673,21 +681,20 @@ int gce_process(gce_engine *e) {
     OutTable o{};
     if (N > 0 && e->dev_error == 0) {
         const size_t seq_cap = hb.seq_bytes + 16 * n1 + 64, qual_cap = hb.qual_bytes + 16 * n1 + 64;
-        ENS(o_src, n1 * 4); ENS(o_kind, n1); ENS(o_qsrc, n1 * 4); ENS(o_nm, n1 * 4); ENS(o_fr, n1 * 2); ENS(o_rr, n1 * 2); ENS(o_mate, n1 * 4); ENS(o_rowof, n1 * 4);
-        ENS(o_units, n1 * 8); ENS(o_soff, n1 * 8); ENS(o_qoff, n1 * 8); ENS(o_seq, seq_cap); ENS(o_qual, qual_cap);
+        ENS(o_src, n1 * 4); ENS(o_kind, n1); ENS(o_qsrc, n1 * 4); ENS(o_nm, n1 * 4); ENS(o_fr, n1 * 2); ENS(o_rr, n1 * 2); ENS(o_mate, n1 * 4);
+        ENS(o_soff, n1 * 8); ENS(o_qoff, n1 * 8); ENS(o_seq, seq_cap); ENS(o_qual, qual_cap);
+        ENS(o_key, n1 * sizeof(OutKey)); ENS(o_rec, n1 * sizeof(OutRec)); ENS(o_ksoff, n1 * 8); ENS(o_kqoff, n1 * 8); ENS(o_krow, n1 * 4); const unsigned nblk_O = cdiv(n1, OUT_TILE); ENS(o_part3, (size_t)nblk_O * 24 + 64);
         o.src = e->o_src.as<uint32_t>(); o.kind = e->o_kind.as<uint8_t>(); o.qname_src = e->o_qsrc.as<uint32_t>(); o.nm_new = e->o_nm.as<int32_t>();
-        o.fr = e->o_fr.as<int16_t>(); o.rr = e->o_rr.as<int16_t>(); o.mate = e->o_mate.as<uint32_t>(); o.row_of = e->o_rowof.as<uint32_t>();
-        o.units = e->o_units.as<uint64_t>(); o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
-        hipLaunchKernelGGL(k_flag_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, w.scan_part);
-        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nblk_N, &w.si->n_out, (unsigned long long *)nullptr);
-        hipLaunchKernelGGL(k_flag_apply, dim3(nblk_N), dim3(256), 0, s, (const uint8_t *)w.out_flag, (uint64_t)N, (const uint64_t *)w.scan_part, w.out_index);
-        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups, emitted reads (out_index)
+        o.fr = e->o_fr.as<int16_t>(); o.rr = e->o_rr.as<int16_t>(); o.mate = e->o_mate.as<uint32_t>();
+        o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
+        o.key = e->o_key.as<OutKey>(); o.rec = e->o_rec.as<OutRec>(); o.ksoff = e->o_ksoff.as<uint64_t>(); o.kqoff = e->o_kqoff.as<uint64_t>(); o.krow = e->o_krow.as<uint32_t>(); o.part3 = e->o_part3.as<uint64_t>();
+        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups
+        hipLaunchKernelGGL(k_out_reduce, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
+        hipLaunchKernelGGL(k_out_partials, dim3(1), dim3(1024), 0, s, o, (uint64_t)nblk_O, w);
+        hipLaunchKernelGGL(k_out_meta, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
         const unsigned og = std::min<unsigned>(cdiv(n1, 256), 8192u);
-        hipLaunchKernelGGL(k_out_order, dim3(og), dim3(256), 0, s, b, w, o);
-        hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, b, w, o);
-        hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)o.units, (const unsigned long long *)&w.si->n_out, w.scan_part);
-        hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_out, &w.si->out_units);
-        hipLaunchKernelGGL(k_out_offsets, dim3(nblk_N), dim3(256), 0, s, o, (const unsigned long long *)&w.si->n_out, (const uint64_t *)w.scan_part);
+        hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, w, o);
+        hipLaunchKernelGGL(k_out_mate, dim3(og), dim3(256), 0, s, w, o);
         hipLaunchKernelGGL(k_out_gather, dim3(std::min<unsigned>(cdiv(n1, 16), 16384u)), dim3(256), 0, s, b, w, o);
     }
     HIPCHK(hipEventRecord(e->ev[EV_OUTPUT], s));

@@ -553,6 +553,7 @@ __global__ __launch_bounds__(SB_T) void k_scatter(int64_t n, Work w) {
 __global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Work w, int tiles_per_block) {
     __shared__ long long s_stat[WAVES_PER_BLOCK][6];
     long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
+    int lqmin = 0x7FFFFFFF, lqmax = -1;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     for (int cb = 0; cb < tiles_per_block; cb++) {
         const int64_t i = ((int64_t)blockIdx.x * tiles_per_block + cb) * 256 + threadIdx.x;
@@ -561,10 +562,13 @@ __global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Wo
             const gce_core k = t.c;
             const uint8_t c = d_classify(k);
             bool mapped = k.tid >= 0;                                          // Stats::addRead, stats.cpp:101-121
-            int mism = (mapped && b.nm_type[i]) ? b.nm[i] : 0;
+            const int nmv = b.nm[i]; const bool has_nm = b.nm_type[i] != 0;
+            int mism = (mapped && has_nm) ? nmv : 0;
+            w.nmx[i] = ((uint32_t)nmv << 1) | (has_nm ? 1u : 0u);              // for the Stats of the emitted records (k_out_meta)
             st[0] += 1; st[1] += k.l_qseq; st[4] += mism;
             if (!mapped) { st[2] += 1; st[3] += k.l_qseq; }
             if (mism > 0) st[5] += 1;
+            if (c != CLS_DROP) { lqmin = min(lqmin, k.l_qseq); lqmax = max(lqmax, k.l_qseq); }
             if (c == CLS_CLUSTERED) {
                 const uint32_t *cg = b.cigar + b.cigar_off[i];
                 const uint32_t c0w = k.n_cigar ? cg[0] : 0;
@@ -584,6 +588,11 @@ __global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Wo
         }
     }
     for (int k = 0; k < 6; k++) { long long v = wave_sum64(st[k]); if (lane == 0) s_stat[wv][k] = v; }
+    lqmin = wave_min(lqmin); lqmax = wave_max(lqmax);
+    if (lane == 0) {                                                           // (guarded by a plain look: after the first blocks nothing changes any more)
+        if (lqmin < *(volatile int *)&w.si->lq_min) atomicMin(&w.si->lq_min, lqmin);
+        if (lqmax > *(volatile int *)&w.si->lq_max) atomicMax(&w.si->lq_max, lqmax);
+    }
     __syncthreads();
     if (threadIdx.x < 6) {
         long long v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];

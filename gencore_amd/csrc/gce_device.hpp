@@ -65,7 +65,7 @@ struct StreamInfo {
     unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
-    unsigned int pad0, pad1;
+    int lq_min, lq_max;                  // shortest / longest read that can be emitted (clustered or passed through): k_describe
     unsigned long long n_clusters, n_groups, n_pairs, n_out;
     unsigned long long n_pairs_total;    // pairs over all processed clusters
     unsigned long long vote_weight;      // sum of the group weights: k_vote runs vote_weight / VB_W + 1 batches
@@ -76,6 +76,7 @@ struct StreamInfo {
     unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
+    long long post_slot[GCE_PRE_SLOTS][8];  // k_out_meta's six addRead counters of the emitted records, spread the same way
     long long pre_slot[GCE_PRE_SLOTS][8];   // k_prescan's six addRead counters, spread over GCE_PRE_SLOTS address sets (block & mask) and added
                                            // up by the host: tens of thousands of blocks adding to SIX words queued behind each other
 };

@@ -35,6 +35,7 @@ struct Work {
     int8_t *score;                       // parallel to qual
     // outputs per read: out_flag for every read (0 = not emitted, 1 = outputPair, 2 = pass-through); orec only where out_flag == 1
     uint8_t *out_flag; OutRec *orec;
+    uint32_t *nmx;                       // per read: NM value << 1 | NM present (k_describe)
     uint32_t *out_index;                 // emitted reads, ascending
     // scan blocks (gce_cluster.hpp): leaders of every block, what k_leaders made of them, where their runs start in members[]
     struct LeadRec *lrec; struct LeadOut *lout;
@@ -1738,6 +1739,7 @@ __global__ __launch_bounds__(256) void k_finish(DevBatch b, DevParams p, Work w,
 
 // ===================================================================================================== Stats
 // All counters are additive (stats.h:47-65).  Block-local accumulation in LDS, one global atomic per non-zero counter.
+// (Stats::addRead of the emitted records: k_out_meta, gce_output.hpp)
 __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_clusters, uint32_t n_groups) {
     __shared__ unsigned long long s_pre[GCE_STATS_WORDS], s_post[GCE_STATS_WORDS], s_np;
     for (int k = threadIdx.x; k < GCE_STATS_WORDS; k += blockDim.x) { s_pre[k] = 0; s_post[k] = 0; }
@@ -1769,19 +1771,6 @@ __global__ __launch_bounds__(256) void k_stats(DevBatch b, Work w, uint32_t n_cl
             post[st == RP_OUT_DCS ? 12 : 11] += 1;                                       // addSSCS / addDCS
             post[8] += 1; post_h1 += 1; post[pe ? 10 : 9] += 1;                          // outputPair: addMolecule(1, PE)
         }
-    }
-    const uint64_t n_out = w.si->n_out;                                                   // (launched behind the scan that lists the emitted reads:
-    for (uint64_t r = tid0; r < n_out; r += stride) {                                     //  an eighth of the reads instead of a flag per read)
-        const uint32_t i = w.out_index[r];                                                // writeBam -> mPostStats->addRead
-        gce_core k = b.core[i];
-        bool mapped = k.tid >= 0;
-        const int nmn = w.out_flag[i] == 1 ? (int)w.orec[i].nm_new : -1;
-        int nm = nmn >= 0 ? nmn : b.nm[i];
-        int mism = (mapped && b.nm_type[i]) ? nm : 0;
-        post[0] += 1; post[1] += k.l_qseq;
-        post[4] += mism;
-        if (!mapped) { post[2] += 1; post[3] += k.l_qseq; }
-        if (mism > 0) post[5] += 1;
     }
     const int lane = lane_id();
 #pragma unroll

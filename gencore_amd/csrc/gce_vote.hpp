@@ -132,6 +132,8 @@ __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base
 
 #ifdef VB_PROF
 #define VB_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#elif defined(VB_STOP)                  // cumulative cost of the phases (tools/vote_stop.sh): the kernel ends at tick VB_STOP
+#define VB_TICK(k) do { if ((k) >= VB_STOP) return; } while (0)
 #else
 #define VB_TICK(k) do { } while (0)
 #endif
