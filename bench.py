@@ -136,7 +136,9 @@ def main():
         dist.barrier()
     import numpy as np
     from gencore_amd import capi, synth
-    from gencore_amd.batch import check_output_order, diff_results, table_from_rows
+    from gencore_amd.batch import table_from_rows
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_helpers import check_output_order, diff_results          # test infrastructure (the parity_checked leg only)
     from gencore_amd.capi import GceTiming
     lib = capi.load_library()
     dev = torch.device("cuda", local_rank)
@@ -236,6 +238,8 @@ def main():
         "cluster": dict(ms=avg["cluster_ms"], algorithmic_bytes=cluster_bytes),
         "consensus": dict(ms=avg["score_ms"] + avg["consensus_ms"], algorithmic_bytes=consensus_bytes),
         "cluster_formation": dict(ms=avg["cluster_ms"] + avg["csr_ms"], algorithmic_bytes=cluster_bytes),
+        # mate pairing + UMI grouping (A3-A5): every read name (the UMI is part of it) read once, one (left, right) pair record written per pair
+        "pairing": dict(ms=avg["pairing_ms"], algorithmic_bytes=float(data.t["qname"].numel() - 64) + 8.0 * n_pairs),
     }
     for v in kernels.values():
         v["achieved_gbs"] = v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
@@ -245,7 +249,7 @@ def main():
     # HBM traffic of the dominant phase from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # same command: profiles/hbm_traffic.json, tools/hbm_summary.py): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md
     # prescribes for gfx950.  Quoted only for the workload it was measured on; PMC counters cannot be read inside this process.
-    traffic = None
+    traffic, hj = None, {}
     tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tj) and args.pairs is None and world == 1:
         hj = json.load(open(tj))
@@ -256,10 +260,14 @@ def main():
     roofline = dict(bound="hbm", kernel={"consensus": "k_vote (+ k_score2/k_consensus_fast/_slow for handed-on groups): Pair::computeScore + Group::makeConsensus",
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic and traffic[dom] else None), algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
+                    frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic and traffic[dom] else None),
+                    traffic_source=("static: profiles/hbm_traffic.json (%s), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not a measurement of this run" % hj.get("tag", "?")) if traffic else None,
+                    algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
                     clustering_scan=dict(achieved=round(kernels["cluster"]["achieved_gbs"], 2), frac=round(kernels["cluster"]["frac"], 5),
                                          ms=round(kernels["cluster"]["ms"], 4), algorithmic_bytes=round(cluster_bytes),
                                          traffic=(round(traffic["cluster"]) if traffic and traffic["cluster"] else None)),
+                    pairing=dict(what="k_pairing_sub<16|32> + fast/deep/generic + group tables: qname bytes once + 8 B per pair",
+                                 ms=round(kernels["pairing"]["ms"], 4), algorithmic_bytes=round(kernels["pairing"]["algorithmic_bytes"]), frac=round(kernels["pairing"]["frac"], 5)),
                     cluster_formation=dict(what="everything that forms the clusters (SURVEY 8 A1-A3): k_cluster + tick scan + flush events + leader table + cluster/member lists, against the same 40 B/read; the bucket table is wiped by its users, no memset",
                                            ms=round(kernels["cluster_formation"]["ms"], 4), frac=round(kernels["cluster_formation"]["frac"], 5)),
                     phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3), leader_runs=round(avg["n_leaders"]))
@@ -329,7 +337,8 @@ def main():
             ok = all(o[1] == 0 for o in outs) and np.array_equal(sum(o[3] for o in outs), res.pre.as_array()) and np.array_equal(sum(o[4] for o in outs), res.post.as_array())
             multi = dict(value=round(sd.info["n_pairs"] / ms_, 1), processes=len(procs), host_cores=cores, seconds=round(ms_, 2),
                          slowest_process_seconds=round(max(o[2] for o in outs), 2), stats_equal_single=bool(ok))
-        cpu = dict(value=round(sd.info["n_pairs"] / cs, 1), unit="read-pairs/s", cores=1, kind="port",
+        cpu = dict(value=round(sd.info["n_pairs"] / cs, 1), unit="read-pairs/s", cores=1, kind="port", port_vs_reference=None,
+                   why_no_reference="reference gencore links htslib (Makefile:17), absent from this image and not to be stubbed: oracle/_ref holds only util.h's split; the port restates the reference function by function at -O3 and was never calibrated against it",
                    sample="%s generator, %d pairs, oracle/gencore_oracle.c single thread, %.1f s" % (workload, sd.info["n_pairs"], cs),
                    all_cores=multi)
 
@@ -340,8 +349,8 @@ def main():
             "value": round(value, 1), "unit": "read-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d paired %d bp reads per GPU, %s, mean group depth %.1f, -s %d, %s, genome %.2f Gb%s" % (
-                workload, n_pairs, L, ("%d bp UMI" % data.info["umi_len"]) if data.info["umi_len"] else "no UMI", d,
+            "config": {"workload": "%s: %d paired %d bp reads per GPU, %s, mean cluster depth %.1f pairs (UMI groups: %.1f), -s %d, %s, genome %.2f Gb%s" % (
+                workload, n_pairs, L, ("%d bp UMI" % data.info["umi_len"]) if data.info["umi_len"] else "no UMI", n_pairs / max(1, pre.get("clusters") or 1), d,
                 data.info["supporting_reads"], ("one stream cut into %d key ranges" % world) if world > 1 else "one stream",
                 data.info["genome_bases"] / 1e9, (", %d BED targets x 200 bp" % data.info["bed_targets"]) if data.info.get("bed_targets") else ""),
                 "pairs_per_gpu": n_pairs, "reads_per_gpu": n_reads, "records_out_per_gpu": last_res.get("n_out"),

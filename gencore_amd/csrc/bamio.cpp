@@ -436,6 +436,7 @@ size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* 
     }
     const size_t clen = zs.total_out;
     deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return 0;                                         // (cannot happen for <= 0xff00 bytes stored; the caller reports it)
     const size_t total = 18 + clen + 8;
     const uint16_t bsize = (uint16_t)(total - 1);
     memcpy(dst + 16, &bsize, 2);
@@ -458,10 +459,11 @@ template <class T> struct Raw {
                 p = (T *)aligned_alloc(2u << 20, rounded);
                 if (p) madvise(p, rounded, MADV_HUGEPAGE);
             } else p = (T *)malloc(bytes);
-            cap = k;
+            cap = p ? k : 0;
         }
-        n = k;
+        n = p ? k : 0;
     }
+    bool ok() const { return p != nullptr; }                                     // false after a failed allocation (callers return GCE_ERR_OOM)
     T *data() { return p; }
     const T *data() const { return p; }
     size_t size() const { return n; }
@@ -478,6 +480,7 @@ bool read_file_parallel(const char *path, Raw<uint8_t> &out, int threads) {
     if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return false; }
     const int64_t sz = (int64_t)st.st_size;
     out.resize((size_t)sz);
+    if (!out.ok()) { close(fd); return false; }
     std::atomic<int> bad{0};
     const int64_t piece = 8 << 20;
     parallel_for(threads, (sz + piece - 1) / piece, [&](int, int64_t a, int64_t e) {
@@ -538,6 +541,7 @@ int write_bgzf(const char *path, const Raw<uint8_t> &body, int T, int level) {
     const int64_t nb = (int64_t)((body.size() + BS - 1) / BS);
     Raw<uint8_t> z; z.resize((size_t)nb * 0x10000 + 64);                      // (not a std::vector: its zero fill of these 400 MB, and of the body's, on one
                                                                               //  thread was most of the write stage)
+    if (!z.ok()) return GCE_ERR_OOM;
     std::vector<uint32_t> zs((size_t)nb, 0);
     parallel_for(T, nb, [&](int, int64_t a, int64_t e) {
         for (int64_t k = a; k < e; k++) {
@@ -545,12 +549,13 @@ int write_bgzf(const char *path, const Raw<uint8_t> &body, int T, int level) {
             zs[k] = (uint32_t)deflate_block(body.data() + o, len, level, z.data() + (size_t)k * 0x10000);
         }
     });
+    for (int64_t k = 0; k < nb; k++) if (zs[k] == 0) return GCE_ERR_INVALID;       // a block that could not be deflated
     FILE *f = fopen(path, "wb");
     if (!f) return GCE_ERR_INVALID;
     for (int64_t k = 0; k < nb; k++) if (fwrite(z.data() + (size_t)k * 0x10000, 1, zs[k], f) != zs[k]) { fclose(f); return GCE_ERR_INVALID; }
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    fwrite(eof_block, 1, 28, f);
-    fclose(f);
+    const bool eof_ok = fwrite(eof_block, 1, 28, f) == 28;                         // (a full disk must not pass for a finished BAM: the reference exits when sam_write1 / sam_close fail)
+    if (fclose(f) != 0 || !eof_ok) return GCE_ERR_INVALID;
     return GCE_OK;
 }
 
@@ -587,19 +592,23 @@ int gce_bam_open(const char *path, int threads, gce_bam **out) {
         const uint8_t *p = z.data() + off;
         if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { f->err = "not a BGZF file"; return GCE_ERR_INVALID; }
         const uint16_t xlen = rd16(p + 10);
+        if (off + 12 + (uint64_t)xlen + 8 > z.size()) { f->err = "truncated BGZF block header"; return GCE_ERR_INVALID; }   // the extra field (and the trailer) must lie inside the file
         uint32_t bsize = 0; bool found = false;
         for (uint32_t x = 0; x + 4 <= xlen; ) {
             const uint8_t *s = p + 12 + x; const uint16_t sl = rd16(s + 2);
+            if (x + 4 + (uint32_t)sl > xlen) break;                                 // a subfield that runs past the extra field
             if (s[0] == 'B' && s[1] == 'C' && sl == 2) { bsize = (uint32_t)rd16(s + 4) + 1; found = true; }
             x += 4 + sl;
         }
         if (!found || off + bsize > z.size() || bsize < 12u + xlen + 8u) { f->err = "bad BGZF block"; return GCE_ERR_INVALID; }
         Block b; b.coff = off; b.csize = bsize; b.usize = rd32(p + bsize - 4); b.uoff = uoff;
+        if (b.usize > 0x10000u) { f->err = "bad BGZF block (ISIZE above 64 KB)"; return GCE_ERR_INVALID; }   // the format's limit: the sum of these sizes the buffer below
         blocks.push_back(b);
         off += bsize; uoff += b.usize;
     }
     if (off != z.size()) { f->err = "trailing bytes after the last BGZF block"; return GCE_ERR_INVALID; }
     f->u.resize(uoff + 64);
+    if (!f->u.ok()) { f->err = "out of host memory for the inflated stream"; return GCE_ERR_OOM; }
     if (getenv("GCE_BAM_PRETOUCH")) {                                              // diagnostic: first-touch cost of the destination alone
         const double tp = now_s();
         parallel_for(f->threads, (int64_t)((uoff + 4095) / 4096), [&](int, int64_t a, int64_t e) { for (int64_t k = a; k < e; k++) f->u.data()[(size_t)k * 4096] = 0; });
@@ -752,6 +761,8 @@ int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_bat
     s.core.resize(count); s.qoff.resize(count); s.coff.resize(count); s.soff.resize(count); s.loff.resize(count); s.nm.resize(count); s.nmt.resize(count);
     s.qname.resize(tq[T] + 64); s.cigar.resize(tc[T] + 16); s.seq.resize(ts[T] + 64); s.qual.resize(tl[T] + 64);
     if (mi) { s.mioff.resize(count); s.mi.resize(tm[T] + 64); }
+    if (!s.core.ok() || !s.qoff.ok() || !s.coff.ok() || !s.soff.ok() || !s.loff.ok() || !s.nm.ok() || !s.nmt.ok() || !s.qname.ok() || !s.cigar.ok() || !s.seq.ok() || !s.qual.ok() ||
+        (mi && (!s.mioff.ok() || !s.mi.ok()))) { f->err = "out of host memory for a batch"; return GCE_ERR_OOM; }
     const int nthreads_used = (int)std::max<int64_t>(1, std::min<int64_t>(T, count));
     parallel_for(T, count, [&](int t, int64_t a, int64_t e) {
         // parallel_for hands thread t the same range as in the counting pass, so the prefix sums are this range's start offsets
@@ -814,6 +825,7 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
     });
     for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
     Raw<uint8_t> body; body.resize(hdr.size() + roff[n]);
+    if (!body.ok()) return GCE_ERR_OOM;
     memcpy(body.data(), hdr.data(), hdr.size());
     uint8_t *rb = body.data() + hdr.size();
     parallel_for(T, n, [&](int, int64_t a, int64_t e) {
@@ -879,6 +891,7 @@ int gce_bam_from_batch(const char *path, const gce_batch *b, int32_t n_targets, 
     });
     for (int64_t k = 0; k < n; k++) roff[k + 1] += roff[k];
     Raw<uint8_t> body; body.resize(hdr.size() + roff[n]);
+    if (!body.ok()) return GCE_ERR_OOM;
     memcpy(body.data(), hdr.data(), hdr.size());
     uint8_t *rb = body.data() + hdr.size();
     parallel_for(T, n, [&](int, int64_t a, int64_t e) {

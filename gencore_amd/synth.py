@@ -7,7 +7,7 @@ struct-of-arrays layout plus the reference contigs in FastaReader's 4-bit code.
 Workloads (BASELINE.json `configs`):
   cfg1s : plumbing substitute for configs[0] (2k pairs, depth 2, no UMI, 1 contig)
   cfg2  : 1 M pairs, 150 bp, no UMI, mean depth 4, single 10 Mb contig, -s 1
-  cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean depth 8, -s 2; 24 hg19-shaped contigs (`scale` x hg19 lengths:
+  cfg3  : 10 M pairs, 150 bp, 8 bp UMI (":UMI_XXXXXXXX"), mean CLUSTER depth 8 (molecule depth 10.4), -s 2; 24 hg19-shaped contigs (`scale` x hg19 lengths:
           0.1 = 300 Mb by default, bench.py uses 1.0 = 3.04 Gb); molecules concentrated on 5 k x 200 bp BED targets (the target
           count follows n_pairs so that a down-scaled stream keeps ~250 molecules per target)
   cfg4s : per-GPU eighth of configs[3] (12.5 M pairs, UMI, depth 16, whole-genome coverage of `scale` x hg19; the 8-GPU stream is
@@ -64,7 +64,7 @@ CONFIGS = {
                   supporting_reads=1),
     "cfg2": dict(n_pairs=1_000_000, L=150, umi=0, duplex=False, mean_depth=4, contigs=[10_000_000], ins_mu=300, ins_sd=30,
                  ins_max=600, supporting_reads=1),
-    "cfg3": dict(n_pairs=10_000_000, L=150, umi=8, duplex=False, mean_depth=8, scale=0.1,
+    "cfg3": dict(n_pairs=10_000_000, L=150, umi=8, duplex=False, mean_depth=10.4, scale=0.1,   # molecules of 10.4 reads -> CLUSTERS of 8.0 pairs (soft clips, indels and UMI errors split molecules)
                  contigs=[w * 1_000_000 for w in (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103,
                                                   90, 81, 78, 59, 63, 48, 51, 155, 59)],      # hg19 chr1..22, X, Y (Mb)
                  bed_targets=5000, bed_len=200, ins_mu=300, ins_sd=30, ins_max=600, supporting_reads=2),

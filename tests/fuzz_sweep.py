@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import fuzzgen
-from gencore_amd.batch import diff_results
+from parity_helpers import diff_results
 from gencore_amd.capi import GceError
 from gencore_amd.engine import run_stream
 from oracle import oracle_py

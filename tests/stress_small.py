@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import fuzzgen
-from gencore_amd.batch import ReadBatch, diff_results
+from gencore_amd.batch import ReadBatch
+from parity_helpers import diff_results
 from gencore_amd.capi import GceError, default_params
 from gencore_amd.engine import run_stream
 from oracle import oracle_py

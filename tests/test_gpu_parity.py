@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import fuzzgen
-from gencore_amd.batch import check_output_order, diff_results
+from parity_helpers import check_output_order, diff_results
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from gencore_amd.batch import ReadBatch, check_output_order
+from gencore_amd.batch import ReadBatch
+from parity_helpers import check_output_order
 from gencore_amd.capi import default_params
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand_derived")

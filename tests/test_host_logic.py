@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import fuzzgen
-from gencore_amd.batch import ReadBatch, diff_results
+from gencore_amd.batch import ReadBatch
+from parity_helpers import diff_results
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -178,7 +179,8 @@ def rows_from_table(batch, t):
 @pytest.mark.parametrize("seed", [3, 17, 604])
 def test_result_table_round_trip(oracle, seed):
     """gce_result (rows of emitted records) <-> the per-read form diff_results compares: host-side plumbing of every GPU test."""
-    from gencore_amd.batch import check_output_order, table_from_rows
+    from gencore_amd.batch import table_from_rows
+    from parity_helpers import check_output_order
     batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=50, exotic=seed >= 600)
     want = oracle.run(batch, fuzzgen.make_params(over, contig_len), reference)
     rows = rows_from_table(batch, want)
