@@ -64,11 +64,12 @@ class BamFile:
                          mi_off=arr(b.mi_off, np.uint64, n) if mi else None, mi=arr(b.mi, np.uint8, b.mi_bytes) if mi else None)
 
 
-def load_fasta(path):
-    """{contig id: ASCII bases (bytes)} in file order, with FastaReader's quirks (src/fastareader.cpp:57-104)."""
+def load_fasta(path, threads=0):
+    """{contig id: ASCII bases (bytes)} in file order, with FastaReader's quirks (src/fastareader.cpp:57-104).
+    threads: 0 = all host cores (the file is cut at provable line starts), 1 = the literal one-pass walk."""
     lib = capi.load_library()
     h = C.c_void_p()
-    rc = lib.gce_fasta_load(str(path).encode(), C.byref(h))
+    rc = lib.gce_fasta_load(str(path).encode(), int(threads), C.byref(h))
     if rc != 0:
         raise GceError(rc, "gce_fasta_load")
     n = C.c_int32()

@@ -95,10 +95,10 @@ class GceTiming(C.Structure):
 STATUS_NAMES = {
     0: "GCE_OK", -1: "GCE_ERR_INVALID", -2: "GCE_ERR_NO_DEVICE", -3: "GCE_ERR_HIP", -4: "GCE_ERR_OOM",
     -10: "GCE_ERR_UNSORTED", -11: "GCE_ERR_UMI_MISMATCH", -12: "GCE_ERR_NM_MISSING", -13: "GCE_ERR_UMI_PARSE",
-    -14: "GCE_ERR_QNAME_SHORT"}
+    -14: "GCE_ERR_QNAME_SHORT", -15: "GCE_ERR_REF_WINDOW"}
 
 EXPORTED_SYMBOLS = [
-    "gce_params_default", "gce_detect_umi_prefix", "gce_create", "gce_destroy", "gce_set_reference", "gce_set_reference_ascii",
+    "gce_params_default", "gce_detect_umi_prefix", "gce_create", "gce_destroy", "gce_set_reference", "gce_set_reference_ascii", "gce_set_reference_window",
     "gce_pack_reference", "gce_set_flush_events", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
@@ -151,6 +151,7 @@ def load_library(path=None):
     lib.gce_destroy.restype = None
     lib.gce_set_reference.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     lib.gce_set_reference_ascii.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    lib.gce_set_reference_window.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.gce_pack_reference.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
     lib.gce_pack_reference.restype = None
     lib.gce_set_flush_events.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -178,7 +179,7 @@ def load_library(path=None):
     lib.gce_bam_chunk.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(GceBatch)]
     lib.gce_bam_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(GceResult), C.c_int, C.c_int]
     lib.gce_bam_from_batch.argtypes = [C.c_char_p, C.POINTER(GceBatch), C.c_int32, C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.c_int]
-    lib.gce_fasta_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.gce_fasta_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.gce_fasta_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
     lib.gce_fasta_free.argtypes = [C.c_void_p]
     lib.gce_fasta_free.restype = None

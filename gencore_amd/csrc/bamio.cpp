@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include "../../include/gencore_amd.h"
 
@@ -448,6 +449,10 @@ size_t deflate_block(const uint8_t *src, uint32_t n, int level, uint8_t *dst /* 
 // a growable buffer that is NOT value-initialised (std::vector::resize would write gigabytes of zeros on one thread)
 template <class T> struct Raw {
     T *p = nullptr; size_t cap = 0, n = 0;
+    Raw() = default;
+    Raw(const Raw &) = delete; Raw &operator=(const Raw &) = delete;
+    Raw(Raw &&o) noexcept : p(o.p), cap(o.cap), n(o.n) { o.p = nullptr; o.cap = o.n = 0; }
+    Raw &operator=(Raw &&o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; n = o.n; o.p = nullptr; o.cap = o.n = 0; } return *this; }
     ~Raw() { free(p); }
     void release() { free(p); p = nullptr; cap = n = 0; }
     void resize(size_t k) {
@@ -928,47 +933,128 @@ int gce_bam_from_batch(const char *path, const gce_batch *b, int32_t n_targets, 
 // contig therefore contributes its '\n' as one base (code 0) and the line after it is taken whole; lower case is folded
 // (forceUpperCase = true, fastareader.h:21); the contig ID is the header up to the first blank.  Later contigs of the same name
 // replace earlier ones (std::map assignment).  Returns the contigs as upper-cased ASCII, ready for gce_set_reference_ascii.
-struct gce_fasta { std::vector<std::string> ids, seqs; std::vector<const char *> idp, seqp; std::vector<int64_t> len; };
+//
+// The walk of FastaReader::readNext is a chain of ITERATIONS: get(c) takes one character -- '>' ends the record, anything else goes
+// unfiltered into the header (first iteration of a record) or the sequence --, then getline takes the rest of the line.  Where an
+// iteration starts depends on the file only through its line feeds, so the file (read by parallel preads) is cut into one range per
+// thread at positions that are PROVABLY iteration starts: a position q with d[q-1] == '\n' and d[q-2] neither '\n' nor '>' (that
+// line feed cannot be the first character of an iteration, because the character in front of it neither ended an iteration nor was
+// a one-character '>' iteration: it ends one, and q starts the next; q is never the start of a header iteration, which follows a
+// '>').  Every thread then walks its iterations exactly as the reference does; the pieces are stitched per contig.  threads == 1 is
+// the literal one-pass walk (the test oracle of the parallel one); a file without such cut positions falls back to it.
+struct FaPiece { int64_t hdr_a = -1, hdr_b = -1; char *seq = nullptr; size_t n = 0; };     // one (part of a) record seen by one thread: a slice of the thread's arena
+struct gce_fasta {
+    std::vector<std::string> ids; std::vector<Raw<char>> seqs, arena; Raw<uint8_t> file; std::vector<const char *> idp, seqp; std::vector<int64_t> len;
+    double t_map = 0, t_parse = 0, t_stitch = 0;
+};
 
-int gce_fasta_load(const char *path, gce_fasta **out) {
+namespace {
+inline char fa_upper(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - ('a' - 'A')) : c; }
+// walk the iterations of [p, end): `end` is an iteration start (or the file's end).  `in_header`: the first iteration is a header's.
+// Sequence characters are appended to pieces.back(); a '>' iteration opens a new piece whose header follows.
+void fa_walk(const uint8_t *d, size_t n, size_t p, size_t end, bool in_header, std::vector<FaPiece> &pieces, char *arena) {
+    // (an iteration never emits more characters than it consumes: the arena, as long as the range, cannot overflow)
+    bool header_next = in_header;
+    char *o = arena;
+    pieces.back().seq = o;
+    while (p < end) {
+        const char c = (char)d[p++];
+        if (c == '>') { pieces.back().n = (size_t)(o - pieces.back().seq); pieces.emplace_back(); pieces.back().seq = o; header_next = true; continue; }   // `if(c == '>' || eof) break;` -- in a header iteration too: that record has an empty header
+        size_t e = p;
+        if (e < n) { const void *nl = memchr(d + p, '\n', n - p); e = nl ? (size_t)((const uint8_t *)nl - d) : n; }
+        if (header_next) { pieces.back().hdr_a = (int64_t)p - 1; pieces.back().hdr_b = (int64_t)e; header_next = false; }   // header = c + rest of the line
+        else {
+            *o++ = fa_upper(c);                                                                      // get(c): no validity filter
+            for (size_t k = p; k < e; k++) { const char ch = fa_upper((char)d[k]); if ((ch >= 'A' && ch <= 'Z') || ch == '-' || ch == '*') *o++ = ch; }   // str_keep_valid_sequence (util.h:194-210); isalpha after the fold = A-Z
+        }
+        p = e < n ? e + 1 : n;
+    }
+    pieces.back().n = (size_t)(o - pieces.back().seq);
+}
+}  // namespace
+
+int gce_fasta_load(const char *path, int threads, gce_fasta **out) {
     if (!path || !out) return GCE_ERR_INVALID;
-    std::vector<uint8_t> d;
-    if (!read_file(path, d)) return GCE_ERR_INVALID;
+    *out = nullptr;
+    double t0 = now_s();
+    int T = threads > 0 ? threads : default_threads();
     gce_fasta *fa = new gce_fasta();
     *out = fa;
-    size_t p = 0; const size_t n = d.size();
-    while (p < n && d[p] != '>') p++;                                         // seek to the first contig
-    if (p < n) p++;
-    bool eof = p >= n;
-    // ifstream semantics: eof() turns true only when a read hits the end; get() past the end fails and sets it
-    auto upper = [](char c) { return (c >= 'a' && c <= 'z') ? (char)(c - ('a' - 'A')) : c; };
-    while (!eof) {                                                            // readAll: while(!eof) readNext()
-        std::string header, seq;
-        bool found_header = false;
-        for (;;) {
-            if (p >= n) { eof = true; break; }                                // get(c) fails at the end
-            const char c = (char)d[p++];
-            if (c == '>') break;
-            if (found_header) seq.push_back(upper(c)); else header.push_back(c);
-            std::string line;                                                 // getline(stream, line, '\n')
-            if (p >= n) eof = true;                                           //   (an empty rest sets eof and yields "")
-            else {
-                size_t e = p;
-                while (e < n && d[e] != '\n') e++;
-                line.assign((const char *)d.data() + p, e - p);
-                if (e >= n) { eof = true; p = n; } else p = e + 1;
-            }
-            if (!found_header) { header += line; found_header = true; }
-            else for (char ch : line) { ch = upper(ch); if (isalpha((unsigned char)ch) || ch == '-' || ch == '*') seq.push_back(ch); }
-            if (eof) break;
+    if (!read_file_parallel(path, fa->file, T)) return GCE_ERR_INVALID;          // parallel preads into one 2 MB-page buffer (page faults of an mmap'ed file
+    const size_t n = fa->file.size();                                              //  from eight threads, next to their allocations, serialised on the mm lock: slower than one thread)
+    const uint8_t *d = fa->file.data();
+    fa->t_map = now_s() - t0; t0 = now_s();
+    size_t p0 = 0;
+    while (p0 < n && d[p0] != '>') p0++;                                      // seek to the first contig
+    if (p0 < n) p0++;
+    std::vector<std::vector<FaPiece>> per;
+    if (p0 < n) {
+        // ---- cut positions
+        { const char *mb = getenv("GCE_FASTA_MIN_PARALLEL"); const size_t min_par = mb ? (size_t)atoll(mb) : (size_t)(1 << 20); if ((n - p0) < min_par) T = 1; }   // (tests set it to 0)
+        std::vector<size_t> cut{p0};
+        for (int t = 1; t < T; t++) {
+            size_t q = std::max(p0 + (n - p0) / T * t, cut.back() + 2);
+            const size_t lim = std::min(n, q + (size_t)(16 << 20));              // (a cut is found within a line or two; give up on odd files)
+            for (; q < lim; q++) if (d[q - 1] == '\n' && d[q - 2] != '\n' && d[q - 2] != '>' && q - 2 >= p0) break;
+            if (q >= lim) { cut.assign(1, p0); break; }                          // no provable iteration start: one thread walks it all
+            if (q > cut.back()) cut.push_back(q);
         }
-        const size_t sp = header.find(' ');
-        const std::string id = header.substr(0, sp);
-        size_t at = fa->ids.size();
-        for (size_t k = 0; k < fa->ids.size(); k++) if (fa->ids[k] == id) at = k;
-        if (at == fa->ids.size()) { fa->ids.push_back(id); fa->seqs.push_back(seq); } else fa->seqs[at] = seq;
+        const int nt = (int)cut.size();
+        cut.push_back(n);
+        per.resize(nt); fa->arena.resize(nt);
+        for (int t = 0; t < nt; t++) { fa->arena[t].resize(cut[t + 1] - cut[t] + 64); if (!fa->arena[t].ok()) return GCE_ERR_OOM; }   // (all allocations in front of the threads)
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back([&, t] {
+            per[t].emplace_back();                                               // thread 0: the first record; others: the record that is open at the cut
+            fa_walk(d, n, cut[t], cut[t + 1], t == 0, per[t], fa->arena[t].data());
+        });
+        for (auto &x : th) x.join();
     }
-    for (size_t k = 0; k < fa->ids.size(); k++) { fa->idp.push_back(fa->ids[k].c_str()); fa->seqp.push_back(fa->seqs[k].data()); fa->len.push_back((int64_t)fa->seqs[k].size()); }
+    fa->t_parse = now_s() - t0; t0 = now_s();
+    // ---- stitch: a thread's first piece continues the last piece of the thread in front of it (unless it is thread 0's)
+    struct Rec { std::string hdr; std::vector<std::pair<int, int>> parts; size_t total = 0; };
+    std::vector<Rec> recs;
+    bool any = false;
+    for (size_t t = 0; t < per.size(); t++)
+        for (size_t k = 0; k < per[t].size(); k++) {
+            FaPiece &pc = per[t][k];
+            if (!(t > 0 && k == 0)) { recs.emplace_back(); if (pc.hdr_a >= 0) recs.back().hdr.assign((const char *)d + pc.hdr_a, (size_t)(pc.hdr_b - pc.hdr_a)); }
+            recs.back().parts.emplace_back((int)t, (int)k); recs.back().total += pc.n; any = true;
+        }
+    (void)any;
+    // readAll (fastareader.cpp:157-168): `while(!eof) readNext()` -- a record that a '>' opened right at the end of the file exists
+    // (empty id, empty sequence) exactly when the walk above produced its piece; contigs of the same id: the LAST one stays, at the
+    // place of the first (std::map assignment).
+    std::unordered_map<std::string, size_t> where;
+    std::vector<int64_t> rec_of;                                               // contig -> record that supplies its sequence
+    for (size_t r = 0; r < recs.size(); r++) {
+        const size_t sp = recs[r].hdr.find(' ');
+        const std::string id = recs[r].hdr.substr(0, sp);
+        auto it = where.find(id);
+        if (it == where.end()) { where.emplace(id, fa->ids.size()); fa->ids.push_back(id); rec_of.push_back((int64_t)r); }
+        else rec_of[it->second] = (int64_t)r;
+    }
+    fa->seqs.resize(fa->ids.size()); fa->seqp.assign(fa->ids.size(), nullptr); fa->len.assign(fa->ids.size(), 0);
+    static const char empty_seq[1] = {0};
+    {
+        std::vector<std::thread> th;                                           // a contig inside one thread's range stays where it is; one that spans ranges is
+        for (size_t c = 0; c < fa->ids.size(); c++) {                          // copied together, one thread per part
+            Rec &r = recs[(size_t)rec_of[c]];
+            fa->len[c] = (int64_t)r.total;
+            if (r.total == 0) { fa->seqp[c] = empty_seq; continue; }
+            if (r.parts.size() == 1) { fa->seqp[c] = per[r.parts[0].first][r.parts[0].second].seq; continue; }
+            fa->seqs[c].resize(r.total + 1);
+            if (!fa->seqs[c].ok()) { for (auto &x : th) x.join(); return GCE_ERR_OOM; }
+            fa->seqp[c] = fa->seqs[c].p;
+            size_t at = 0;
+            for (auto &pr : r.parts) { const FaPiece *pc = &per[pr.first][pr.second]; char *dst = fa->seqs[c].p + at; if (pc->n) th.emplace_back([pc, dst] { memcpy(dst, pc->seq, pc->n); }); at += pc->n; }
+        }
+        for (auto &x : th) x.join();
+    }
+    fa->file.release();
+    for (size_t k = 0; k < fa->ids.size(); k++) fa->idp.push_back(fa->ids[k].c_str());
+    fa->t_stitch = now_s() - t0;
+    if (getenv("GCE_FASTA_TIMING")) fprintf(stderr, "gce_fasta_load: %zu bytes, %d threads: map %.3f s, parse %.3f s, stitch %.3f s\n", n, (int)per.size(), fa->t_map, fa->t_parse, fa->t_stitch);
     return GCE_OK;
 }
 int gce_fasta_get(const gce_fasta *fa, int32_t *n, const char *const **ids, const char *const **seqs, const int64_t **lens) {
@@ -1063,7 +1149,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     }
     if ((rc = gce_create(&prm, &e)) != GCE_OK) return done(rc, gce_status_message(rc));
     if (fasta_path && *fasta_path) {
-        if ((rc = gce_fasta_load(fasta_path, &fa)) != GCE_OK) return done(rc, "cannot read the FASTA file");
+        if ((rc = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) return done(rc, "cannot read the FASTA file");
         int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *lens;
         gce_fasta_get(fa, &nc, &ids, &seqs, &lens);
         for (int32_t t = 0; t < bi.n_targets; t++)                               // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)

@@ -54,8 +54,8 @@ struct gce_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT]{};
     // reference
-    std::vector<DevBuf> ref_buf; std::vector<const uint8_t *> ref_ptr; std::vector<int64_t> ref_len;
-    DevBuf d_ref_ptr, d_ref_len, d_target_len, d_target_cum;
+    std::vector<DevBuf> ref_buf; std::vector<const uint8_t *> ref_ptr; std::vector<int64_t> ref_len, ref_win; bool have_win = false;
+    DevBuf d_ref_ptr, d_ref_len, d_ref_win, d_target_len, d_target_cum;
     // host staging (gce_submit)
     std::vector<gce_core> h_core; std::vector<uint64_t> h_qoff, h_coff, h_soff, h_loff, h_mioff;
     std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm; std::vector<uint64_t> h_tick;
@@ -121,6 +121,7 @@ const char *gce_status_message(int s) {
     case GCE_ERR_NM_MISSING: return "NM tag missing on a consensus template whose mismatch count changed";
     case GCE_ERR_UMI_PARSE: return "UMI parse: substr start beyond the end of the read name";
     case GCE_ERR_QNAME_SHORT: return "copyQName ERROR: desitination qname is shorter";
+    case GCE_ERR_REF_WINDOW: return "reference window: a clustered read lies outside the bases staged for its contig";
     default: return "unknown status";
     }
 }
@@ -147,7 +148,7 @@ void gce_destroy(gce_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
-    DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
+    DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_ref_win, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
                      &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
                      &e->slot, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->nmx, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
                      &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
@@ -186,6 +187,7 @@ int gce_set_reference(gce_engine *e, int32_t tid, const uint8_t *nibbles, int64_
     HIPCHK(hipMemcpyAsync(e->ref_buf[tid].p, nibbles, bytes, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->ref_ptr[tid] = e->ref_buf[tid].as<uint8_t>(); e->ref_len[tid] = n_bases;
+    if (2 * (size_t)tid + 1 < e->ref_win.size()) e->ref_win[2 * tid] = e->ref_win[2 * tid + 1] = 0;
     return GCE_OK;
 }
 
@@ -207,6 +209,19 @@ int gce_set_reference_ascii(gce_engine *e, int32_t tid, const char *bases, int64
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
     e->ref_ptr[tid] = e->ref_buf[tid].as<uint8_t>(); e->ref_len[tid] = n_bases;
+    if (2 * (size_t)tid + 1 < e->ref_win.size()) e->ref_win[2 * tid] = e->ref_win[2 * tid + 1] = 0;
+    return GCE_OK;
+}
+
+int gce_set_reference_window(gce_engine *e, int32_t tid, int64_t contig_len, int64_t win_start, const char *bases, int64_t n_bases) {
+    if (!e || tid < 0 || contig_len < 0 || win_start < 0 || (win_start & 1) || n_bases < 0 || win_start + n_bases > contig_len || (!bases && n_bases > 0)) return GCE_ERR_INVALID;
+    const int rc = gce_set_reference_ascii(e, tid, bases, n_bases);             // the window's bases, packed from offset 0 (win_start is even: the nibble parity is that of the contig)
+    if (rc != GCE_OK) return rc;
+    if (e->ref_win.size() < 2 * e->ref_ptr.size()) e->ref_win.resize(2 * e->ref_ptr.size(), 0);
+    e->ref_ptr[tid] = e->ref_buf[tid].as<uint8_t>() - (win_start >> 1);           // virtual origin: ref[pos >> 1] for pos inside the window
+    e->ref_len[tid] = contig_len;
+    e->ref_win[2 * tid] = win_start; e->ref_win[2 * tid + 1] = win_start + n_bases;
+    e->have_win = true;
     return GCE_OK;
 }
 
@@ -463,7 +478,15 @@ int gce_process(gce_engine *e) {
         int bl = 1; while (bl < 32 && (1ull << bl) <= (uint64_t)mx) bl++;
         p.key_bt = bt; p.key_bl = bl;
     }
-    p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>();
+    p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>(); p.ref_win = nullptr;
+    if (e->have_win && nref) {                                                     // contigs staged whole: window = [0, length)
+        std::vector<int64_t> win(2 * (size_t)nref, 0);
+        for (int t = 0; t < nref; t++) { const bool wd = 2 * (size_t)t + 1 < e->ref_win.size() && e->ref_win[2 * t + 1] > 0; win[2 * t] = wd ? e->ref_win[2 * t] : 0; win[2 * t + 1] = wd ? e->ref_win[2 * t + 1] : e->ref_len[t]; }
+        HIPCHK(e->d_ref_win.ensure(win.size() * 8));
+        HIPCHK(hipMemcpyAsync(e->d_ref_win.p, win.data(), win.size() * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        p.ref_win = e->d_ref_win.as<int64_t>();
+    }
 
     // ---- allocations that only depend on N
     Work w{};

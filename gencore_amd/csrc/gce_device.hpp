@@ -50,6 +50,7 @@ struct DevParams {
     int32_t n_ref;
     const uint8_t *const *ref_data;   // [n_ref] device pointers or nullptr
     const int64_t *ref_len;           // [n_ref]
+    const int64_t *ref_win;           // [2 x n_ref] staged window [lo, hi) of every contig (gce_set_reference_window), or nullptr: whole contigs
 };
 
 // stream-level scalars produced by the prescan (device resident)

@@ -53,6 +53,13 @@ class Engine:
         a = np.frombuffer(bases, np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, np.uint8)
         self._check(self.lib.gce_set_reference_ascii(self._h, tid, a.ctypes.data, int(a.size)))
 
+    def set_reference_window(self, tid, contig_len, win_start, bases):
+        """Per-shard staging: only the bases [win_start, win_start + len(bases)) of a contig (gce_set_reference_window)."""
+        if isinstance(bases, str):
+            bases = bases.encode()
+        a = np.frombuffer(bases, np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, np.uint8)
+        self._check(self.lib.gce_set_reference_window(self._h, tid, int(contig_len), int(win_start), a.ctypes.data, int(a.size)))
+
     def set_flush_events(self, ev_tid, ev_pos):
         """Flush events of the whole stream (key-range shards; see gencore_amd/shard.py)."""
         t, p = np.ascontiguousarray(ev_tid, np.int32), np.ascontiguousarray(ev_pos, np.int32)

@@ -47,7 +47,8 @@ typedef enum gce_status {
     GCE_ERR_UMI_MISMATCH = -11,    /* src/pair.cpp:201-212 "The UMI of a read pair should be identical" */
     GCE_ERR_NM_MISSING = -12,      /* src/group.cpp:532-535: NM dereferenced although absent (segfault in the reference) */
     GCE_ERR_UMI_PARSE = -13,       /* src/bamutil.cpp:47-62: substr(start) with start > length throws in the reference */
-    GCE_ERR_QNAME_SHORT = -14      /* src/bamutil.cpp:343-346 "copyQName ERROR: desitination qname is shorter" */
+    GCE_ERR_QNAME_SHORT = -14,     /* src/bamutil.cpp:343-346 "copyQName ERROR: desitination qname is shorter" */
+    GCE_ERR_REF_WINDOW = -15       /* a clustered read lies outside the reference window staged for its contig (gce_set_reference_window) */
 } gce_status;
 
 /* One read's fixed-size fields.  Byte-for-byte the BAM alignment core block (SAMv1 section 4.2), i.e. what
@@ -216,6 +217,11 @@ int gce_set_reference(gce_engine *e, int32_t tid, const uint8_t *nibbles, int64_
 /* Same from upper-cased ASCII bases (one contig of FastaReader::mAllContigs, src/fastareader.h): packed on the GPU
  * (FastaReader::to4bits, src/fastareader.cpp:139-152). */
 int gce_set_reference_ascii(gce_engine *e, int32_t tid, const char *bases, int64_t n_bases);
+/* Per-shard staging: only the bases [win_start, win_start + n_bases) of a contig of `contig_len` bases, e.g. what the
+ * reads of one key-range shard can touch -- an engine for 1/8 of hg19 then holds 1/8 of the reference.  win_start must be even.
+ * Reference::getData's end-of-contig rule (src/reference.cpp:40,60) keeps using contig_len.  gce_process fails with
+ * GCE_ERR_INVALID ("reference window") if a clustered read whose isize != 0 does not lie inside the window of its contig. */
+int gce_set_reference_window(gce_engine *e, int32_t tid, int64_t contig_len, int64_t win_start, const char *bases, int64_t n_bases);
 /* Convenience: pack an upper-cased ASCII contig into that code on the host (src/fastareader.cpp:139). */
 void gce_pack_reference(const char *bases, int64_t n_bases, uint8_t *nibbles_out);
 
@@ -326,7 +332,7 @@ int gce_bam_from_batch(const char *path, const gce_batch *batch, int32_t n_targe
 /* Replaces: Reference::Reference -> FastaReader(file) + readAll (src/reference.cpp:13-24, src/fastareader.cpp:7-41,57-104,157-168),
  * including its quirks (first character of every line unfiltered, lower case folded, ID = header up to the first blank, a later
  * contig of the same name wins).  Contigs come back as ASCII for gce_set_reference_ascii. */
-int gce_fasta_load(const char *path, gce_fasta **out);
+int gce_fasta_load(const char *path, int threads, gce_fasta **out);   /* threads <= 0: all host cores; 1: the literal one-pass walk */
 int gce_fasta_get(const gce_fasta *fa, int32_t *n_contigs, const char *const **ids, const char *const **bases, const int64_t **lengths);
 void gce_fasta_free(gce_fasta *fa);
 

@@ -243,6 +243,102 @@ def test_fasta_loader_quirks(built, tmp_path, case):
     assert got == want
 
 
+def _fasta_walk_py(data):
+    """FastaReader(file) + readAll restated literally in Python (src/fastareader.cpp:7-41,57-104,157-168; util.h:194-210): the
+    independent check of the loader's one-pass walk and, through it, of the parallel one."""
+    n, p = len(data), 0
+    while p < n and data[p:p + 1] != b">":
+        p += 1
+    if p < n:
+        p += 1
+    eof = p >= n
+    ids, seqs = [], {}
+    while not eof:
+        header, seq, found = bytearray(), bytearray(), False
+        while True:
+            if p >= n:
+                eof = True
+                break
+            c = data[p]; p += 1
+            if c == ord(">"):
+                break
+            if found:
+                seq.append(c - 32 if 97 <= c <= 122 else c)
+            else:
+                header.append(c)
+            if p >= n:
+                line, eof = b"", True
+            else:
+                e = data.find(b"\n", p)
+                if e < 0:
+                    line, p, eof = data[p:], n, True
+                else:
+                    line, p = data[p:e], e + 1
+            if not found:
+                header += line; found = True
+            else:
+                for ch in line:
+                    ch = ch - 32 if 97 <= ch <= 122 else ch
+                    if 65 <= ch <= 90 or ch in (45, 42):
+                        seq.append(ch)
+            if eof:
+                break
+        hid = bytes(header).split(b" ", 1)[0]
+        if hid not in seqs:
+            ids.append(hid)
+        seqs[hid] = bytes(seq)
+    return [(i, seqs[i]) for i in ids]
+
+
+def _load_fasta_raw(path, threads):
+    import ctypes as C
+    from gencore_amd import capi
+    lib = capi.load_library()
+    h = C.c_void_p()
+    assert lib.gce_fasta_load(str(path).encode(), threads, C.byref(h)) == 0
+    n = C.c_int32()
+    ids, seqs, lens = C.POINTER(C.c_char_p)(), C.POINTER(C.c_void_p)(), C.POINTER(C.c_int64)()
+    lib.gce_fasta_get(h, C.byref(n), C.byref(ids), C.byref(seqs), C.byref(lens))
+    out = [(ids[i], C.string_at(seqs[i], lens[i])) for i in range(n.value)]
+    lib.gce_fasta_free(h)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fasta_parallel_equals_the_literal_walk(built, tmp_path, monkeypatch, seed):
+    """Random FASTA-like text with everything the walk is sensitive to (runs of line feeds, '>' at line starts / inside lines / doubled /
+    at the very end, CRLF, lower case, digits, missing final newline): the Python restatement, the one-thread walk and the file cut
+    into 2..9 ranges must agree byte for byte."""
+    rng = np.random.default_rng(1000 + seed)
+    monkeypatch.setenv("GCE_FASTA_MIN_PARALLEL", "0")
+    parts = [rng.choice([b"", b"junk\n", b"\n"])]
+    for _ in range(int(rng.integers(1, 12))):
+        hdr = rng.choice([b">c%d" % rng.integers(0, 6), b">c%d some words" % rng.integers(0, 6), b">", b">>x", b">c\r", b"> lead"])
+        parts.append(hdr + b"\n")
+        for _ in range(int(rng.integers(0, 40))):
+            kind = rng.integers(0, 20)
+            if kind == 0:
+                parts.append(b"\n" * int(rng.integers(1, 5)))
+            elif kind == 1:
+                parts.append(b"ac>gt\n")
+            elif kind == 2:
+                parts.append(b"12 AC-*gtn\r\n")
+            else:
+                ln = int(rng.integers(1, 70))
+                parts.append(bytes(rng.choice(list(b"ACGTNacgtn"), ln).astype(np.uint8)) + b"\n")
+    data = b"".join(parts)
+    if seed % 3 == 0:
+        data = data.rstrip(b"\n")
+    if seed % 7 == 0:
+        data += b">"
+    p = tmp_path / "f.fa"
+    p.write_bytes(data)
+    want = _fasta_walk_py(data)
+    assert _load_fasta_raw(p, 1) == want
+    for t in (2, 3, 5, 9):
+        assert _load_fasta_raw(p, t) == want
+
+
 # ------------------------------------------------------------------------------------------------------------------ end to end
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,n_pairs,chunk", [("cfg3", 30000, 7000), ("cfg2", 20000, 1 << 21), ("cfg5", 3000, 1000)])

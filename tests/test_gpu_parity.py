@@ -406,3 +406,46 @@ def test_key_range_shards_at_scale(built):
         pre += got.pre.as_array(); post += got.post.as_array()
     assert np.array_equal(flags, whole.out_flag)
     assert np.array_equal(pre, whole.pre.as_array()) and np.array_equal(post, whole.post.as_array())
+
+
+@pytest.mark.gpu
+def test_reference_windows_equal_whole_contigs(built):
+    """Per-shard reference staging: an engine that holds only the bases its reads can touch -- per contig the window
+    [first read position (rounded down to even), last read end) -- gives the result of the engine that holds the whole contigs;
+    a window that cuts a read off is refused (GCE_ERR_REF_WINDOW), never read past."""
+    from gencore_amd import synth
+    from gencore_amd.capi import GceError, default_params
+    from gencore_amd.engine import Engine, run_stream
+    from test_cabi_driver import ascii_of
+    d = synth.generate("cfg3", n_pairs=20000)
+    b = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, umi_prefix=d.info["umi_prefix"], cluster_size_req=d.info["supporting_reads"])
+    ref = d.reference_host()
+    want = run_stream(b, prm, ref)
+    asc = ascii_of(ref)
+    tid, pos = b.core["tid"].astype(np.int64), b.core["pos"].astype(np.int64)
+    end = pos + b.core["l_qseq"].astype(np.int64) + 64                       # (soft clips aside a read spans at most its length + deletions)
+    for shrink in (0, 1):
+        e = Engine(prm)
+        try:
+            for t in range(len(tl)):
+                sel = (tid == t) & (pos >= 0)
+                if asc[t] is None or not sel.any():
+                    continue
+                lo = int(pos[sel].min()) & ~1
+                hi = min(int(end[sel].max()), int(tl[t]))
+                if shrink:
+                    hi = max(lo + 2, lo + (hi - lo) // 2)
+                e.set_reference_window(t, int(tl[t]), lo, asc[t][lo:hi])
+            e.add_reads(b)
+            if shrink:
+                with pytest.raises(GceError) as err:
+                    e.finish()
+                assert err.value.status == -15
+            else:
+                e.finish()
+                got = e.output(b)
+                assert not diff_results(b, got, want)
+        finally:
+            e.close()
