@@ -12,7 +12,7 @@ from parity_helpers import check_output_order
 from gencore_amd.capi import default_params
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand_derived")
-CASES = sorted(os.path.basename(f)[:-5] for f in glob.glob(os.path.join(HERE, "*.json")))
+CASES = sorted(os.path.basename(f)[:-5] for f in glob.glob(os.path.join(HERE, "*.json")))      # (_write_r03_vectors.py only spells out the inputs of the long ones)
 KEYS = ("qname", "flag", "tid", "pos", "cigar", "seq", "qual", "nm", "fr", "rr")
 
 
@@ -21,11 +21,11 @@ def load(name):
     recs = []
     for r in v["records"]:
         r = dict(r)
-        n = r.pop("repeat", None)
+        n, r0 = r.pop("repeat", None), r.pop("repeat_from", 0)
         if n is None:
             recs.append(r)
         else:
-            recs += [dict(r, qname=r["qname"].format(i=i)) for i in range(n)]
+            recs += [dict(r, qname=r["qname"].format(i=i)) for i in range(r0, r0 + n)]
     batch = ReadBatch.from_records(recs)
     tl = np.asarray([c["length"] for c in v["contigs"]], np.uint32)
     prm = default_params(n_targets=len(tl), target_len=tl.ctypes.data, **v["params"])
@@ -72,7 +72,7 @@ def test_oracle_matches_hand_derivation(oracle, name):
 
 
 def test_vectors_present():
-    assert len(CASES) >= 11
+    assert len(CASES) >= 23
 
 
 @pytest.mark.gpu
