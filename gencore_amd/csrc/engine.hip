@@ -649,6 +649,7 @@ int gce_process(gce_engine *e) {
         HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
         HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
         HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
+        HIPCHK(hipMemsetAsync(e->rp_left.p, 0xFF, g1 * 4, s)); HIPCHK(hipMemsetAsync(e->rp_right.p, 0xFF, g1 * 4, s));   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
         HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
         const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
 #ifdef VB_STOP
