@@ -94,6 +94,19 @@ def run_bam(in_path, out_path, params, fasta=None, threads=0, chunk_reads=1 << 2
     return run
 
 
+def run_bam_sharded(in_path, out_path, params, devices, fasta=None, plan_mode=0, threads=0, level=6):
+    """gce_run_bam_sharded: one engine per entry of `devices` (HIP ordinals, may repeat), planned on the GPU, tables merged."""
+    lib = capi.load_library()
+    run = GceBamRun()
+    err = (C.c_char * 256)()
+    dv = (C.c_int32 * len(devices))(*devices)
+    rc = lib.gce_run_bam_sharded(str(in_path).encode(), str(out_path).encode(), str(fasta).encode() if fasta else None, C.byref(params), len(devices), dv,
+                                 plan_mode, threads, level, C.byref(run), err)
+    if rc != 0:
+        raise GceError(rc, err.value.decode(errors="replace"))
+    return run
+
+
 def write_batch_as_bam(path, batch, target_len, target_name=None, text="@HD\tVN:1.6\tSO:coordinate\n", threads=0, level=1):
     """gce_bam_from_batch: a ReadBatch as a BAM file (synthetic inputs for the end-to-end runs)."""
     lib = capi.load_library()

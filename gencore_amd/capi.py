@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
     "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch",
-    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_depth_stats", "gce_bed_load", "gce_bed_free"]
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_sharded", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
 
 
 class GceBamInfo(C.Structure):
@@ -161,6 +161,11 @@ def load_library(path=None):
     lib.gce_drain.argtypes = [C.c_void_p, C.POINTER(GceResult)]
     lib.gce_result_device.argtypes = [C.c_void_p, C.POINTER(GceResult)]
     lib.gce_get_timing.argtypes = [C.c_void_p, C.POINTER(GceTiming)]
+    lib.gce_stats_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.gce_stream_context.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
+    lib.gce_plan_shards.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.gce_free.argtypes = [C.c_void_p]
+    lib.gce_free.restype = None
     lib.gce_reset.argtypes = [C.c_void_p]
     lib.gce_last_error.argtypes = [C.c_void_p]
     lib.gce_last_error.restype = C.c_char_p
@@ -188,6 +193,7 @@ def load_library(path=None):
                                  C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_char_p))]
     lib.gce_bed_free.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gce_bed_free.restype = None
+    lib.gce_run_bam_sharded.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(GceParams), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int, C.c_int, C.POINTER(GceBamRun), C.c_char * 256]
     lib.gce_run_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(GceParams), C.c_int, C.c_int64, C.c_int, C.POINTER(GceBamRun), C.c_char * 256]
     if path is None:
         _lib = lib

@@ -745,16 +745,15 @@ int gce_bam_get_info(const gce_bam *f, gce_bam_info *o) {
 }
 
 // records [first, first + count) as a gce_batch in one of the two chunk slots (offsets relative to the slot's blobs)
-int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_batch *out) {
-    if (!f || !out || first < 0 || count < 0 || first + count > (int64_t)f->rec.size() || (slot_id != 0 && slot_id != 1)) return GCE_ERR_INVALID;
-    Slot &s = f->slot[slot_id];
+// records first .. first + count - 1, or (sel != nullptr) the records sel[0 .. count - 1] in that order
+static int bam_chunk_impl(gce_bam *f, int64_t first, const int64_t *sel, int64_t count, Slot &s, gce_batch *out) {
     const uint8_t *u = f->u.data();
     const int T = f->threads;
     std::vector<uint64_t> tq(T + 1, 0), tc(T + 1, 0), ts(T + 1, 0), tl(T + 1, 0), tm(T + 1, 0);
     parallel_for(T, count, [&](int t, int64_t a, int64_t e) {
         uint64_t q = 0, c = 0, sq = 0, l = 0, m = 0;
         for (int64_t k = a; k < e; k++) {
-            const uint8_t *r = u + f->rec[first + k] + 4; const uint32_t bs = rd32(u + f->rec[first + k]);
+            const uint8_t *r = u + f->rec[sel ? sel[k] : first + k] + 4; const uint32_t bs = rd32(u + f->rec[sel ? sel[k] : first + k]);
             const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
             q += lq; c += nc; sq += (uint64_t)(ls + 1) / 2; l += (uint64_t)ls;
             if (f->tot_mi) { const AuxInfo ai = scan_aux(r + 32 + lq + 4 * nc + (ls + 1) / 2 + ls, r + bs); if (ai.mi) m += strlen(ai.mi) + 1; }
@@ -773,7 +772,7 @@ int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_bat
         // parallel_for hands thread t the same range as in the counting pass, so the prefix sums are this range's start offsets
         uint64_t q = tq[t], c = tc[t], sq = ts[t], l = tl[t], m = tm[t];
         for (int64_t k = a; k < e; k++) {
-            const uint8_t *r = u + f->rec[first + k] + 4; const uint32_t bs = rd32(u + f->rec[first + k]);
+            const uint8_t *r = u + f->rec[sel ? sel[k] : first + k] + 4; const uint32_t bs = rd32(u + f->rec[sel ? sel[k] : first + k]);
             memcpy(&s.core[k], r, 32);                                        // gce_core IS the 32-byte BAM core block
             const uint32_t lq = r[8], nc = rd16(r + 12); const int32_t ls = rdi32(r + 16);
             const uint8_t *pq = r + 32, *pc = pq + lq, *ps = pc + 4 * nc, *pl = ps + (ls + 1) / 2, *pa = pl + ls;
@@ -802,11 +801,22 @@ int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_bat
 
 // Gencore::writeBam for every row of the result (src/gencore.cpp:85-111): the input record res->src[k] with the row's bases,
 // qualities, name (BamUtil::copyQName, src/bamutil.cpp:338-364), NM byte (src/group.cpp:570) and FR / RR aux (src/pair.cpp:57-67).
-int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, int threads, int level) {
-    if (!path || !in || !res) return GCE_ERR_INVALID;
+
+int gce_bam_chunk(gce_bam *f, int64_t first, int64_t count, int slot_id, gce_batch *out) {
+    if (!f || !out || first < 0 || count < 0 || first + count > (int64_t)f->rec.size() || (slot_id != 0 && slot_id != 1)) return GCE_ERR_INVALID;
+    return bam_chunk_impl(f, first, nullptr, count, f->slot[slot_id], out);
+}
+
+// the rows of an output table as BAM records: row k = input record src[k] with the name of record qname_src[k], the bases / qualities
+// at seqp(k) / qualp(k), NM patched, FR / RR appended (gce_result's meaning; one table, or several engines' tables merged)
+struct OutRows { int64_t n; const uint32_t *src, *qname_src; const int32_t *nm_new; const int16_t *fr, *rr; };
+extern "C++" {
+template <class SP, class QP>
+static int bam_write_rows(const char *path, const gce_bam *in, const OutRows rows, SP seqp, QP qualp, int threads, int level) {
+    const OutRows *res = &rows;
     const int T = threads > 0 ? threads : in->threads;
     const uint8_t *u = in->u.data();
-    const int64_t n = res->n_out;
+    const int64_t n = rows.n;
     for (int64_t k = 0; k < n; k++) if (res->src[k] >= in->rec.size() || res->qname_src[k] >= in->rec.size()) return GCE_ERR_INVALID;
     // ---- header bytes
     std::vector<uint8_t> hdr;
@@ -845,8 +855,8 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
             uint8_t *w = o + 36;
             memcpy(w, nr + 32, lq_new); w += lq_new;
             memcpy(w, r + 32 + lq_old, 4 * nc); w += 4 * nc;
-            memcpy(w, res->seq + res->seq_off[k], (ls + 1) / 2); w += (ls + 1) / 2;
-            memcpy(w, res->qual + res->qual_off[k], ls); w += ls;
+            memcpy(w, seqp(k), (ls + 1) / 2); w += (ls + 1) / 2;
+            memcpy(w, qualp(k), ls); w += ls;
             const uint8_t *aux = r + 32 + lq_old + 4 * nc + (ls + 1) / 2 + ls; const size_t al = (size_t)(r + bs - aux);
             memcpy(w, aux, al);
             if (res->nm_new[k] >= 0) {                                       // dataNM[1] = newValNM (type 'C' only, checked by the engine)
@@ -864,6 +874,13 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
         }
     });
     return write_bgzf(path, body, T, level);
+}
+}  // extern "C++"
+
+int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, int threads, int level) {
+    if (!path || !in || !res) return GCE_ERR_INVALID;
+    const OutRows rows{res->n_out, res->src, res->qname_src, res->nm_new, res->fr, res->rr};
+    return bam_write_rows(path, in, rows, [&](int64_t k) { return res->seq + res->seq_off[k]; }, [&](int64_t k) { return res->qual + res->qual_off[k]; }, threads, level);
 }
 
 // The inverse of gce_bam_chunk: a gce_batch (host pointers) as a BAM file -- header, one record per read with its NM tag (type and
@@ -1183,6 +1200,154 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         gce_result res; memset(&res, 0, sizeof res);
         if ((rc = gce_bam_write(out_path, f, &res, threads, level)) != GCE_OK) return done(rc, "cannot write the output BAM");
     }
+    out->write_s = now_s() - t0;
+    out->total_s = now_s() - t_start;
+    return done(GCE_OK, "");
+}
+
+
+// Gencore::consensus() for one BAM over SEVERAL engines: the stream is cut into n_shards ranges of the cluster key by the
+// GPU planner (gce_stream_context + gce_plan_shards on devices[0]); shard r runs on HIP device devices[r] (ordinals may repeat: several
+// engines on one GPU, which is how a one-GPU box tests it) with its reads, their global ticks, the flush events of the whole stream and
+// -- per-shard staging -- only the reference window its reads can touch; the engines run side by side on host threads.  No data-path
+// exchange: the output tables (each in bamComp order) are merged k-way by (tid, pos, mtid, mpos, isize, input index), mate rows are
+// re-pointed, the two Stats blocks are SUMMED ON THE HOST (one process owns all engines here; one process per GPU merges them with one
+// RCCL all-reduce instead, bench.py).  The result equals gce_run_bam's: same records, same order, same Stats.
+int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards, const int32_t *devices,
+                        int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]) {
+    auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
+    seterr("");
+    if (!in_path || !out_path || !params || !out || n_shards < 1 || n_shards > 64 || !devices) return GCE_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    const double t_start = now_s();
+    gce_bam *f = nullptr; gce_fasta *fa = nullptr;
+    std::vector<gce_engine *> eng((size_t)n_shards, nullptr);
+    int32_t *ev_tid = nullptr, *ev_pos = nullptr;
+    int rc = gce_bam_open(in_path, threads, &f);
+    auto done = [&](int code, const char *m) { seterr(m); for (auto *e : eng) if (e) gce_destroy(e); if (f) gce_bam_close(f); if (fa) gce_fasta_free(fa); gce_free(ev_tid); gce_free(ev_pos); return code; };
+    if (rc != GCE_OK) return done(rc, f ? gce_bam_error(f) : "open failed");
+    out->open_s = now_s() - t_start;
+    gce_bam_info bi; gce_bam_get_info(f, &bi);
+    out->read_s = bi.read_s; out->inflate_s = bi.inflate_s; out->index_s = bi.index_s;
+    gce_params prm = *params;
+    prm.n_targets = bi.n_targets; prm.target_len = bi.target_len; prm.tick_offset = 0; prm.trailing_flush = 0;
+    if (strcmp(prm.umi_prefix, "auto") == 0) {                                   // src/gencore.cpp:207-220
+        memset(prm.umi_prefix, 0, sizeof prm.umi_prefix);
+        if (bi.n_records > 0) { gce_batch one; if (gce_bam_chunk(f, 0, 1, 0, &one) == GCE_OK) gce_detect_umi_prefix(one.qname, prm.umi_prefix); }
+    }
+    const int64_t n = bi.n_records;
+    const int T = f->threads;
+    const uint8_t *u = f->u.data();
+    double t0 = now_s();
+    // ---- the key records of the whole stream, the plan
+    Raw<gce_core> cores; cores.resize((size_t)std::max<int64_t>(n, 1));
+    Raw<uint64_t> tick; tick.resize((size_t)std::max<int64_t>(n, 1));
+    Raw<int32_t> shard; shard.resize((size_t)std::max<int64_t>(n, 1));
+    if (!cores.ok() || !tick.ok() || !shard.ok()) return done(GCE_ERR_OOM, "out of host memory");
+    parallel_for(T, n, [&](int, int64_t a, int64_t e) { for (int64_t k = a; k < e; k++) memcpy(&cores[k], u + f->rec[k] + 4, 32); });
+    int32_t n_ev = 0;
+    const int period = prm.flush_period > 0 ? prm.flush_period : 10000;
+    if ((rc = gce_stream_context(devices[0], cores.data(), n, period, tick.data(), &n_ev, &ev_tid, &ev_pos)) != GCE_OK)
+        return done(rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
+    if ((rc = gce_plan_shards(devices[0], cores.data(), n, n_shards, plan_mode, shard.data())) != GCE_OK) return done(rc, gce_status_message(rc));
+    std::vector<std::vector<int64_t>> idx((size_t)n_shards);
+    { std::vector<int64_t> cnt((size_t)n_shards, 0); for (int64_t k = 0; k < n; k++) cnt[shard[k]]++; for (int r = 0; r < n_shards; r++) idx[r].reserve((size_t)cnt[r]); for (int64_t k = 0; k < n; k++) idx[shard[k]].push_back(k); }
+    if (fasta_path && *fasta_path && (rc = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) return done(rc, "cannot read the FASTA file");
+    int32_t nc = 0; const char *const *ids = nullptr; const char *const *seqs = nullptr; const int64_t *lens = nullptr;
+    if (fa) gce_fasta_get(fa, &nc, &ids, &seqs, &lens);
+    std::vector<int32_t> fa_of((size_t)bi.n_targets, -1);                        // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+    for (int32_t t = 0; t < bi.n_targets; t++) for (int32_t c = 0; c < nc; c++) if (strcmp(ids[c], bi.target_name[t]) == 0) fa_of[t] = c;
+    out->submit_s = now_s() - t0; t0 = now_s();
+    // ---- the engines, side by side
+    std::vector<gce_result> res((size_t)n_shards);
+    std::vector<int> rcs((size_t)n_shards, GCE_OK); std::vector<std::string> msgs((size_t)n_shards);
+    std::vector<Slot> slots((size_t)n_shards);
+    std::vector<Raw<uint64_t>> ticks((size_t)n_shards);
+    std::vector<double> kms((size_t)n_shards, 0.0);
+    std::vector<std::thread> th;
+    const int Tsub = std::max(1, T / n_shards);
+    for (int r = 0; r < n_shards; r++) th.emplace_back([&, r] {
+        auto failr = [&](int code, const char *m) { rcs[r] = code; msgs[r] = m ? m : ""; };
+        const int64_t cnt = (int64_t)idx[r].size();
+        memset(&res[r], 0, sizeof res[r]);
+        gce_params pr = prm; pr.device = devices[r];
+        int c2;
+        if ((c2 = gce_create(&pr, &eng[r])) != GCE_OK) return failr(c2, gce_status_message(c2));
+        if (cnt == 0) return;
+        gce_batch b;
+        {   // (gce_bam's own thread count is shared: the chunker of a shard uses its share of the host threads)
+            const int keep = f->threads; (void)keep;
+            if ((c2 = bam_chunk_impl(f, 0, idx[r].data(), cnt, slots[r], &b)) != GCE_OK) return failr(c2, "chunk");
+        }
+        ticks[r].resize((size_t)cnt);
+        if (!ticks[r].ok()) return failr(GCE_ERR_OOM, "out of host memory");
+        for (int64_t k = 0; k < cnt; k++) ticks[r][k] = tick[idx[r][k]];
+        b.tick = ticks[r].data();
+        if (fa) {                                                                // per-shard staging: per contig the bases between the shard's first read and its last reference position
+            std::vector<int64_t> lo((size_t)bi.n_targets, INT64_MAX), hi((size_t)bi.n_targets, -1);
+            for (int64_t k = 0; k < cnt; k++) {
+                const gce_core &c = b.core[k];
+                if (c.tid < 0 || c.tid >= bi.n_targets || c.pos < 0) continue;
+                int64_t rl = 0; const uint32_t *cg = b.cigar + b.cigar_off[k];
+                for (uint32_t q = 0; q < c.n_cigar; q++) { const uint32_t op = cg[q] & 0xF; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cg[q] >> 4; }
+                lo[c.tid] = std::min<int64_t>(lo[c.tid], c.pos); hi[c.tid] = std::max<int64_t>(hi[c.tid], (int64_t)c.pos + rl);
+            }
+            for (int32_t t = 0; t < bi.n_targets; t++) {
+                if (fa_of[t] < 0 || hi[t] < 0) continue;
+                const int64_t clen = lens[fa_of[t]];
+                const int64_t a = std::min<int64_t>(lo[t] & ~(int64_t)1, clen & ~(int64_t)1), z = std::min<int64_t>(hi[t], clen);
+                if ((c2 = gce_set_reference_window(eng[r], t, clen, a, seqs[fa_of[t]] + a, std::max<int64_t>(z - a, 0))) != GCE_OK) return failr(c2, gce_last_error(eng[r]));
+            }
+        }
+        if ((c2 = gce_set_flush_events(eng[r], n_ev, ev_tid, ev_pos)) != GCE_OK || (c2 = gce_submit(eng[r], &b)) != GCE_OK) return failr(c2, gce_last_error(eng[r]));
+        if ((c2 = gce_process(eng[r])) != GCE_OK) return failr(c2, gce_last_error(eng[r])[0] ? gce_last_error(eng[r]) : gce_status_message(c2));
+        gce_timing tm; if (gce_get_timing(eng[r], &tm) == GCE_OK) kms[r] = tm.total_ms;
+        if ((c2 = gce_drain(eng[r], &res[r])) != GCE_OK) return failr(c2, gce_last_error(eng[r]));
+    });
+    for (auto &x : th) x.join();
+    (void)Tsub;
+    for (int r = 0; r < n_shards; r++) if (rcs[r] != GCE_OK) return done(rcs[r], msgs[r].c_str());
+    out->process_s = now_s() - t0; t0 = now_s();
+    for (int r = 0; r < n_shards; r++) out->kernel_ms = std::max(out->kernel_ms, kms[r]);
+    // ---- merge: k-way by bamComp over the global input index
+    int64_t n_out = 0;
+    for (int r = 0; r < n_shards; r++) n_out += res[r].n_out;
+    std::vector<uint32_t> m_src((size_t)n_out), m_qsrc((size_t)n_out); std::vector<int32_t> m_nm((size_t)n_out); std::vector<int16_t> m_fr((size_t)n_out), m_rr((size_t)n_out);
+    std::vector<const uint8_t *> m_seq((size_t)n_out), m_qual((size_t)n_out);
+    std::vector<std::vector<uint32_t>> rowmap((size_t)n_shards);
+    std::vector<int64_t> head((size_t)n_shards, 0);
+    for (int r = 0; r < n_shards; r++) rowmap[r].resize((size_t)res[r].n_out);
+    auto gsrc = [&](int r, int64_t k) { return (uint32_t)idx[r][res[r].src[k]]; };
+    auto less = [&](int ra, int64_t ka, int rb, int64_t kb) {
+        const uint32_t ia = gsrc(ra, ka), ib = gsrc(rb, kb);
+        const gce_core &a = cores[ia], &b = cores[ib];
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.mtid != b.mtid) return a.mtid < b.mtid;
+        if (a.mpos != b.mpos) return a.mpos < b.mpos;
+        if (a.isize != b.isize) return a.isize < b.isize;
+        return ia < ib;
+    };
+    for (int64_t row = 0; row < n_out; row++) {
+        int best = -1;
+        for (int r = 0; r < n_shards; r++) if (head[r] < res[r].n_out && (best < 0 || less(r, head[r], best, head[best]))) best = r;
+        const int64_t k = head[best]++;
+        rowmap[best][k] = (uint32_t)row;
+        m_src[row] = gsrc(best, k); m_qsrc[row] = (uint32_t)idx[best][res[best].qname_src[k]];
+        m_nm[row] = res[best].nm_new[k]; m_fr[row] = res[best].fr[k]; m_rr[row] = res[best].rr[k];
+        m_seq[row] = res[best].seq + res[best].seq_off[k]; m_qual[row] = res[best].qual + res[best].qual_off[k];
+    }
+    // (the unsigned tid of an unmapped record sorts it last in the engines' tables; bamComp compares the signed field: pass-through
+    //  records of unmapped reads do not exist -- unmapped reads are dropped, gencore.cpp:255-266 -- so the two orders agree)
+    for (int r = 0; r < n_shards; r++) {
+        out->n_reads += res[r].n_reads; out->n_out += res[r].n_out;
+        const int64_t *a = (const int64_t *)&res[r].pre, *c = (const int64_t *)&res[r].post;
+        int64_t *pa = (int64_t *)&out->pre, *pc = (int64_t *)&out->post;
+        for (int q = 0; q < GCE_STATS_WORDS; q++) { pa[q] += a[q]; pc[q] += c[q]; }
+    }
+    out->drain_s = now_s() - t0; t0 = now_s();
+    const OutRows rows{n_out, m_src.data(), m_qsrc.data(), m_nm.data(), m_fr.data(), m_rr.data()};
+    if ((rc = bam_write_rows(out_path, f, rows, [&](int64_t k) { return m_seq[k]; }, [&](int64_t k) { return m_qual[k]; }, threads, level)) != GCE_OK) return done(rc, "cannot write the output BAM");
     out->write_s = now_s() - t0;
     out->total_s = now_s() - t_start;
     return done(GCE_OK, "");

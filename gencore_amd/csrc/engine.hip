@@ -242,6 +242,17 @@ int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid,
     return GCE_OK;
 }
 
+// the six addRead counters of either Stats block are spread over GCE_PRE_SLOTS words each (k_describe, k_out_meta): summed into the
+// blocks themselves, the slots cleared, so that the device copy is complete (the host adds the slots of ITS copy: zeros after this)
+__global__ void k_fold_stats(StreamInfo *si) {
+    const int k = threadIdx.x;
+    if (k < 6) {
+        long long a = 0, c = 0;
+        for (int q = 0; q < GCE_PRE_SLOTS; q++) { a += si->pre_slot[q][k]; c += si->post_slot[q][k]; si->pre_slot[q][k] = 0; si->post_slot[q][k] = 0; }
+        si->pre[k] += a; si->post[k] += c;
+    }
+}
+
 __global__ void k_add_u64(uint64_t *a, uint64_t n, uint64_t base) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] += base;
@@ -722,6 +733,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_out_gather, dim3(std::min<unsigned>(cdiv(n1, 16), 16384u)), dim3(256), 0, s, b, w, o);
     }
     HIPCHK(hipEventRecord(e->ev[EV_OUTPUT], s));
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, s, w.si);          // (outside the timed step: a convenience of gce_stats_device)
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
     e->h_si.n_groups = NG;
@@ -838,6 +850,14 @@ int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_
     return GCE_OK;
 }
 
+// the Stats blocks of the last gce_process on the DEVICE: 2 x GCE_STATS_WORDS int64 (pre, then post), complete (the spread addRead
+// counters are folded in), for a collective that should not bounce through the host (one RCCL all-reduce)
+int gce_stats_device(gce_engine *e, const int64_t **pre_then_post) {
+    if (!e || !pre_then_post || !e->processed || e->dev_error) return GCE_ERR_INVALID;
+    *pre_then_post = (const int64_t *)e->si.as<StreamInfo>()->pre;
+    return GCE_OK;
+}
+
 int gce_get_timing(gce_engine *e, gce_timing *out) {
     if (!e || !out) return GCE_ERR_INVALID;
     *out = e->timing;
@@ -845,3 +865,5 @@ int gce_get_timing(gce_engine *e, gce_timing *out) {
 }
 
 }  // extern "C"
+
+#include "gce_plan.hpp"

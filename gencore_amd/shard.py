@@ -146,6 +146,36 @@ def plan_shards(core, world, mode="range"):
     return owner[inv]
 
 
+def stream_context_gpu(core, flush_period=10000, device=0):
+    """stream_context on the GPU through the C-ABI (gce_stream_context): same return values."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load_library()
+    core = np.ascontiguousarray(core)
+    n = len(core)
+    tick = np.zeros(n, np.uint64)
+    ne, et, ep = C.c_int32(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+    rc = lib.gce_stream_context(device, core.ctypes.data, n, flush_period, tick.ctypes.data, C.byref(ne), C.byref(et), C.byref(ep))
+    if rc != 0:
+        raise capi.GceError(rc, "gce_stream_context")
+    ev_tid = np.ctypeslib.as_array(et, shape=(ne.value,)).copy() if ne.value else np.zeros(0, np.int32)
+    ev_pos = np.ctypeslib.as_array(ep, shape=(ne.value,)).copy() if ne.value else np.zeros(0, np.int32)
+    lib.gce_free(et); lib.gce_free(ep)
+    return tick, ev_tid, ev_pos
+
+
+def plan_shards_gpu(core, world, mode="range", device=0):
+    """plan_shards on the GPU through the C-ABI (gce_plan_shards)."""
+    from . import capi
+    lib = capi.load_library()
+    core = np.ascontiguousarray(core)
+    out = np.zeros(len(core), np.int32)
+    rc = lib.gce_plan_shards(device, core.ctypes.data, len(core), world, 0 if mode == "range" else 1, out.ctypes.data)
+    if rc != 0:
+        raise capi.GceError(rc, "gce_plan_shards")
+    return out
+
+
 def shard_by_plan(batch, plan, rank, tick):
     """Sub-batch of `rank` (reads in stream order) carrying the global ticks; returns (sub_batch, read_indices)."""
     idx = np.nonzero(plan == rank)[0]

@@ -281,6 +281,23 @@ int gce_depth_stats(gce_engine *e, int32_t coverage_step, int32_t n_regions, con
                     const int32_t *region_end, gce_depth *out);
 
 int gce_get_timing(gce_engine *e, gce_timing *out);
+/* The two Stats blocks of the last gce_process in DEVICE memory: 2 x GCE_STATS_WORDS int64, pre then post -- for the final Stats merge
+ * of a multi-GPU run (one RCCL all-reduce(sum); all fields are additive, src/stats.h:47-65) without a bounce through the host. */
+int gce_stats_device(gce_engine *e, const int64_t **pre_then_post);
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU planning, on a GPU from the 32-byte key records of the WHOLE sorted stream (host or device pointers).
+ * Clusters shard by cluster key (tid, left), not by read position: a right mate follows its mate (src/gencore.cpp:301-303).
+ * ------------------------------------------------------------------------------------------------------------------------ */
+/* tick_out[i] = the reference's `tick` right after read i was added (src/gencore.cpp:319-320; unchanged by reads that never reach the
+ * cluster map) -> gce_batch.tick of a shard; the flush events (src/gencore.cpp:321-322) as malloc'ed host arrays (gce_free) ->
+ * gce_set_flush_events.  GCE_ERR_INVALID if a clustered read follows the first unmapped read (not shardable by key). */
+int gce_stream_context(int32_t device, const gce_core *core, int64_t n_reads, int32_t flush_period, uint64_t *tick_out,
+                       int32_t *n_events, int32_t **ev_tid, int32_t **ev_pos);
+/* shard_out[i] in [0, world): mode 0 = contiguous key ranges of equal read count (configs[3]: the cuts fall inside contigs),
+ * mode 1 = whole clusters dealt longest-processing-time first with weight reads^2 (configs[4]: ultra-deep hotspots).  world <= 64. */
+int gce_plan_shards(int32_t device, const gce_core *core, int64_t n_reads, int32_t world, int32_t mode, int32_t *shard_out);
+void gce_free(void *p);
 /* Drop all submitted reads/results but keep params, reference and allocations (for repeated bench steps). */
 int gce_reset(gce_engine *e);
 
@@ -359,6 +376,13 @@ typedef struct gce_bam_run {
  * (src/gencore.cpp:207-220).  fasta_path may be NULL. */
 int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
                 int64_t chunk_reads, int level, gce_bam_run *out, char err[256]);
+/* The same over SEVERAL engines, one per entry of `devices` (HIP ordinals; they may repeat): the stream is cut into n_shards ranges of the
+ * cluster key by gce_stream_context + gce_plan_shards (plan_mode as there), every shard gets its reads, their global ticks, the flush
+ * events and the reference window its reads touch; the engines run side by side, their tables are merged in bamComp order, the Stats
+ * blocks summed on the host.  Same records, same order, same Stats as gce_run_bam.  Needs every mapped read in front of the first
+ * unmapped one (a coordinate-sorted BAM).  params->tick_offset / trailing_flush are ignored. */
+int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards,
+                        const int32_t *devices, int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]);
 
 #ifdef __cplusplus
 }

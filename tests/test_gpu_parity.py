@@ -449,3 +449,52 @@ def test_reference_windows_equal_whole_contigs(built):
                 assert not diff_results(b, got, want)
         finally:
             e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_pairs,world,mode,period", [("cfg3", 40000, 4, "range", 10000), ("cfg3", 20000, 3, "range", 977), ("cfg5", 20000, 4, "lpt", 10000),
+                                                          ("cfg2", 30000, 8, "range", 1500), ("cfg1s", None, 2, "lpt", 10000)])
+def test_c_planner_equals_the_python_spec(built, name, n_pairs, world, mode, period):
+    """gce_stream_context / gce_plan_shards (GPU kernels behind the C-ABI) against gencore_amd/shard.py on whole streams: ticks, flush
+    events and the shard of every read, both plan modes."""
+    from gencore_amd import shard, synth
+    d = synth.generate(name, n_pairs=n_pairs)
+    core = d.to_batch().core
+    tick, et, ep = shard.stream_context(core, period)
+    gtick, get, gep = shard.stream_context_gpu(core, period)
+    cm = shard.clustered_mask(core)
+    assert np.array_equal(tick, gtick) and np.array_equal(et, get) and np.array_equal(ep, gep) and len(et) == int(cm.sum()) // period
+    assert np.array_equal(shard.plan_shards(core, world, mode), shard.plan_shards_gpu(core, world, mode))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n_pairs,shards,mode,period", [("cfg3", 30000, 3, 0, 2000), ("cfg5", 3000, 2, 1, 10000), ("cfg2", 20000, 4, 0, 700)])
+def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, workload, n_pairs, shards, mode, period):
+    """gce_run_bam_sharded (C planner, one engine per shard -- all on device 0 here --, ticks + flush events + per-shard reference windows,
+    k-way merge, host Stats sum) writes the same records in the same order with the same Stats as gce_run_bam."""
+    import pybam
+    from gencore_amd import synth
+    from gencore_amd.bamio import run_bam, run_bam_sharded
+    from gencore_amd.capi import default_params
+    from test_bamio import records_of
+    from test_cabi_driver import ascii_of
+    d = synth.generate(workload, n_pairs=n_pairs)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    targets = [("chr%d" % (i + 1), int(l)) for i, l in enumerate(tl)]
+    src, one, many, fa = (str(tmp_path / x) for x in ("in.bam", "one.bam", "many.bam", "ref.fa"))
+    pybam.write_bam(src, records_of(batch), targets)
+    with open(fa, "wb") as f:
+        for (nm, _), bases in zip(targets, ascii_of(d.reference_host())):
+            if bases is not None:
+                f.write(b">" + nm.encode() + b"\n" + bases + b"\n")
+    prm = default_params(umi_prefix="auto", cluster_size_req=d.info["supporting_reads"], flush_period=period)
+    r1 = run_bam(src, one, prm, fasta=fa, threads=4)
+    r2 = run_bam_sharded(src, many, prm, [0] * shards, fasta=fa, plan_mode=mode, threads=4)
+    assert (r1.n_reads, r1.n_out) == (r2.n_reads, r2.n_out) and r1.n_out > 0
+    assert bytes(r1.pre) == bytes(r2.pre) and bytes(r1.post) == bytes(r2.post)
+    _, t1, g1 = pybam.read_bam(one)
+    _, t2, g2 = pybam.read_bam(many)
+    assert t1 == t2 and len(g1) == len(g2)
+    for a, b in zip(g1, g2):                                                 # record by record, in file order
+        assert a == b
