@@ -181,6 +181,7 @@ def main():
     t["qname"] = padded_clone(t["qname"])
 
     stats_dev = torch.zeros(2 * capi.GCE_STATS_WORDS, dtype=torch.int64, device=dev)
+    hip = _hip()
     timings, last_res = [], {}
 
     def step(k):
@@ -191,9 +192,10 @@ def main():
             raise SystemExit("engine failed: %s" % lib.gce_last_error(eng).decode())
         r = capi.GceResult()
         lib.gce_result_device(eng, C.byref(r))
-        if dist:                                            # the final Stats merge: one RCCL all-reduce over xGMI
-            host = np.concatenate([r.pre.as_array(), r.post.as_array()])
-            stats_dev.copy_(torch.from_numpy(host))
+        if dist:                                            # the final Stats merge: one RCCL all-reduce over xGMI, device to device
+            sp = C.c_void_p()                               # (gce_stats_device: both blocks as they lie in HBM, 2 x 114 int64)
+            assert lib.gce_stats_device(eng, C.byref(sp)) == 0
+            assert hip.hipMemcpyAsync(C.c_void_p(stats_dev.data_ptr()), sp, C.c_size_t(stats_dev.numel() * 8), 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
             dist.all_reduce(stats_dev)
         tm = GceTiming()
         lib.gce_get_timing(eng, C.byref(tm))
