@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
     "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch",
-    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_sharded", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_raw_begin", "gce_raw_push", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
 
 
 class GceBamInfo(C.Structure):
@@ -121,7 +121,7 @@ class GceDepth(C.Structure):
 class GceBamRun(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_out", C.c_int64), ("open_s", C.c_double), ("read_s", C.c_double), ("inflate_s", C.c_double), ("index_s", C.c_double), ("submit_s", C.c_double),
                 ("process_s", C.c_double), ("kernel_ms", C.c_double), ("drain_s", C.c_double), ("write_s", C.c_double),
-                ("total_s", C.c_double), ("pre", GceStats), ("post", GceStats)]
+                ("total_s", C.c_double), ("pre", GceStats), ("post", GceStats), ("peak_rss_kb", C.c_int64), ("rss_start_kb", C.c_int64), ("rss_end_kb", C.c_int64)]
 
 
 class GceError(RuntimeError):

@@ -1144,7 +1144,9 @@ void gce_bed_free(int32_t n_regions, int32_t *tid, int32_t *start, int32_t *end,
 }
 
 // Gencore::consensus() for a sorted BAM (src/gencore.cpp:162-293) through the C-ABI.
-int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+// The whole-file path of round 2 (gce_bam_open: everything inflated and indexed on the host, struct-of-arrays chunks, gce_bam_write): kept as
+// gce_run_bam_hostcodec for callers that want the host codec end to end and as the fallback of gce_run_bam.
+int gce_run_bam_hostcodec(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
                 int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {
     auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
     seterr("");
@@ -1205,6 +1207,233 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     return done(GCE_OK, "");
 }
 
+
+
+// ---- the streaming, GPU-assisted file path
+int gce_raw_begin(gce_engine *e, size_t capacity_hint);
+int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket);
+int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records);
+int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
+int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
+int gce_host_alloc(size_t bytes, void **out);
+void gce_host_free(void *p);
+}  // extern "C" (declarations)
+extern "C++" {
+namespace {
+struct Pinned {                                   // a pinned host buffer that grows
+    uint8_t *p = nullptr; size_t cap = 0;
+    ~Pinned() { gce_host_free(p); }
+    bool ensure(size_t n) { if (n <= cap) return true; gce_host_free(p); p = nullptr; cap = 0; void *q = nullptr; if (gce_host_alloc(n + (n >> 3) + 4096, &q) != GCE_OK) return false; p = (uint8_t *)q; cap = n + (n >> 3) + 4096; return true; }
+};
+long status_kb(const char *key) { FILE *f = fopen("/proc/self/status", "r"); if (!f) return 0; char line[256]; long v = 0; const size_t kl = strlen(key); while (fgets(line, sizeof line, f)) if (strncmp(line, key, kl) == 0) { v = atol(line + kl); break; } fclose(f); return v; }
+}  // namespace
+}  // extern "C++"
+extern "C" {
+
+// Replaces Gencore::consensus() end to end (src/gencore.cpp:162-293) as a PIPELINE with a bounded host footprint: a reader thread preads the
+// file in pieces; the host threads inflate the BGZF blocks of piece k (own decoder + CLMUL CRC) into a pinned window while the DMA engine
+// copies window k - 1 into HBM; nothing of the input stays on the host.  Records are indexed, parsed (gce_raw_finish) and -- after
+// gce_process -- re-assembled as BAM records (gce_raw_build_output) on the GPU; the output stream comes back in pieces that are deflated by
+// all host threads and written in order while the next piece is on its way.  Host memory: two compressed pieces, three inflated windows,
+// three output pieces -- independent of the file's size (round 2 held the whole inflated file and every record table on the host).
+int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {
+    auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
+    seterr("");
+    if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
+    if (getenv("GCE_BAM_HOSTCODEC")) return gce_run_bam_hostcodec(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err);
+    memset(out, 0, sizeof *out);
+    out->rss_start_kb = status_kb("VmRSS:");
+    const double t_start = now_s();
+    const int T = threads > 0 ? threads : default_threads();
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) { seterr("cannot open the input BAM"); return GCE_ERR_INVALID; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); seterr("cannot stat the input BAM"); return GCE_ERR_INVALID; }
+    const uint64_t fsz = (uint64_t)st.st_size;
+    gce_engine *e = nullptr; gce_fasta *fa = nullptr; FILE *fo = nullptr;
+    auto done = [&](int code, const char *m) { seterr(m); if (e) gce_destroy(e); if (fa) gce_fasta_free(fa); if (fo) fclose(fo); close(fd); return code; };
+    const size_t PIECE = (size_t)(chunk_reads > 0 && chunk_reads < (1 << 16) ? (1 << 20) : (8 << 20));       // compressed bytes per window (tests shrink it through chunk_reads)
+    Raw<uint8_t> comp[2]; comp[0].resize(PIECE + (1 << 17)); comp[1].resize(PIECE + (1 << 17));
+    if (!comp[0].ok() || !comp[1].ok()) return done(GCE_ERR_OOM, "out of host memory");
+    Pinned win[3]; int32_t win_ticket[3] = {-1, -1, -1};
+    // reader: piece k of the file into comp[k & 1] behind the carry-over of piece k - 1 (a BGZF block cut by the piece border)
+    uint64_t file_off = 0; size_t carry = 0; double t_read = 0, t_inflate = 0, t_wait = 0;
+    std::vector<Block> blocks;
+    std::vector<std::string> names; std::vector<uint32_t> lens; std::string text;
+    uint64_t hdr_end = 0; bool have_header = false;
+    gce_params prm = *params;
+    Raw<uint8_t> head;                                  // the inflated start of the stream until the header is complete (usually one window)
+    std::thread reader; ssize_t got_next = 0; bool reader_on = false;
+    auto start_read = [&](int slot, size_t keep) {
+        const uint64_t at = file_off; const size_t want = (size_t)std::min<uint64_t>(PIECE, fsz - at);
+        reader_on = true;
+        reader = std::thread([&, slot, keep, at, want] { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, comp[slot].data() + keep + o, want - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } got_next = (ssize_t)o; t_read += now_s() - r0; });
+        file_off += want;
+    };
+    int k = 0;
+    size_t have = 0;                                    // bytes in comp[k & 1]: carry + piece
+    if (fsz) { start_read(0, 0); reader.join(); reader_on = false; have = (size_t)got_next; }
+    int rc = GCE_OK;
+    uint64_t pushed = 0;
+    while (have > 0) {
+        const int cs = k & 1, ws = k % 3;
+        uint8_t *z = comp[cs].data();
+        // ---- BGZF members of this piece
+        blocks.clear();
+        size_t off = 0; uint64_t uoff = 0;
+        while (off + 18 <= have) {
+            const uint8_t *p = z + off;
+            if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return done(GCE_ERR_INVALID, "not a BGZF file");
+            const uint16_t xlen = rd16(p + 10);
+            if (off + 12 + (size_t)xlen > have) break;
+            uint32_t bsize = 0; bool found = false;
+            for (uint32_t x = 0; x + 4 <= xlen; ) {
+                const uint8_t *sf = p + 12 + x; const uint16_t sl = rd16(sf + 2);
+                if (x + 4 + (uint32_t)sl > xlen) break;
+                if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) { bsize = (uint32_t)rd16(sf + 4) + 1; found = true; }
+                x += 4 + sl;
+            }
+            if (!found || bsize < 12u + xlen + 8u) return done(GCE_ERR_INVALID, "bad BGZF block");
+            if (off + bsize > have) break;                                              // cut by the piece border: carried over
+            Block b; b.coff = off; b.csize = bsize; b.usize = rd32(p + bsize - 4); b.uoff = uoff;
+            if (b.usize > 0x10000u) return done(GCE_ERR_INVALID, "bad BGZF block (ISIZE above 64 KB)");
+            blocks.push_back(b); off += bsize; uoff += b.usize;
+        }
+        const bool last = file_off >= fsz;
+        if (last && off != have) return done(GCE_ERR_INVALID, "truncated BGZF block at the end of the file");
+        if (!last && blocks.empty()) return done(GCE_ERR_INVALID, "BGZF block larger than a window");
+        // ---- the next piece is read while this one is inflated
+        carry = have - off;
+        if (!last) { memcpy(comp[cs ^ 1].data(), z + off, carry); start_read(cs ^ 1, carry); }
+        if (win_ticket[ws] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, win_ticket[ws])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); } t_wait += now_s() - w0; win_ticket[ws] = -1; }
+        if (!win[ws].ensure((size_t)uoff + 64)) { if (reader_on) reader.join(); return done(GCE_ERR_OOM, "out of pinned host memory"); }
+        const double i0 = now_s();
+        std::atomic<int> bad{0};
+        parallel_for(T, (int64_t)blocks.size(), [&](int, int64_t a, int64_t b2) { for (int64_t q = a; q < b2; q++) if (blocks[q].usize && !inflate_block(z + blocks[q].coff, blocks[q], win[ws].p + blocks[q].uoff)) bad = 1; });
+        t_inflate += now_s() - i0;
+        if (bad) { if (reader_on) reader.join(); return done(GCE_ERR_INVALID, "inflate / CRC failure"); }
+        // ---- header (first window(s)), engine, reference
+        if (!have_header) {
+            const size_t old = head.size();
+            Raw<uint8_t> h2; h2.resize(old + (size_t)uoff + 1); if (!h2.ok()) { if (reader_on) reader.join(); return done(GCE_ERR_OOM, "out of host memory"); }
+            if (old) memcpy(h2.data(), head.data(), old);
+            memcpy(h2.data() + old, win[ws].p, (size_t)uoff); h2.n = old + (size_t)uoff; head = std::move(h2);
+            const uint8_t *u = head.data(); const uint64_t n = head.size();
+            bool complete = false;
+            if (n >= 12 && memcmp(u, "BAM\1", 4) != 0) { if (reader_on) reader.join(); return done(GCE_ERR_INVALID, "not a BAM stream"); }
+            if (n >= 12) {
+                uint64_t p = 4; const uint32_t l_text = rd32(u + p); p += 4;
+                if (p + l_text + 4 <= n) {
+                    const uint64_t tp = p; p += l_text;
+                    const uint32_t n_ref = rd32(u + p); p += 4;
+                    names.clear(); lens.clear(); bool ok = true;
+                    for (uint32_t r = 0; r < n_ref && ok; r++) {
+                        if (p + 4 > n) { ok = false; break; }
+                        const uint32_t ln = rd32(u + p); p += 4;
+                        if (ln == 0 || p + ln + 4 > n) { ok = false; break; }
+                        names.emplace_back((const char *)u + p, ln - 1); p += ln; lens.push_back(rd32(u + p)); p += 4;
+                    }
+                    if (ok) { complete = true; hdr_end = p; text.assign((const char *)u + tp, l_text); }
+                }
+            }
+            if (!complete && last) { if (reader_on) reader.join(); return done(GCE_ERR_INVALID, "truncated header"); }
+            if (complete) {
+                have_header = true;
+                prm.n_targets = (int32_t)lens.size(); prm.target_len = lens.data();
+                if (strcmp(prm.umi_prefix, "auto") == 0) {                               // src/gencore.cpp:207-220: the first record's name
+                    memset(prm.umi_prefix, 0, sizeof prm.umi_prefix);
+                    if (hdr_end + 36 < n) { const uint32_t lq = u[hdr_end + 12]; if (hdr_end + 36 + lq <= n) gce_detect_umi_prefix((const char *)u + hdr_end + 36, prm.umi_prefix); }
+                }
+                if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS before gce_create %ld MB (entry %ld MB)\n", status_kb("VmRSS:") >> 10, (long)(out->rss_start_kb >> 10));
+                if ((rc = gce_create(&prm, &e)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_status_message(rc)); }
+                if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
+                if (fasta_path && *fasta_path) {
+                    if ((rc = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, "cannot read the FASTA file"); }
+                    int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *flen;
+                    gce_fasta_get(fa, &nc, &ids, &seqs, &flen);
+                    for (size_t t = 0; t < lens.size(); t++)                             // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+                        for (int32_t c = 0; c < nc; c++)
+                            if (names[t] == ids[c] && (rc = gce_set_reference_ascii(e, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
+                    gce_fasta_free(fa); fa = nullptr;                                    // (packed in HBM: the host copy goes)
+                }
+                if ((rc = gce_raw_begin(e, (size_t)std::max<uint64_t>(fsz * 5, head.size()))) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
+                // what was inflated so far goes up in one piece (normally: this very window)
+                if (old) { int32_t tk; if ((rc = gce_raw_push(e, head.data(), old, &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); } pushed += old; }
+                head.release();
+            }
+        }
+        if (have_header && uoff) {
+            if ((rc = gce_raw_push(e, win[ws].p, (size_t)uoff, &win_ticket[ws])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
+            pushed += uoff;
+        }
+        if (reader_on) { reader.join(); reader_on = false; have = carry + (size_t)got_next; } else have = 0;
+        k++;
+    }
+    if (!have_header) return done(GCE_ERR_INVALID, fsz ? "truncated header" : "empty file");
+    out->read_s = t_read; out->inflate_s = t_inflate; out->submit_s = t_wait;
+    out->open_s = now_s() - t_start;
+    if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after the input pipeline %ld MB\n", status_kb("VmRSS:") >> 10);
+    double t0 = now_s();
+    int64_t n_rec = 0;
+    if ((rc = gce_raw_finish(e, hdr_end, prm.n_targets, &n_rec)) != GCE_OK) return done(rc, gce_last_error(e));
+    out->index_s = now_s() - t0; t0 = now_s();
+    uint64_t body = 0; int64_t n_out = 0;
+    if (n_rec > 0) {
+        if ((rc = gce_process(e)) != GCE_OK) return done(rc, gce_last_error(e)[0] ? gce_last_error(e) : gce_status_message(rc));
+        out->process_s = now_s() - t0; t0 = now_s();
+        gce_timing tm; if (gce_get_timing(e, &tm) == GCE_OK) out->kernel_ms = tm.total_ms;
+        gce_result res;
+        if ((rc = gce_result_device(e, &res)) != GCE_OK) return done(rc, gce_last_error(e));
+        out->n_reads = res.n_reads; out->n_out = res.n_out; out->pre = res.pre; out->post = res.post;
+        if ((rc = gce_raw_build_output(e, &body, &n_out)) != GCE_OK) return done(rc, gce_last_error(e));
+        out->drain_s = now_s() - t0; t0 = now_s();
+        if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after process + output records %ld MB\n", status_kb("VmRSS:") >> 10);
+    }
+    // ---- the output file: header bytes + the record stream from HBM, in pieces; deflate by all threads, written in order
+    std::vector<uint8_t> hdr;
+    auto put32 = [&](uint32_t x) { const uint8_t *p = (const uint8_t *)&x; hdr.insert(hdr.end(), p, p + 4); };
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32((uint32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end());
+    put32((uint32_t)lens.size());
+    for (size_t r = 0; r < lens.size(); r++) { put32((uint32_t)names[r].size() + 1); hdr.insert(hdr.end(), names[r].begin(), names[r].end()); hdr.push_back(0); put32(lens[r]); }
+    fo = fopen(out_path, "wb");
+    if (!fo) return done(GCE_ERR_INVALID, "cannot open the output BAM");
+    const uint64_t BS = 0xff00, OC = BS * 256, total = hdr.size() + body;
+    const int64_t npieces = (int64_t)((total + OC - 1) / OC);
+    Pinned obuf[3]; int32_t otk[3] = {-1, -1, -1};
+    Raw<uint8_t> zbuf; zbuf.resize((size_t)256 * 0x10000 + 64);
+    if (!zbuf.ok()) return done(GCE_ERR_OOM, "out of host memory");
+    auto fetch = [&](int64_t pc) -> int {                                                 // piece pc of (header ++ body) into obuf[pc % 3]
+        const uint64_t a = (uint64_t)pc * OC, z2 = std::min<uint64_t>(total, a + OC);
+        Pinned &b = obuf[pc % 3];
+        if (!b.ensure((size_t)(z2 - a) + 64)) return GCE_ERR_OOM;
+        uint64_t at = a;
+        if (at < hdr.size()) { const uint64_t hn = std::min<uint64_t>(hdr.size(), z2) - at; memcpy(b.p, hdr.data() + at, hn); at += hn; }
+        if (at < z2) return gce_raw_read_output_async(e, at - hdr.size(), b.p + (at - a), (size_t)(z2 - at), &otk[pc % 3]);
+        otk[pc % 3] = -1; return GCE_OK;
+    };
+    if (npieces > 0 && (rc = fetch(0)) != GCE_OK) return done(rc, "output piece");
+    for (int64_t pc = 0; pc < npieces; pc++) {
+        if (pc + 1 < npieces && (rc = fetch(pc + 1)) != GCE_OK) return done(rc, "output piece");
+        if (otk[pc % 3] >= 0 && (rc = gce_submit_wait(e, otk[pc % 3])) != GCE_OK) return done(rc, gce_last_error(e));
+        const uint64_t a = (uint64_t)pc * OC, z2 = std::min<uint64_t>(total, a + OC);
+        const int64_t nb = (int64_t)((z2 - a + BS - 1) / BS);
+        std::vector<uint32_t> zs((size_t)nb, 0);
+        const uint8_t *src = obuf[pc % 3].p;
+        parallel_for(T, nb, [&](int, int64_t x, int64_t y) { for (int64_t q = x; q < y; q++) { const uint64_t o = (uint64_t)q * BS; zs[q] = (uint32_t)deflate_block(src + o, (uint32_t)std::min<uint64_t>(BS, z2 - a - o), level, zbuf.data() + (size_t)q * 0x10000); } });
+        for (int64_t q = 0; q < nb; q++) { if (zs[q] == 0 || fwrite(zbuf.data() + (size_t)q * 0x10000, 1, zs[q], fo) != zs[q]) return done(GCE_ERR_INVALID, "cannot write the output BAM"); }
+    }
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool eof_ok = fwrite(eof_block, 1, 28, fo) == 28;
+    const bool closed = fclose(fo) == 0; fo = nullptr;
+    if (!eof_ok || !closed) return done(GCE_ERR_INVALID, "cannot write the output BAM");
+    out->write_s = now_s() - t0;
+    out->total_s = now_s() - t_start;
+    out->peak_rss_kb = status_kb("VmHWM:"); out->rss_end_kb = status_kb("VmRSS:");
+    (void)pushed;
+    return done(GCE_OK, "");
+}
 
 // Gencore::consensus() for one BAM over SEVERAL engines: the stream is cut into n_shards ranges of the cluster key by the
 // GPU planner (gce_stream_context + gce_plan_shards on devices[0]); shard r runs on HIP device devices[r] (ordinals may repeat: several

@@ -72,6 +72,9 @@ struct gce_engine {
     DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_soff, o_qoff, o_seq, o_qual, o_key, o_rec, o_ksoff, o_kqoff, o_krow, o_part3, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
     DevBuf lrec, lout, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
+    // the raw BAM stream in HBM (gce_bamdev.hpp)
+    DevBuf raw, rw_bad, rw_guess, rw_leave, rw_cnt, rw_base, rw_misc, rw_tmp, rw_off, rw_ncig, rw_nmpos, rw_rsize, rw_roff, rw_body;
+    size_t raw_n = 0; bool raw_mode = false; int64_t raw_records = 0; uint64_t raw_body_bytes = 0;
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
@@ -157,6 +160,7 @@ void gce_destroy(gce_engine *e) {
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
+    for (DevBuf *b : {&e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }
@@ -229,7 +233,7 @@ int gce_reset(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
     e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear(); e->h_tick.clear();
     e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
-    e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = false; e->n = 0; e->n_out = 0;
+    e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = e->raw_mode = false; e->n = 0; e->n_out = 0;
     e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = 0;                     // a reservation (gce_reserve) stays
     return GCE_OK;
 }
@@ -867,3 +871,4 @@ int gce_get_timing(gce_engine *e, gce_timing *out) {
 }  // extern "C"
 
 #include "gce_plan.hpp"
+#include "gce_bamdev.hpp"

@@ -1,0 +1,413 @@
+// gce_bamdev.hpp — the GPU side of the BAM codec ("multi-threaded or GPU-assisted"): the host only inflates and deflates
+// BGZF blocks; everything that touches RECORDS happens in HBM.
+//   gce_raw_begin / gce_raw_push     the inflated BAM stream arrives window by window (host pinned buffer -> HBM, asynchronously, while the host
+//                                    inflates the next window); the host keeps nothing of it
+//   gce_raw_finish                   record index on the GPU (the chain of block_size fields, walked by one lane per 16 KB segment from a
+//                                    guessed record start and joined where the guesses meet the chain -- the scheme of the host index in
+//                                    bamio.cpp --), then the gce_batch of the stream WITHOUT copying names, bases or qualities: the blobs of
+//                                    the struct-of-arrays ARE the raw stream (offsets point into it); only the 32-byte key records, the CIGAR
+//                                    words (alignment) and NM / MI (aux walk) are extracted.  Replaces sam_read1's record parsing
+//                                    (src/gencore.cpp:205-274 via htslib) for the whole file at once.
+//   gce_raw_build_output             after gce_process: the emitted records as BAM records, assembled in HBM from the raw stream (the template's
+//                                    record, mutated in place by the vote, with the name of its copyQName source, NM patched, FR / RR
+//                                    appended: src/gencore.cpp:83-111 writeBam, src/pair.cpp:43-68) -- the host gets a byte stream that only
+//                                    needs BGZF blocks around it
+//   gce_raw_read_output[_async]      that stream, piece by piece, into host (pinned) memory
+#pragma once
+
+namespace {
+
+typedef uint32_t rb_u32u __attribute__((aligned(1)));
+typedef uint16_t rb_u16u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t rb32(const uint8_t *p) { return *(const rb_u32u *)p; }
+__device__ __forceinline__ uint32_t rb16(const uint8_t *p) { return *(const rb_u16u *)p; }
+#define RAW_SEG (16u << 10)
+
+// does a record start at o?  (bamio.cpp's test: sane block_size, contig ids inside the header's, a NUL-terminated name, the fixed fields fit)
+__device__ __forceinline__ bool raw_plausible(const uint8_t *u, uint64_t o, uint64_t n, int32_t nref) {
+    if (o + 36 > n) return false;
+    const uint32_t bs = rb32(u + o);
+    if (bs < 32 || bs > (1u << 28) || o + 4 + bs > n) return false;
+    const uint8_t *r = u + o + 4;
+    const int32_t tid = (int32_t)rb32(r), mtid = (int32_t)rb32(r + 20), ls = (int32_t)rb32(r + 16); const uint32_t lq = r[8], nc = rb16(r + 12);
+    if (tid < -1 || tid >= nref || mtid < -1 || mtid >= nref || lq == 0 || ls < 0) return false;
+    if (32ull + lq + 4ull * nc + (uint64_t)(ls + 1) / 2 + (uint64_t)ls > bs) return false;
+    return r[32 + lq - 1] == 0;
+}
+// records starting in [o, hi): count, optionally their offsets; returns where the chain leaves the range (~0 = broken chain)
+__device__ __forceinline__ uint64_t raw_walk(const uint8_t *u, uint64_t o, uint64_t hi, uint64_t n, uint32_t &cnt, uint64_t *out) {
+    while (o < hi && o + 4 <= n) {
+        const uint32_t bs = rb32(u + o);
+        if (bs < 32 || o + 4 + bs > n) return ~0ull;
+        if (out) out[cnt] = o;
+        cnt++;
+        o += 4ull + bs;
+    }
+    return o;
+}
+__global__ __launch_bounds__(256) void k_raw_seg(const uint8_t *u, uint64_t first, uint64_t n, int32_t nref, uint64_t nseg, uint64_t *guess, uint64_t *leave, uint32_t *cnt) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const uint64_t lo = first + s * RAW_SEG, hi = min(n, lo + RAW_SEG);
+    uint64_t o = lo;
+    if (s > 0) {                                                   // a guessed start: two sane records in a row (the first segment starts on the first record)
+        while (o < hi && !(raw_plausible(u, o, n, nref) && (o + 4 + rb32(u + o) + 3 >= n || raw_plausible(u, o + 4 + rb32(u + o), n, nref)))) o++;
+        if (o >= hi) { guess[s] = ~0ull; leave[s] = ~0ull; cnt[s] = 0; return; }
+    }
+    uint32_t c = 0;
+    guess[s] = o;
+    leave[s] = raw_walk(u, o, hi, n, c, nullptr);
+    cnt[s] = c;
+}
+// every segment's guess must be where the chain of the segment in front of it leaves: flag = number of segments for which it is not
+__global__ __launch_bounds__(256) void k_raw_check(const uint64_t *guess, const uint64_t *leave, uint64_t nseg, uint64_t n, unsigned int *bad, uint8_t *bad_of) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const bool b = leave[s] == ~0ull || (s > 0 && guess[s] != leave[s - 1]) || (s == nseg - 1 && leave[s] != n);
+    bad_of[s] = b;
+    if (b) atomicAdd(bad, 1u);
+}
+// repair, in parallel.  A guess can be a coincidence: one byte in front of a record of contig 0 the shifted fields pass the test about once
+// in 4000 segments (block_size x 256 + the last NM byte, tid x 256 = 0 ...), and the chain walked from there leaves far behind the
+// segment, which also puts the NEXT segment off the chain although its own guess is right.  Every round re-walks the flagged segments
+// whose predecessor is NOT flagged (that one's chain is final, nothing it reads changes in the round) from where that chain leaves; the
+// check that follows clears the neighbours.  Rounds = the longest run of truly wrong segments (records longer than a segment).
+__global__ __launch_bounds__(256) void k_raw_fix(const uint8_t *u, uint64_t first, uint64_t n, uint64_t nseg, uint64_t *guess, uint64_t *leave, uint32_t *cnt, const uint8_t *bad_of, unsigned int *changed, unsigned int *broken) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg || s == 0 || !bad_of[s] || bad_of[s - 1]) return;
+    const uint64_t at = leave[s - 1];
+    if (at == ~0ull) return;
+    const uint64_t hi = min(n, first + s * RAW_SEG + RAW_SEG);
+    uint32_t c = 0; uint64_t x = at;
+    if (at < hi) { x = raw_walk(u, at, hi, n, c, nullptr); if (x == ~0ull) { *broken = 1u; return; } }
+    guess[s] = at; leave[s] = x; cnt[s] = c;
+    *changed = 1u;
+}
+// the last resort (after several parallel rounds): ONE thread follows the chain from segment to segment
+// and re-walks only the segments whose guess does not lie on it
+__global__ void k_raw_repair(const uint8_t *u, uint64_t first, uint64_t n, uint64_t nseg, uint64_t *guess, uint64_t *leave, uint32_t *cnt, unsigned int *broken) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t at = first;
+    for (uint64_t s = 0; s < nseg; s++) {
+        const uint64_t lo = first + s * RAW_SEG, hi = min(n, lo + RAW_SEG);
+        if (at >= hi) { guess[s] = at; leave[s] = at; cnt[s] = 0; continue; }       // a record spans the whole segment
+        if (guess[s] != at || leave[s] == ~0ull) {
+            uint32_t c = 0;
+            const uint64_t x = raw_walk(u, at, hi, n, c, nullptr);
+            if (x == ~0ull) { *broken = 1u; return; }
+            guess[s] = at; leave[s] = x; cnt[s] = c;
+        }
+        at = leave[s];
+    }
+    if (at != n) *broken = 1u;
+}
+__global__ __launch_bounds__(256) void k_raw_offsets(const uint8_t *u, uint64_t first, uint64_t n, uint64_t nseg, const uint64_t *guess, const uint64_t *base, uint64_t *rec_off) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const uint64_t hi = min(n, first + s * RAW_SEG + RAW_SEG);
+    uint32_t c = 0;
+    (void)raw_walk(u, guess[s], hi, n, c, rec_off + base[s]);
+}
+// bytes of an aux value behind its type byte, or ~0 (bamio.cpp aux_size)
+__device__ __forceinline__ uint64_t raw_aux_size(uint8_t type, const uint8_t *p, const uint8_t *end) {
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    case 'Z': case 'H': { const uint8_t *q = p; while (q < end && *q) q++; return q < end ? (uint64_t)(q - p) + 1 : ~0ull; }
+    case 'B': {
+        if (p + 5 > end) return ~0ull;
+        const uint8_t t = p[0];
+        const uint64_t es = (t == 'c' || t == 'C') ? 1 : (t == 's' || t == 'S') ? 2 : (t == 'i' || t == 'I' || t == 'f') ? 4 : ~0ull;
+        return es == ~0ull ? ~0ull : 5 + es * (uint64_t)rb32(p + 1);
+    }
+    default: return ~0ull;
+    }
+}
+struct RawSoA {
+    gce_core *core; uint64_t *qoff, *soff, *loff, *mioff; uint32_t *ncig, *nm_pos; int32_t *nm; uint8_t *nmt; unsigned int *have_mi;
+};
+// one thread per record: the 32-byte key record, the offsets of name / bases / qualities INSIDE the raw stream, NM (first match, value as
+// bam_aux2i gives it) and MI:Z from the aux area (bamio.cpp scan_aux), the place of NM's value byte for the writer
+__global__ __launch_bounds__(256) void k_raw_fill(const uint8_t *u, const uint64_t *rec_off, uint64_t n_rec, RawSoA o) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint64_t ro = rec_off[i];
+    const uint8_t *r = u + ro + 4; const uint32_t bs = rb32(u + ro);
+    union { gce_core c; uint32_t w[8]; uint4 q[2]; } t;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t.w[k] = rb32(r + 4 * k);
+    reinterpret_cast<uint4 *>(o.core + i)[0] = t.q[0]; reinterpret_cast<uint4 *>(o.core + i)[1] = t.q[1];
+    const uint32_t lq = t.c.l_qname, nc = t.c.n_cigar; const int32_t ls = t.c.l_qseq;
+    const uint64_t q0 = ro + 36, c0 = q0 + lq, s0 = c0 + 4ull * nc, l0 = s0 + (uint64_t)(ls + 1) / 2, a0 = l0 + (uint64_t)ls;
+    o.qoff[i] = q0; o.soff[i] = s0; o.loff[i] = l0; o.ncig[i] = nc;
+    uint8_t nmt = 0; int32_t nm = 0; uint32_t nm_pos = 0; uint64_t mi = ~0ull;
+    const uint8_t *p = u + a0, *end = r + bs;
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2]; const uint8_t *v = p + 3;
+        const uint64_t sz = raw_aux_size(ty, v, end);
+        if (sz == ~0ull || v + sz > end) break;
+        if (t0 == 'N' && t1 == 'M' && nmt == 0) {
+            nmt = ty; nm_pos = (uint32_t)(v - (u + ro));
+            switch (ty) {
+            case 'c': nm = (int8_t)v[0]; break;            case 'C': nm = v[0]; break;
+            case 's': nm = (int16_t)rb16(v); break;        case 'S': nm = (int32_t)rb16(v); break;
+            case 'i': nm = (int32_t)rb32(v); break;        case 'I': nm = (int32_t)rb32(v); break;
+            default: nm = 0; break;
+            }
+        } else if (t0 == 'M' && t1 == 'I' && ty == 'Z' && mi == ~0ull) mi = (uint64_t)(v - u);
+        p = v + sz;
+    }
+    o.nm[i] = nm; o.nmt[i] = nmt; o.nm_pos[i] = nm_pos; o.mioff[i] = mi;
+    if (mi != ~0ull && *(volatile unsigned int *)o.have_mi == 0u) atomicOr(o.have_mi, 1u);
+}
+__global__ __launch_bounds__(256) void k_raw_cigar(const uint8_t *u, const uint64_t *rec_off, uint64_t n_rec, const uint64_t *coff, uint32_t *cigar) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint8_t *r = u + rec_off[i] + 4;
+    const uint32_t lq = r[8], nc = rb16(r + 12);
+    const uint8_t *c = r + 32 + lq;
+    uint32_t *dst = cigar + coff[i];
+    for (uint32_t k = 0; k < nc; k++) dst[k] = rb32(c + 4 * k);
+}
+
+// ---- output records
+struct RawOut { const uint32_t *src, *qname_src; const int32_t *nm_new; const int16_t *fr, *rr; };
+__global__ __launch_bounds__(256) void k_rec_size(const uint8_t *u, const uint64_t *rec_off, RawOut r, uint64_t n_out, uint64_t *size) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const uint64_t so = rec_off[r.src[k]], qo = rec_off[r.qname_src[k]];
+    const uint32_t bs = rb32(u + so), lq_old = u[so + 12], lq_new = u[qo + 12];
+    size[k] = 4ull + bs - lq_old + lq_new + (r.fr[k] >= 0 ? 4 : 0) + (r.rr[k] >= 0 ? 4 : 0);
+}
+// 16 lanes per record: [block_size][core, l_qname of the name's source][that name][everything behind the name of the template's own record:
+// CIGAR, bases and qualities as the vote left them, aux][FR][RR]; NM's value byte patched (type 'C' only, checked by the vote)
+__global__ __launch_bounds__(256) void k_rec_build(const uint8_t *u, const uint64_t *rec_off, const uint32_t *nm_pos, RawOut r, uint64_t n_out, const uint64_t *roff, uint8_t *body) {
+    const int sub = threadIdx.x & 15;
+    for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; k < n_out; k += ((uint64_t)gridDim.x * blockDim.x) >> 4) {
+        const uint32_t src = r.src[k];
+        const uint64_t so = rec_off[src], qo = rec_off[r.qname_src[k]];
+        const uint32_t bs = rb32(u + so), lq_old = u[so + 12], lq_new = u[qo + 12];
+        const int fr = r.fr[k], rr = r.rr[k];
+        const uint32_t tail = bs - 32 - lq_old;                                    // CIGAR .. aux
+        const uint32_t nbs = 32 + lq_new + tail + (fr >= 0 ? 4 : 0) + (rr >= 0 ? 4 : 0);
+        uint8_t *d = body + roff[k];
+        if (sub < 9) {                                                             // block_size + the eight words of the core
+            uint32_t w = sub == 0 ? nbs : rb32(u + so + 4 * sub);
+            if (sub == 3) w = (w & ~0xFFu) | lq_new;                               // l_read_name is the low byte of the third core word
+            *(rb_u32u *)(d + 4 * sub) = w;
+        }
+        for (uint32_t j = sub; j < lq_new; j += 16) d[36 + j] = u[qo + 36 + j];
+        const uint8_t *ts = u + so + 36 + lq_old; uint8_t *td = d + 36 + lq_new;
+        for (uint32_t j = 4 * sub; j < tail; j += 64) {                            // four bytes per lane and trip
+            if (j + 4 <= tail) *(rb_u32u *)(td + j) = rb32(ts + j);
+            else for (uint32_t q = j; q < tail; q++) td[q] = ts[q];
+        }
+        if (sub == 15) {
+            uint8_t *e2 = td + tail;
+            if (fr >= 0) { e2[0] = 'F'; e2[1] = 'R'; e2[2] = 'C'; e2[3] = (uint8_t)fr; e2 += 4; }
+            if (rr >= 0) { e2[0] = 'R'; e2[1] = 'R'; e2[2] = 'C'; e2[3] = (uint8_t)rr; }
+        }
+    }
+}
+// (after k_rec_build: one more pass so that the NM patch cannot race with the copy of the same byte by another lane)
+__global__ __launch_bounds__(256) void k_rec_nm(const uint8_t *u, const uint64_t *rec_off, const uint32_t *nm_pos, RawOut r, uint64_t n_out, const uint64_t *roff, uint8_t *body) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out || r.nm_new[k] < 0) return;
+    const uint32_t src = r.src[k], np = nm_pos[src];
+    if (!np) return;
+    const uint64_t so = rec_off[src], qo = rec_off[r.qname_src[k]];
+    const uint32_t lq_old = u[so + 12], lq_new = u[qo + 12];
+    body[roff[k] + np - lq_old + lq_new] = (uint8_t)r.nm_new[k];                   // dataNM[1] = newValNM (group.cpp:570)
+}
+
+}  // namespace
+
+extern "C" {
+
+int gce_raw_begin(gce_engine *e, size_t capacity_hint) {
+    if (!e) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (e->processed || e->host_mode || e->device_mode) gce_reset(e);
+    if (!e->up_stream) HIPCHK(hipStreamCreate(&e->up_stream));
+    HIPCHK(e->raw.ensure(capacity_hint + 256));
+    {   // the per-record arrays, sized for the most records the stream can hold (a record with bases is > 96 bytes): allocated NOW, beside
+        // the host's first inflate, instead of in gce_raw_finish on the critical path (hipMalloc of gigabytes takes tens of milliseconds)
+        const size_t n1 = capacity_hint / 96 + 1024, nseg = capacity_hint / RAW_SEG + 16;
+        HIPCHK(e->rw_guess.ensure(nseg * 8)); HIPCHK(e->rw_leave.ensure(nseg * 8)); HIPCHK(e->rw_cnt.ensure(nseg * 4 + 8)); HIPCHK(e->rw_base.ensure(nseg * 8 + 8)); HIPCHK(e->rw_misc.ensure(64));
+        HIPCHK(e->rw_off.ensure((n1 + 1) * 8));
+        HIPCHK(e->b_core.ensure(n1 * sizeof(gce_core) + 64)); HIPCHK(e->b_qoff.ensure(n1 * 8 + 64)); HIPCHK(e->b_coff.ensure((n1 + 1) * 8 + 64)); HIPCHK(e->b_soff.ensure(n1 * 8 + 64)); HIPCHK(e->b_loff.ensure(n1 * 8 + 64));
+        HIPCHK(e->b_nm.ensure(n1 * 4 + 64)); HIPCHK(e->b_nmt.ensure(n1 + 64)); HIPCHK(e->b_mioff.ensure(n1 * 8 + 64)); HIPCHK(e->rw_ncig.ensure(n1 * 4 + 64)); HIPCHK(e->rw_nmpos.ensure(n1 * 4 + 64));
+        HIPCHK(e->b_cigar.ensure(n1 * 8 + 64));
+    }
+    e->raw_n = 0; e->raw_mode = true; e->raw_records = 0;
+    return GCE_OK;
+}
+
+// bytes of the inflated stream, in order.  Asynchronous: `host` (pinned memory makes it a real DMA) must stay untouched until gce_raw_wait(ticket).
+int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket) {
+    if (!e || !e->raw_mode || (!host && bytes)) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (e->raw_n + bytes + 256 > e->raw.cap) {                                     // grow: the copies so far are in flight on the same stream, the move queues behind them
+        DevBuf nb;
+        HIPCHK(nb.ensure((e->raw_n + bytes) * 2 + 256));
+        if (e->raw_n) HIPCHK(hipMemcpyAsync(nb.p, e->raw.p, e->raw_n, hipMemcpyDeviceToDevice, e->up_stream));
+        HIPCHK(hipStreamSynchronize(e->up_stream));
+        e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
+    }
+    if (bytes) HIPCHK(hipMemcpyAsync((char *)e->raw.p + e->raw_n, host, bytes, hipMemcpyHostToDevice, e->up_stream));
+    e->raw_n += bytes;
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, e->up_stream));
+    e->up_events.push_back(ev);
+    if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    return GCE_OK;
+}
+
+// The whole stream is in HBM: index the records behind `records_begin` (the end of the BAM header), build the batch.  Afterwards the engine is
+// in the state gce_submit_device leaves it in: gce_process, then gce_drain / gce_result_device or gce_raw_build_output.
+int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records) {
+    if (!e || !e->raw_mode || records_begin > e->raw_n) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    const bool tprint = getenv("GCE_RAW_TIMING") != nullptr; const auto tnow = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }; double tq = tnow();
+    auto lap = [&](const char *what) { if (tprint) { (void)hipStreamSynchronize(e->stream); const double x = tnow(); fprintf(stderr, "gce_raw_finish %s %.4f s\n", what, x - tq); tq = x; } };
+    HIPCHK(hipStreamSynchronize(e->up_stream));
+    lap("wait for the last copies");
+    for (auto ev : e->up_events) (void)hipEventDestroy(ev);
+    e->up_events.clear();
+    hipStream_t s = e->stream;
+    const uint8_t *u = e->raw.as<uint8_t>();
+    const uint64_t total = e->raw_n;
+    HIPCHK(hipMemsetAsync((char *)e->raw.p + total, 0, 64, s));                    // the blobs are readable 16 bytes past their end
+    uint64_t n_rec = 0;
+    if (total > records_begin) {
+        const uint64_t nseg = (total - records_begin + RAW_SEG - 1) / RAW_SEG;
+        HIPCHK(e->rw_guess.ensure(nseg * 8)); HIPCHK(e->rw_leave.ensure(nseg * 8)); HIPCHK(e->rw_cnt.ensure(nseg * 4 + 8)); HIPCHK(e->rw_base.ensure(nseg * 8 + 8)); HIPCHK(e->rw_misc.ensure(64)); HIPCHK(e->rw_bad.ensure(nseg + 8));
+        HIPCHK(hipMemsetAsync(e->rw_misc.p, 0, 64, s));
+        const unsigned nbs = (unsigned)((nseg + 255) / 256);
+        hipLaunchKernelGGL(k_raw_seg, dim3(nbs), dim3(256), 0, s, u, records_begin, total, n_ref, nseg, e->rw_guess.as<uint64_t>(), e->rw_leave.as<uint64_t>(), e->rw_cnt.as<uint32_t>());
+        hipLaunchKernelGGL(k_raw_check, dim3(nbs), dim3(256), 0, s, (const uint64_t *)e->rw_guess.p, (const uint64_t *)e->rw_leave.p, nseg, total, e->rw_misc.as<unsigned int>(), e->rw_bad.as<uint8_t>());
+        unsigned int flags[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(flags, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+        lap("segment walks + check");
+        if (tprint) fprintf(stderr, "gce_raw_finish: %u of %llu segments off the chain\n", flags[0], (unsigned long long)nseg);
+        if (tprint && flags[0]) {                                                       // which ones, and why
+            std::vector<uint64_t> g(nseg), l(nseg);
+            (void)hipMemcpy(g.data(), e->rw_guess.p, nseg * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(l.data(), e->rw_leave.p, nseg * 8, hipMemcpyDeviceToHost);
+            int shown = 0;
+            for (uint64_t q = 1; q < nseg && shown < 6; q++) if (l[q] == ~0ull || g[q] != l[q - 1]) { fprintf(stderr, "  segment %llu [%llu, +16K): guess %lld, chain enters at %lld, leaves %lld\n", (unsigned long long)q, (unsigned long long)(records_begin + q * RAW_SEG), (long long)g[q], (long long)l[q - 1], (long long)l[q]); shown++; }
+        }
+        for (int round = 0; flags[0] && round < 64; round++) {                           // parallel repair rounds
+            HIPCHK(hipMemsetAsync(e->rw_misc.p, 0, 16, s));
+            hipLaunchKernelGGL(k_raw_fix, dim3(nbs), dim3(256), 0, s, u, records_begin, total, nseg, e->rw_guess.as<uint64_t>(), e->rw_leave.as<uint64_t>(), e->rw_cnt.as<uint32_t>(), (const uint8_t *)e->rw_bad.p, e->rw_misc.as<unsigned int>() + 3, e->rw_misc.as<unsigned int>() + 1);
+            hipLaunchKernelGGL(k_raw_check, dim3(nbs), dim3(256), 0, s, (const uint64_t *)e->rw_guess.p, (const uint64_t *)e->rw_leave.p, nseg, total, e->rw_misc.as<unsigned int>(), e->rw_bad.as<uint8_t>());
+            HIPCHK(hipMemcpyAsync(flags, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            if (flags[1]) return fail(e, GCE_ERR_INVALID, "truncated or damaged BAM record stream");
+        }
+        lap("parallel repair");
+        if (flags[0]) {
+            HIPCHK(hipMemsetAsync(e->rw_misc.p, 0, 16, s));
+            hipLaunchKernelGGL(k_raw_repair, dim3(1), dim3(64), 0, s, u, records_begin, total, nseg, e->rw_guess.as<uint64_t>(), e->rw_leave.as<uint64_t>(), e->rw_cnt.as<uint32_t>(), e->rw_misc.as<unsigned int>() + 1);
+            HIPCHK(hipMemcpyAsync(flags, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            if (flags[1]) return fail(e, GCE_ERR_INVALID, "truncated or damaged BAM record stream");
+            lap("repair");
+        }
+        size_t tb = 0;                                                             // exclusive scan of the segments' record counts (rocPRIM through hipCUB)
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_cnt.as<uint32_t>(), hipcub::CastOp<uint64_t>()), e->rw_base.as<uint64_t>(), (int)(nseg + 1), s));
+        HIPCHK(e->rw_tmp.ensure(tb));
+        HIPCHK(hipMemsetAsync((char *)e->rw_cnt.p + nseg * 4, 0, 4, s));           // (one element past the end: the total comes out as base[nseg])
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_cnt.as<uint32_t>(), hipcub::CastOp<uint64_t>()), e->rw_base.as<uint64_t>(), (int)(nseg + 1), s));
+        HIPCHK(hipMemcpyAsync(&n_rec, e->rw_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+        if (n_rec >= 0x7FFFFFF0ull) return fail(e, GCE_ERR_INVALID, "more than 2^31 records in one stream");
+        lap("segments + scan");
+        HIPCHK(e->rw_off.ensure((size_t)(n_rec + 1) * 8));
+        hipLaunchKernelGGL(k_raw_offsets, dim3(nbs), dim3(256), 0, s, u, records_begin, total, nseg, (const uint64_t *)e->rw_guess.p, (const uint64_t *)e->rw_base.p, e->rw_off.as<uint64_t>());
+    }
+    const size_t n1 = (size_t)(n_rec ? n_rec : 1);
+    HIPCHK(e->b_core.ensure(n1 * sizeof(gce_core) + 64)); HIPCHK(e->b_qoff.ensure(n1 * 8 + 64)); HIPCHK(e->b_coff.ensure(n1 * 8 + 64)); HIPCHK(e->b_soff.ensure(n1 * 8 + 64)); HIPCHK(e->b_loff.ensure(n1 * 8 + 64));
+    HIPCHK(e->b_nm.ensure(n1 * 4 + 64)); HIPCHK(e->b_nmt.ensure(n1 + 64)); HIPCHK(e->b_mioff.ensure(n1 * 8 + 64)); HIPCHK(e->rw_ncig.ensure(n1 * 4 + 64)); HIPCHK(e->rw_nmpos.ensure(n1 * 4 + 64));
+    lap("offsets + allocations");
+    uint64_t cig_words = 0;
+    unsigned int have_mi = 0;
+    if (n_rec) {
+        RawSoA o{e->b_core.as<gce_core>(), e->b_qoff.as<uint64_t>(), e->b_soff.as<uint64_t>(), e->b_loff.as<uint64_t>(), e->b_mioff.as<uint64_t>(), e->rw_ncig.as<uint32_t>(), e->rw_nmpos.as<uint32_t>(),
+                 e->b_nm.as<int32_t>(), e->b_nmt.as<uint8_t>(), e->rw_misc.as<unsigned int>() + 2};
+        const unsigned nbr = (unsigned)((n_rec + 255) / 256);
+        hipLaunchKernelGGL(k_raw_fill, dim3(nbr), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, n_rec, o);
+        size_t tb = 0;
+        HIPCHK(hipMemsetAsync((char *)e->rw_ncig.p + n_rec * 4, 0, 4, s));
+        auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_ncig.as<uint32_t>(), hipcub::CastOp<uint64_t>());
+        HIPCHK(e->b_coff.ensure((n1 + 1) * 8 + 64));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, e->b_coff.as<uint64_t>(), (int)(n_rec + 1), s));
+        HIPCHK(e->rw_tmp.ensure(tb));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, it, e->b_coff.as<uint64_t>(), (int)(n_rec + 1), s));
+        HIPCHK(hipMemcpyAsync(&cig_words, e->b_coff.as<uint64_t>() + n_rec, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&have_mi, e->rw_misc.as<unsigned int>() + 2, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(e->b_cigar.ensure((size_t)cig_words * 4 + 64));
+        hipLaunchKernelGGL(k_raw_cigar, dim3(nbr), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, n_rec, (const uint64_t *)e->b_coff.p, e->b_cigar.as<uint32_t>());
+    } else HIPCHK(e->b_cigar.ensure(64));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    lap("fill + cigar");
+    gce_batch &d = e->dev_batch; memset(&d, 0, sizeof d);
+    d.n_reads = (int64_t)n_rec; d.core = e->b_core.as<gce_core>();
+    d.qname_off = e->b_qoff.as<uint64_t>(); d.qname = e->raw.as<char>(); d.cigar_off = e->b_coff.as<uint64_t>(); d.cigar = e->b_cigar.as<uint32_t>();
+    d.seq_off = e->b_soff.as<uint64_t>(); d.seq = e->raw.as<uint8_t>(); d.qual_off = e->b_loff.as<uint64_t>(); d.qual = e->raw.as<uint8_t>();
+    d.nm = e->b_nm.as<int32_t>(); d.nm_type = e->b_nmt.as<uint8_t>();
+    if (have_mi) { d.mi_off = e->b_mioff.as<uint64_t>(); d.mi = e->raw.as<char>(); d.mi_bytes = total; }
+    d.qname_bytes = total; d.cigar_words = cig_words; d.seq_bytes = total; d.qual_bytes = total;
+    e->device_mode = true; e->have_tick = false; e->raw_records = (int64_t)n_rec;
+    if (n_records) *n_records = (int64_t)n_rec;
+    return GCE_OK;
+}
+
+// after gce_process: the emitted records as a stream of BAM records in HBM, in the order of the output table
+int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out) {
+    if (!e || !e->raw_mode || !e->processed || e->dev_error || !body_bytes) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    hipStream_t s = e->stream;
+    const uint64_t no = (uint64_t)e->n_out;
+    *body_bytes = 0; if (n_out) *n_out = e->n_out;
+    if (!no) return GCE_OK;
+    HIPCHK(e->rw_rsize.ensure((no + 1) * 8)); HIPCHK(e->rw_roff.ensure((no + 1) * 8));
+    const uint8_t *u = e->raw.as<uint8_t>();
+    RawOut r{e->o_src.as<uint32_t>(), e->o_qsrc.as<uint32_t>(), e->o_nm.as<int32_t>(), e->o_fr.as<int16_t>(), e->o_rr.as<int16_t>()};
+    const unsigned nb = (unsigned)((no + 255) / 256);
+    hipLaunchKernelGGL(k_rec_size, dim3(nb), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, r, no, e->rw_rsize.as<uint64_t>());
+    HIPCHK(hipMemsetAsync((char *)e->rw_rsize.p + no * 8, 0, 8, s));
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, e->rw_rsize.as<uint64_t>(), e->rw_roff.as<uint64_t>(), (int)(no + 1), s));
+    HIPCHK(e->rw_tmp.ensure(tb));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, e->rw_rsize.as<uint64_t>(), e->rw_roff.as<uint64_t>(), (int)(no + 1), s));
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, e->rw_roff.as<uint64_t>() + no, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(e->rw_body.ensure(total + 64));
+    hipLaunchKernelGGL(k_rec_build, dim3((unsigned)std::min<uint64_t>((no + 15) / 16, 65535u)), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, (const uint32_t *)e->rw_nmpos.p, r, no, (const uint64_t *)e->rw_roff.p, e->rw_body.as<uint8_t>());
+    hipLaunchKernelGGL(k_rec_nm, dim3(nb), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, (const uint32_t *)e->rw_nmpos.p, r, no, (const uint64_t *)e->rw_roff.p, e->rw_body.as<uint8_t>());
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    e->raw_body_bytes = total;
+    *body_bytes = total;
+    return GCE_OK;
+}
+
+int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket) {
+    if (!e || !e->raw_mode || offset + bytes > e->raw_body_bytes || (!host && bytes)) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (bytes) HIPCHK(hipMemcpyAsync(host, (const char *)e->rw_body.p + offset, bytes, hipMemcpyDeviceToHost, e->up_stream));
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, e->up_stream));
+    e->up_events.push_back(ev);
+    if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    return GCE_OK;
+}
+
+// pinned host memory for the windows of the file path (the DMA engines copy from / to it without a staging copy)
+int gce_host_alloc(size_t bytes, void **out) { if (!out) return GCE_ERR_INVALID; return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? GCE_OK : GCE_ERR_OOM; }
+void gce_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+}  // extern "C"

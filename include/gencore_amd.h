@@ -369,13 +369,39 @@ typedef struct gce_bam_run {
     double  kernel_ms;       /* gce_timing.total_ms */
     double  drain_s, write_s, total_s;
     gce_stats pre, post;
+    int64_t peak_rss_kb;     /* VmHWM of the process when the run ended (the streaming path holds windows, not the file) */
+    int64_t rss_start_kb, rss_end_kb;   /* VmRSS when gce_run_bam was entered / left: the path's own footprint is the difference to the peak */
 } gce_bam_run;
-/* Replaces: Gencore::consensus() end to end for a coordinate-sorted BAM (src/gencore.cpp:162-293): open, (optional) reference,
- * chunks of `chunk_reads` records through gce_reserve / gce_submit_async, gce_process, gce_drain, gce_bam_write.
+/* Replaces: Gencore::consensus() end to end for a coordinate-sorted BAM (src/gencore.cpp:162-293) as a pipeline with a bounded host
+ * footprint: the file is read and inflated window by window (pinned buffers, copied to HBM while the next window is inflated), records
+ * are indexed, parsed and -- after gce_process -- re-assembled as BAM records on the GPU (gce_raw_*), the output stream is deflated by all
+ * host threads piece by piece.  chunk_reads < 65536 shrinks the windows to 1 MB of compressed bytes (tests).
  * params->n_targets / target_len are taken from the BAM header; params->umi_prefix "auto" is resolved on the first read
  * (src/gencore.cpp:207-220).  fasta_path may be NULL. */
 int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
                 int64_t chunk_reads, int level, gce_bam_run *out, char err[256]);
+/* The whole-file host-codec path of ABI v2 (gce_bam_open: everything inflated and indexed on the host, struct-of-arrays chunks, gce_bam_write);
+ * also what GCE_BAM_HOSTCODEC=1 makes gce_run_bam do. */
+int gce_run_bam_hostcodec(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                          int64_t chunk_reads, int level, gce_bam_run *out, char err[256]);
+
+/* The GPU side of the BAM codec (gencore_amd/csrc/gce_bamdev.hpp), the pieces gce_run_bam is made of.  Replaces sam_read1's record
+ * parsing and sam_write1's record assembly (src/gencore.cpp:205-274,83-111 via htslib) for a whole file at once; the host only inflates
+ * and deflates BGZF blocks.
+ *   gce_raw_begin / gce_raw_push: the INFLATED BAM stream (header included), in order, window by window; asynchronous (gce_submit_wait on
+ *     the ticket before the host buffer is reused; pinned buffers -- gce_host_alloc -- make the copies true DMA).
+ *   gce_raw_finish: records indexed and parsed in HBM (records_begin = end of the BAM header, n_ref = its contig count); the engine is then
+ *     in the state gce_submit_device leaves it in.  Names, bases and qualities are NOT copied: the batch's blobs are the raw stream.
+ *   gce_raw_build_output (after gce_process): the emitted records as a stream of BAM records in HBM, table order; gce_raw_read_output_async
+ *     copies a piece of it to the host (ticket -> gce_submit_wait). */
+int gce_raw_begin(gce_engine *e, size_t capacity_hint);
+int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket);
+int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records);
+int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
+int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
+int gce_host_alloc(size_t bytes, void **out);
+void gce_host_free(void *p);
+
 /* The same over SEVERAL engines, one per entry of `devices` (HIP ordinals; they may repeat): the stream is cut into n_shards ranges of the
  * cluster key by gce_stream_context + gce_plan_shards (plan_mode as there), every shard gets its reads, their global ticks, the flush
  * events and the reference window its reads touch; the engines run side by side, their tables are merged in bamComp order, the Stats
