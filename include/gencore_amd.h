@@ -220,7 +220,7 @@ int gce_set_reference_ascii(gce_engine *e, int32_t tid, const char *bases, int64
 /* Per-shard staging: only the bases [win_start, win_start + n_bases) of a contig of `contig_len` bases, e.g. what the
  * reads of one key-range shard can touch -- an engine for 1/8 of hg19 then holds 1/8 of the reference.  win_start must be even.
  * Reference::getData's end-of-contig rule (src/reference.cpp:40,60) keeps using contig_len.  gce_process fails with
- * GCE_ERR_INVALID ("reference window") if a clustered read whose isize != 0 does not lie inside the window of its contig. */
+ * GCE_ERR_REF_WINDOW if a clustered read whose isize != 0 does not lie inside the window of its contig. */
 int gce_set_reference_window(gce_engine *e, int32_t tid, int64_t contig_len, int64_t win_start, const char *bases, int64_t n_bases);
 /* Convenience: pack an upper-cased ASCII contig into that code on the host (src/fastareader.cpp:139). */
 void gce_pack_reference(const char *bases, int64_t n_bases, uint8_t *nibbles_out);

@@ -5,7 +5,7 @@
 #   3. separate --pmc passes for HBM traffic (FETCH_SIZE, WRITE_SIZE), kernel-trace only
 #   4. the end-to-end file path (tools/bam_bench.py)
 # Output: gpurun_out/<tag>_*   (copy the summaries into profiles/ afterwards: tools/prof_summary.py, hbm_summary.py, sq_summary.py)
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 600 python bench.py 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg3.json
 timeout 300 python bench.py --workload cfg2 --cpu-sample-pairs 1000000 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg2.json
