@@ -133,15 +133,16 @@ class GceError(RuntimeError):
 _lib = None
 
 
-def load_library(path=None):
-    """dlopen libgencore_amd.so; raises OSError if it has not been built (no fallback)."""
+def load_library(path=None, mode=C.RTLD_GLOBAL):
+    """dlopen libgencore_amd.so; raises OSError if it has not been built (no fallback).  mode=os.RTLD_LOCAL keeps several builds of the
+    library apart in one process (tools/vote_phases.py): under RTLD_GLOBAL the second build's kernels bind to the first one's."""
     global _lib
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("GCE_LIB") or LIB_PATH          # GCE_LIB: A/B another build of the same ABI (tools/ab.sh)
     if not os.path.exists(p):
         raise OSError("libgencore_amd.so not built at %s — run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
-    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(p, mode=mode)
     lib.gce_params_default.argtypes = [C.POINTER(GceParams)]
     lib.gce_params_default.restype = None
     lib.gce_detect_umi_prefix.argtypes = [C.c_char_p, C.c_char * 32]

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
     __shared__ uint8_t s_glp0[VB_MAXG + 1], s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng;
+    __shared__ uint32_t s_cnt[VB_SIDES];                                           // contested columns of a side, counted by pass A (NOT in the tally space: the tallies are cleared while other waves still read these)
     // P1 -> P3 only, in the (not yet used) tally space: contig of either read of a pair (the template's reference lookup); length of its
     // last CIGAR op if that is an M block (isPartOf from the right end); per side the masks of its reads / its single-M reads, the range of
     // their positions, the voters and "a read outside the scope was seen"; the group of every pair
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                 }
             }
         }
-        if (lane < VB_SIDES) s_hm[lane] = 0u;                                          // from here on: contested columns of the side, counted by pass A
+        if (lane < VB_SIDES) s_cnt[lane] = 0u;
         // a group goes on as a whole (all shuffles on wave-uniform paths)
         const int other_gen = __shfl_xor((int)to_gen, 1);                              // (unconditional: `a || shfl(..)` would shuffle in a divergent branch)
         const bool grp_gen = to_gen || other_gen != 0;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             {   // into the side's column mask, next to the columns P3 forced (complete by now); the side's count goes along
                 const uint32_t sh = 16u * (chunk & 1), forced = (s_cmask[s][chunk >> 1] >> sh) & colmask, tot = forced | contested;
                 if (contested & ~forced) atomicOr(&s_cmask[s][chunk >> 1], contested << sh);
-                if (tot) atomicAdd(&s_hm[s], (uint32_t)__popc(tot));
+                if (tot) atomicAdd(&s_cnt[s], (uint32_t)__popc(tot));
             }
         }
     }
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     //     prefixes over the sides: of the columns, and of the (voter, column) items
     if (tid < 64) {
         const bool act = lane < VB_SIDES && s_side[lane].state == VS_ACTIVE && s_gflag[s_side[lane].grp] == 0;
-        int cnt = act ? (int)s_hm[lane] : 0;
+        int cnt = act ? (int)s_cnt[lane] : 0;
         const int over = cnt > VB_SMAX, other_over = __shfl_xor(over, 1);
         if (over && lane < VB_SIDES) s_gflag[s_side[lane].grp] = 2;
         if (over || other_over || !act) cnt = 0;
@@ -495,8 +496,10 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     const int n_cont = s_cpre[VB_SIDES];
     // sides are voted in rounds of whole sides whose columns fit the tallies (usually one round)
     for (int s0 = 0; s0 < VB_SIDES;) {
-        int s1 = s0;
-        while (s1 < VB_SIDES && (int)s_cpre[s1 + 1] - (int)s_cpre[s0] <= VB_CCAP) s1++;          // sides [s0, s1) : a side has <= VB_SMAX columns
+        // sides [s0, s1): the longest run whose columns fit (a side has <= VB_SMAX of them).  One look per lane and a ballot -- the walk
+        // `while (s_cpre[s1 + 1] - s_cpre[s0] <= VB_CCAP) s1++` was 32 dependent LDS round trips in every wave of the block
+        const int fits_ = lane < VB_SIDES && (lane < s0 || (int)s_cpre[lane + 1] - (int)s_cpre[s0] <= VB_CCAP);
+        const int s1 = __ffsll((long long)~__ballot(fits_)) - 1;                                // first side that does not fit (prefixes ascend: every later one does not either); 32 if all do
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
