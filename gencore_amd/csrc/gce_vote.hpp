@@ -129,14 +129,21 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
 }
 
 // The same for the 64 consecutive items base + lane of a wave (all lanes must call it; items past `last` are clamped): the wave's first
-// item is placed by one ballot over the <= 32 prefix entries, every lane then walks on from there -- two or three steps, not five
-// dependent LDS round trips.
+// item is placed by one ballot over the <= 32 prefix entries, every lane then walks on from there FOUR entries per LDS round trip (the
+// entries ascend: those <= the item are a prefix of the four) -- a wave's items span two to ten sides, and one entry per trip made
+// the last lanes wait for as many dependent trips.
 __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base, int lane, int last) {
     last = max(last, 0);
     const int b0 = min(base, last), it = min(base + lane, last);
     const int pl = lane < n ? (int)pre[lane] : 0x7FFFFFFF;
     int s = __popcll(__ballot(pl <= b0)) - 1;
-    while (s + 1 < n && (int)pre[s + 1] <= it) s++;
+    for (;;) {
+        const int a1 = s + 1 < n ? (int)pre[s + 1] : 0x7FFFFFFF, a2 = s + 2 < n ? (int)pre[s + 2] : 0x7FFFFFFF;
+        const int a3 = s + 3 < n ? (int)pre[s + 3] : 0x7FFFFFFF, a4 = s + 4 < n ? (int)pre[s + 4] : 0x7FFFFFFF;
+        const int c = (a1 <= it) + (a2 <= it) + (a3 <= it) + (a4 <= it);
+        s += c;
+        if (c < 4) break;
+    }
     return s;
 }
 
@@ -159,8 +166,9 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ uint16_t s_jpre[VB_SIDES + 1];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
     __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
-    __shared__ uint8_t s_glp0[VB_MAXG + 1], s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
-    __shared__ int s_ng;
+    __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
+    __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
+    __shared__ int s_ng, s_np;
     __shared__ uint32_t s_cnt[VB_SIDES];                                           // contested columns of a side, counted by pass A (NOT in the tally space: the tallies are cleared while other waves still read these)
     // P1 -> P3 only, in the (not yet used) tally space: contig of either read of a pair (the template's reference lookup); length of its
     // last CIGAR op if that is an M block (isPartOf from the right end); per side the masks of its reads / its single-M reads, the range of
@@ -191,7 +199,8 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         int x = deep ? 0 : (int)np, pre = x;
         pre = wave_scan_incl(pre);
         if (in) { s_ggi[lane] = gi; s_gbeg[lane] = w.g_begin[gi]; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
-        if (lane == ng - 1) s_glp0[ng] = (uint8_t)pre;
+        if (lane == ng - 1) s_np = pre;
+        if (lane < VB_MAXG && !in) s_glp0[lane] = 127;                                 // (P1's bytewise search)
         if (lane == 0) s_ng = ng;
         if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
@@ -206,12 +215,18 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         if (k < VB_SIDES) { s_pmin[k] = 0x7FFFFFFF; s_pmax[k] = -0x7FFFFFFF; }
     }
     __syncthreads();
-    const int ng = s_ng, npairs = s_glp0[ng];
+    const int ng = s_ng, npairs = s_np;
     VB_TICK(0);
     // ---------------------------------------------------------------- P1: pairs -> read descriptors, overlap window
     if (tid < npairs) {
-        int j = 0;
-        while (j + 1 < ng && (int)s_glp0[j + 1] <= tid) j++;
+        // group of the pair = (number of groups that start at or in front of it) - 1: the 16 starts (< 127; unused entries hold 127) in one
+        // LDS load, compared bytewise -- (0x80 | tid) - start keeps bit 7 iff start <= tid, no borrow crosses a byte
+        int j;
+        {
+            const uint4 g4 = *reinterpret_cast<const uint4 *>(s_glp0);
+            const uint32_t tb = 0x80808080u | (0x01010101u * (uint32_t)tid);
+            j = __popc((tb - g4.x) & 0x80808080u) + __popc((tb - g4.y) & 0x80808080u) + __popc((tb - g4.z) & 0x80808080u) + __popc((tb - g4.w) & 0x80808080u) - 1;
+        }
         const uint32_t slot = s_gbeg[j] + (uint32_t)(tid - (int)s_glp0[j]);
         const uint32_t L = w.gpl[slot], R = w.gpr[slot];
         ReadDesc lk{}, rk{};
