@@ -63,7 +63,7 @@ enum : uint8_t { VS_FINAL = 0, VS_ACTIVE = 1, VS_GEN = 2, VS_RESTORE = 3 };
 struct __attribute__((aligned(8))) VSide {
     uint64_t ref; int64_t ref_len;
     uint32_t vmask, o_c0, result; int32_t o_pos, minc;
-    uint16_t len, item0; uint8_t tmpl, nvot, o_nc, state, grp, pad[3];
+    uint16_t len, item0; uint8_t tmpl, nvot, o_nc, state, grp, lp0, pad[2];     // lp0: the group's first pair in the batch (s_rd index)
 };
 
 typedef unsigned short vb_us2 __attribute__((ext_vector_type(2)));
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
     __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
-    __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index inside the group), ascending
+    __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index in the batch), ascending
     __shared__ __attribute__((aligned(8))) uint32_t s_tal[VB_CCAP][5][2];          // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
                                                                                    // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
     __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         const int j = lane >> 1, side = lane & 1;
         const bool mine = lane < 2 * ng && s_gflag[j] == 0;
         VSide sd; sd.ref = 0; sd.ref_len = 0; sd.vmask = 0; sd.o_c0 = 0; sd.result = NONE32; sd.o_pos = 0; sd.minc = 0; sd.len = 0; sd.item0 = 0;
-        sd.tmpl = 0; sd.nvot = 0; sd.o_nc = 0; sd.state = VS_FINAL; sd.grp = (uint8_t)j; sd.pad[0] = sd.pad[1] = sd.pad[2] = 0;
+        sd.tmpl = 0; sd.nvot = 0; sd.o_nc = 0; sd.state = VS_FINAL; sd.grp = (uint8_t)j; sd.lp0 = mine ? s_glp0[j] : 0; sd.pad[0] = sd.pad[1] = 0;
         bool to_gen = false;
         if (mine) {
             const int np = s_gnp[j], lp0 = s_glp0[j];
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             const uint32_t vm = s_side[2 * j + side].vmask;                             // (0 unless the side is active)
-            if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)k;
+            if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)tid;     // (the pair's index in the batch)
         }
     }
     VB_TICK(3);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
         if (it < n_items) {
             const VSide sd = s_side[s];
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
-            const VRead *rds = s_rd[s & 1] + s_glp0[sd.grp];
+            const VRead *rds = s_rd[s & 1] + sd.lp0;
             uint64_t sor = 0, sand = ~0ull; uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
             // four voters per step: their twelve 8-byte loads are issued before the first byte is looked at; a short last step repeats the
             // step's first voter -- OR, AND and max do not mind
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             x.ci = (int)s_cpre[s] + c; x.col = s_ccol[x.ci];
             const VSide *sd = &s_side[s];
             x.grp = sd->grp;
-            const int lp = s_glp0[sd->grp] + s_vlist[s][kv];
+            const int lp = s_vlist[s][kv];
             const VRead *r = &s_rd[x.side][lp];
             const VOv ov = s_ov[lp];
             const int mystart = x.side ? ov.rs : ov.ls;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
                 const int ro = sd.o_nc == 1 ? (col < cig_len(sd.o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[sd.result], sd.o_nc, col);
                 if (ro >= 0 && (int64_t)sd.o_pos + ro < sd.ref_len) ref4 = d_ref_nib((const uint8_t *)sd.ref, (int64_t)sd.o_pos + ro);
             }
-            const int out_base = d_nib(b.seq + s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl].so, col);
+            const int out_base = d_nib(b.seq + s_rd[s & 1][sd.lp0 + sd.tmpl].so, col);
             Tally5 t; t.total = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             if (sd.state == VS_RESTORE) {
                 any_restore = true;
                 const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16), side = s & 1;
-                const int lp = s_glp0[sd.grp] + sd.tmpl;
+                const int lp = sd.lp0 + sd.tmpl;
                 const VRead *r = &s_rd[side][lp], *mt = &s_rd[side ^ 1][lp];
                 const VOv ov = s_ov[lp];
                 const int mystart = side ? ov.rs : ov.ls;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
             const VSide sd = s_side[s];
             if (sd.state != VS_ACTIVE && sd.state != VS_RESTORE) continue;
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
-            const VRead *r = &s_rd[s & 1][s_glp0[sd.grp] + sd.tmpl];
+            const VRead *r = &s_rd[s & 1][sd.lp0 + sd.tmpl];
             uint8_t *oq = b.qual + r->qo + c16, *os = b.seq + r->so + 8 * chunk;
             uint64_t qlo = (uint64_t)keep[kk].x | ((uint64_t)keep[kk].y << 32), qhi = (uint64_t)keep[kk].z | ((uint64_t)keep[kk].w << 32);
             uint32_t cm = sd.state == VS_ACTIVE ? (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu : 0u;
