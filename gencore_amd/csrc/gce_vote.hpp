@@ -154,7 +154,8 @@ __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base
 #else
 #define VB_TICK(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+#define gb_ gb_
+__global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
@@ -191,20 +192,22 @@ __global__ __launch_bounds__(VB_T) void k_vote(DevBatch b, DevParams p, Work w, 
     // ---------------------------------------------------------------- P0: the groups of this batch
     if (tid < 64) {
         const uint32_t gi = g0 + (uint32_t)lane;
-        bool in = lane < VB_MAXG && gi < n_groups && w.g_wbase[gi] < (blockIdx.x + 1u) * VB_W;
-        uint32_t np = in ? w.g_np[gi] : 0u;
+        const bool maybe = lane < VB_MAXG && gi < n_groups;                            // (the three loads side by side: whether the group belongs to the batch only decides who uses them)
+        const uint32_t wb_ = maybe ? w.g_wbase[gi] : 0u, np_ = maybe ? w.g_np[gi] : 0u, gb_ = maybe ? w.g_begin[gi] : 0u;
+        bool in = maybe && wb_ < (blockIdx.x + 1u) * VB_W;
+        uint32_t np = in ? np_ : 0u;
         const bool deep = in && (np > 32u || (int)np > p.skip_low_complexity_thr || !p.vote_ok);
         const unsigned long long im = __ballot(in);
         const int ng = __popcll(im);                                                   // (groups of a batch are consecutive: im = low bits)
         int x = deep ? 0 : (int)np, pre = x;
         pre = wave_scan_incl(pre);
-        if (in) { s_ggi[lane] = gi; s_gbeg[lane] = w.g_begin[gi]; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
+        if (in) { s_ggi[lane] = gi; s_gbeg[lane] = gb_; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
         if (lane == ng - 1) s_np = pre;
         if (lane < VB_MAXG && !in) s_glp0[lane] = 127;                                 // (P1's bytewise search)
         if (lane == 0) s_ng = ng;
         if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
-            const uint32_t gb = w.g_begin[gi];
+            const uint32_t gb = gb_;
             for (uint32_t k = 0; k < np; k++) w.slot_flag[gb + k] = 1;
         }
     }
