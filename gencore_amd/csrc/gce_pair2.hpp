@@ -44,11 +44,13 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     }
     uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0;
+    const char *up = nullptr;
     if (live && n <= (uint32_t)SUB && hl < (int)n) {
         my = w.members[start + hl];
         nl = (int)b.core[my].l_qname - 1;
         nm = d_qname(b, my);
         ul = w.umi_len[my];
+        up = w.umi_ptr[my];                                 // (asked for with the name's place: where it is used it was two dependent round trips, pointer then bytes)
     }
     const uint32_t toolong = sub_ballot<SUB>(nl > 64 || ul > 24, hb);
     if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
@@ -65,6 +67,8 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
         nw[k] = v;
     }
+    uint64_t ruw[3];                                        // the UMI's bytes travel with the name's
+    load_be_words<3>(act ? up : nullptr, act ? ul : 0, ruw);
     // ---- name classes: 32-bit hash as a filter (verified word by word below)
     uint32_t h32 = 0x9E3779B9u;
 #pragma unroll
@@ -160,8 +164,6 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
     }
     const uint32_t pidx = __popc(LT);                       // distinct names before mine
-    uint64_t ruw[3];
-    load_be_words<3>(act2 ? w.umi_ptr[my] : nullptr, act2 ? ul : 0, ruw);
     {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty; the pair's current read is
         // the predecessor in arrival order = the largest read index among the same-name reads before mine
         uint32_t prev = act2 ? (EQ & LOW) : 0u;
