@@ -16,7 +16,9 @@
 #define DV_T 256                 // threads per block
 #define DV_COLS 512              // template columns per block
 #define DV_CHUNK 256             // voters staged per round
+#ifndef DV_UNROLL
 #define DV_UNROLL 4
+#endif
 #define DV_DONE 2                // gen_flag value: side finished here
 
 struct DVoter { uint64_t so, qo; int rl, ld; uint32_t patch, pad; };
@@ -88,6 +90,18 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
             const int lim = (int)min((uint32_t)DV_CHUNK, sp.nv - qb);
             for (int cb = 0; cb < len; cb += 256) {
                 const int c0 = cb + 4 * lane;
+                // Votes FOR the template's base -- all but the sequencing errors -- are tallied in registers, the lane's four columns side by side
+                // (counts in byte lanes, score / quality sums and top qualities in 16-bit lanes: a wave sees <= DV_CHUNK / 4 = 64 voters of a
+                // chunk, 64 x 255 fits), and reach the LDS tallies once per chunk; only a vote for another base is an LDS atomic of its own.
+                // One 64-bit atomic add + one atomic max per (voter, column) with their operand assembly and four branches were ~245
+                // VALU + ~210 SALU instructions per (voter, 256 columns).
+                uint32_t tb4 = 0;                                                      // the template's four bases, one per byte
+                if (c0 < len) {
+                    const uint32_t t2 = *(const u16_unaligned *)(b.seq + b.seq_off[rec.out] + (c0 >> 1));
+                    uint32_t x = ((t2 & 0x0F0Fu) << 4) | ((t2 & 0xF0F0u) >> 4);        // nibble i = column c0 + i
+                    x = (x | (x << 8)) & 0x00FF00FFu; tb4 = (x | (x << 4)) & 0x0F0F0F0Fu;
+                }
+                uint32_t C4 = 0, S02 = 0, S13 = 0, Q02 = 0, Q13 = 0, T02 = 0, T13 = 0;
                 for (int q0 = wv; q0 < lim; q0 += (DV_T / 64) * DV_UNROLL) {
                     uint32_t q4[DV_UNROLL], s4[DV_UNROLL], sc4[DV_UNROLL]; int rp0[DV_UNROLL]; bool on[DV_UNROLL], bytewise[DV_UNROLL];
 #pragma unroll
@@ -131,8 +145,12 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
                         const int nval = min(min(4, len - c0), v.rl - rp0[u]);
                         const uint32_t vm = nval >= 4 ? 0xFFFFFFFFu : (1u << (8 * nval)) - 1u;
                         if (q4[u] & 0x80808080u & vm) { s_exotic = 1; continue; }
-                        uint32_t sw = ((s4[u] & 0x0F0F0F0Fu) << 4) | ((s4[u] & 0xF0F0F0F0u) >> 4);      // nibble i of the word now at bits 4i
-                        sw >>= 4 * (rp0[u] & 1);
+                        uint32_t vb4;                                                      // the voter's four bases, one per byte
+                        {
+                            uint32_t x = ((s4[u] & 0x0F0F0F0Fu) << 4) | ((s4[u] & 0xF0F0F0F0u) >> 4);     // nibble i of the word now at bits 4i
+                            x = (x >> (4 * (rp0[u] & 1))) & 0xFFFFu;
+                            x = (x | (x << 8)) & 0x00FF00FFu; vb4 = (x | (x << 4)) & 0x0F0F0F0Fu;
+                        }
                         uint32_t sb4;                                                      // biased scores
                         if (v.patch == GCE_PATCH_CONST) sb4 = 0x01010101u * (uint32_t)(p.s_moderate + p.score_bias);
                         else {
@@ -145,18 +163,46 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
                                 sb4 = (sc4[u] & m) | (sb4 & ~m);
                             }
                         }
-                        const int slb = ((cb >> 2) + lane) & 127;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (j >= nval) continue;
-                            const uint32_t nib = (sw >> (4 * j)) & 15u;
-                            const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;       // A,C,G,T,N -> 0..4, anything else 7
-                            if (k == 7u) { s_exotic = 1; continue; }
-                            const uint32_t qu = (q4[u] >> (8 * j)) & 0xFFu, sb = (sb4 >> (8 * j)) & 0xFFu;
-                            const int sl = (j << 7) | slb;
-                            atomicAdd(&s_acc[k][sl], (unsigned long long)(1u | (sb << 16)) | ((unsigned long long)(qu << 8) << 32));
-                            atomicMax(&s_tq[k][sl], qu);
+                        // bytes whose base is the template's (bases are < 16: + 15 reaches bit 4 iff they differ)
+                        const uint32_t ne = (((vb4 ^ tb4) + 0x0F0F0F0Fu) >> 4) & 0x01010101u, eq1 = (ne ^ 0x01010101u) & vm;
+                        const uint32_t m4 = (eq1 << 8) - eq1;
+                        const uint32_t qm = q4[u] & m4, sm = sb4 & m4, qa = qm & 0x00FF00FFu, qb2 = (qm >> 8) & 0x00FF00FFu;
+                        C4 += eq1;
+                        S02 += sm & 0x00FF00FFu; S13 += (sm >> 8) & 0x00FF00FFu;
+                        Q02 += qa; Q13 += qb2;
+                        T02 = pk_max_u16(T02, qa); T13 = pk_max_u16(T13, qb2);
+                        uint32_t rest = vm & ~m4 & 0x01010101u;                           // votes for another base: bit 8 j
+                        if (rest) {
+                            const int slb = ((cb >> 2) + lane) & 127;
+                            do {
+                                const int j = (__ffs((int)rest) - 1) >> 3;
+                                rest &= rest - 1;
+                                const uint32_t nib = (vb4 >> (8 * j)) & 15u;
+                                const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;       // A,C,G,T,N -> 0..4, anything else 7
+                                if (k == 7u) { s_exotic = 1; continue; }
+                                const uint32_t qu = (q4[u] >> (8 * j)) & 0xFFu, sb = (sb4 >> (8 * j)) & 0xFFu;
+                                const int sl = (j << 7) | slb;
+                                atomicAdd(&s_acc[k][sl], (unsigned long long)(1u | (sb << 16)) | ((unsigned long long)(qu << 8) << 32));
+                                atomicMax(&s_tq[k][sl], qu);
+                            } while (rest);
                         }
+                    }
+                }
+                // the lane's register tallies -> the template base's bins (a template base outside A,C,G,T,N: the template votes for itself, exotic)
+                if (c0 < len && C4 != 0u) {
+                    const int slb = ((cb >> 2) + lane) & 127;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t cnt = (C4 >> (8 * j)) & 0xFFu;
+                        if (cnt == 0u) continue;
+                        const uint32_t nib = (tb4 >> (8 * j)) & 15u;
+                        const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;
+                        if (k == 7u) { s_exotic = 1; continue; }
+                        const uint32_t ss = ((j & 1) ? S13 : S02) >> (16 * (j >> 1)) & 0xFFFFu, qs = ((j & 1) ? Q13 : Q02) >> (16 * (j >> 1)) & 0xFFFFu;
+                        const uint32_t tq = ((j & 1) ? T13 : T02) >> (16 * (j >> 1)) & 0xFFFFu;
+                        const int sl = (j << 7) | slb;
+                        atomicAdd(&s_acc[k][sl], (unsigned long long)(cnt | (ss << 16)) | ((unsigned long long)(qs << 8) << 32));
+                        atomicMax(&s_tq[k][sl], tq);
                     }
                 }
             }

@@ -763,32 +763,63 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     // registers instead of O(reads^2) walks through memory.  One class per lane (<= 64), CIGARs of <= 4 ops; anything else
     // takes the pairwise loop below.
     bool classed = false, lowc_done = false;
+    int lr_lq = 0, lr_pos = 0; uint32_t lr_rd = NONE32;                          // (of the last load_read: read length, position, read)
+    auto load_read = [&](uint32_t k, bool &has, int &n_, int &rr_, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
+        has = false; n_ = 0; rr_ = 0; w0 = w1 = w2 = w3 = 0; lr_rd = NONE32;
+        uint32_t rd = k < np ? side[begin + k] : NONE32;
+        if (rd == NONE32) return;
+        has = true;
+        const ReadDesc d = load_desc(w.rdesc, rd);
+        lr_lq = d.lq; lr_pos = d.pos; lr_rd = rd;
+        n_ = d.nc; rr_ = is_left ? 0 : d.pos + (d.rlen != RLEN_WALK ? d.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], d.nc));
+        if (n_ == 1) w0 = d.c0;
+        else if (n_ >= 2 && n_ <= 4) {                                     // oriented: i-th op from the compared end (bamutil.cpp:213-218)
+            const uint32_t *cg = b.cigar + b.cigar_off[rd];
+            w0 = left_mode ? cg[0] : cg[n_ - 1]; w1 = left_mode ? cg[1] : cg[n_ - 2];
+            if (n_ >= 3) w2 = left_mode ? cg[2] : cg[n_ - 3];
+            if (n_ >= 4) w3 = left_mode ? cg[3] : cg[0];
+        }
+    };
+    auto part_of4 = [&](int pn, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int wn, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+        if (wn < pn) return false;                                      // BamUtil::isPartOf (bamutil.cpp:204-255) on oriented words
+        const uint32_t pw[4] = {p0, p1, p2, p3}, ww[4] = {q0, q1, q2, q3};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < pn) {
+                if (cig_op(pw[i]) != cig_op(ww[i])) return false;
+                const int la = cig_len(pw[i]), lb = cig_len(ww[i]);
+                if (la > lb) return false;
+                if (la < lb && i != pn - 1) {
+                    if (i != pn - 2) return false;
+                    if (cig_op(pw[i + 1 < 4 ? i + 1 : 3]) != 5 /*H*/) return false;
+                }
+            }
+        }
+        return true;
+    };
     uint32_t first_read = NONE32;                  // firstRead of group.cpp:145-160: the side's first present read
     if (np > 64) {
         int c_n = 0, c_cnt = 0, c_rr = 0; uint32_t c_w0 = 0, c_w1 = 0, c_w2 = 0, c_w3 = 0;      // lane c = class c
         int nclass = 0; bool fail = false;
-        auto load_read = [&](uint32_t k, bool &has, int &n_, int &rr_, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
-            has = false; n_ = 0; rr_ = 0; w0 = w1 = w2 = w3 = 0;
-            uint32_t rd = k < np ? side[begin + k] : NONE32;
-            if (rd == NONE32) return;
-            has = true;
-            const ReadDesc d = load_desc(w.rdesc, rd);
-            n_ = d.nc; rr_ = is_left ? 0 : d.pos + (d.rlen != RLEN_WALK ? d.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], d.nc));
-            if (n_ == 1) w0 = d.c0;
-            else if (n_ >= 2 && n_ <= 4) {                                     // oriented: i-th op from the compared end (bamutil.cpp:213-218)
-                const uint32_t *cg = b.cigar + b.cigar_off[rd];
-                w0 = left_mode ? cg[0] : cg[n_ - 1]; w1 = left_mode ? cg[1] : cg[n_ - 2];
-                if (n_ >= 3) w2 = left_mode ? cg[2] : cg[n_ - 3];
-                if (n_ >= 4) w3 = left_mode ? cg[3] : cg[0];
-            }
-        };
         for (uint32_t base = 0; base < np && !fail; base += 64) {
             bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
             load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
             if (__any(has && n_ > 4)) { fail = true; break; }
             const unsigned long long hm = __ballot(has);
             if (first_read == NONE32 && hm) first_read = side[begin + base + (__ffsll((long long)hm) - 1)];
-            for (unsigned long long m = hm; m; m &= m - 1) {
+            // against the classes known so far: all reads of the batch at once, one broadcast per CLASS (a read at a time -- 64 rounds of six
+            // broadcasts and a ballot per batch -- was most of this kernel's instruction stream: a deep side has a handful of classes)
+            bool placed = !has;
+            for (int cc = 0; cc < nclass; cc++) {
+                const int q_n = rl32(c_n, cc), q_rr = rl32(c_rr, cc);
+                const uint32_t q0 = (uint32_t)rl32((int)c_w0, cc), q1 = (uint32_t)rl32((int)c_w1, cc), q2 = (uint32_t)rl32((int)c_w2, cc), q3 = (uint32_t)rl32((int)c_w3, cc);
+                const bool eq = !placed && n_ == q_n && rr_ == q_rr && w0 == q0 && w1 == q1 && w2 == q2 && w3 == q3;
+                const unsigned long long hit = __ballot(eq);
+                if (lane == cc) c_cnt += __popcll(hit);
+                placed |= eq;
+            }
+            // reads of a class not seen before, one at a time (a later one may belong to the class an earlier one opens)
+            for (unsigned long long m = __ballot(!placed); m; m &= m - 1) {
                 const int t = __ffsll((long long)m) - 1;
                 const int r_n = rl32(n_, t), r_rr = rl32(rr_, t);
                 const uint32_t r0 = (uint32_t)rl32((int)w0, t), r1 = (uint32_t)rl32((int)w1, t), r2 = (uint32_t)rl32((int)w2, t), r3 = (uint32_t)rl32((int)w3, t);
@@ -821,23 +852,6 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
             }
         }
         if (!fail) {
-            auto part_of4 = [&](int pn, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int wn, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
-                if (wn < pn) return false;                                      // BamUtil::isPartOf (bamutil.cpp:204-255) on oriented words
-                const uint32_t pw[4] = {p0, p1, p2, p3}, ww[4] = {q0, q1, q2, q3};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (i < pn) {
-                        if (cig_op(pw[i]) != cig_op(ww[i])) return false;
-                        const int la = cig_len(pw[i]), lb = cig_len(ww[i]);
-                        if (la > lb) return false;
-                        if (la < lb && i != pn - 1) {
-                            if (i != pn - 2) return false;
-                            if (cig_op(pw[i + 1 < 4 ? i + 1 : 3]) != 5 /*H*/) return false;
-                        }
-                    }
-                }
-                return true;
-            };
             for (uint32_t base = 0; base < np; base += 64) {
                 bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
                 load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
@@ -938,6 +952,27 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     WAVE_SYNC();
     uint32_t nv = 1;
     if (lane == 0) { voters[begin] = out; vld[begin] = 0; }
+    if (classed) {
+        // the classes' reads have <= 4 CIGAR ops: isPartOf on the oriented words in registers (as containedBy above), length and position
+        // from the descriptor -- not a gather of the alignment record and two CIGAR walks through memory per read
+        bool t_has; int t_n, t_rr; uint32_t t0, t1, t2, t3;
+        load_read(best, t_has, t_n, t_rr, t0, t1, t2, t3);                      // (every lane: the template)
+        for (uint32_t base = 0; base < np; base += 64) {
+            const uint32_t j = base + lane;
+            bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
+            load_read(j, has, n_, rr_, w0, w1, w2, w3);
+            const uint32_t rd = lr_rd;
+            bool take = has && j != best && part_of4(t_n, t0, t1, t2, t3, n_, w0, w1, w2, w3);
+            int ld = 0;
+            if (take) {
+                ld = lr_lq - ok.l_qseq;
+                if (ld != 0 && lr_pos == ok.pos && (left_mode || d_is_part_of(ocig, ok.n_cigar, b.cigar + b.cigar_off[rd], n_, true))) ld = 0;
+            }
+            const unsigned long long m = __ballot(take);
+            if (take) { const uint32_t d = begin + nv + lanes_below(m); voters[d] = rd; vld[d] = (uint32_t)ld; }
+            nv += __popcll(m);
+        }
+    } else
     for (uint32_t base = 0; base < np; base += 64) {
         uint32_t j = base + lane;
         bool take = false; uint32_t rd = NONE32; int ld = 0;
