@@ -686,7 +686,7 @@ int gce_process(gce_engine *e) {
         }
         hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
-        hipLaunchKernelGGL(k_vote_deep, dim3(2048), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
+        hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);

@@ -17,15 +17,15 @@
 #define DV_COLS 512              // template columns per block
 #define DV_CHUNK 256             // voters staged per round
 #ifndef DV_UNROLL
-#define DV_UNROLL 4
+#define DV_UNROLL 2          // rows of four voters in flight per wave
 #endif
 #define DV_DONE 2                // gen_flag value: side finished here
 
 struct DVoter { uint64_t so, qo; int rl, ld; uint32_t patch, pad; };
 
-// column -> LDS slot: the four columns of a lane go to four different 64-slot groups, so that one atomic instruction of a wave
-// (one column j of every lane) touches consecutive slots
-__device__ __forceinline__ int dv_slot(int col) { return ((col & 3) << 7) | ((col >> 2) & 127); }        // DV_COLS = 512: 4 x 128
+// column -> LDS slot: a lane owns 16 adjacent columns, so one atomic instruction of a wave touches columns 16 apart: column j of every
+// 16-column run goes to the j-th group of 32 slots (DV_COLS = 512 = 16 x 32), and the lanes land on consecutive slots
+__device__ __forceinline__ int dv_slot(int col) { return ((col & 15) << 5) | (col >> 4); }
 
 struct DeepRec { uint32_t e, out, nv, len_mode; };      // len | left_mode << 16
 
@@ -34,7 +34,12 @@ struct DeepRec { uint32_t e, out, nv, len_mode; };      // len | left_mode << 16
 __global__ __launch_bounds__(256) void k_deep_prepare(DevBatch b, DevParams p, Work w) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n_slow = (uint32_t)w.si->n_slow;
-    for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
+    // sides differ by two orders of magnitude in size: a wave draws its next one when it is done (a fixed stride gave a few waves three big ones)
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&w.si->prep_next, 1u);
+        idx = (uint32_t)__shfl((int)idx, 0);
+        if (idx >= n_slow) break;
         const uint32_t e = w.slow_list[idx], gi = e >> 1; const bool is_left = !(e & 1);
         const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
         if (np <= 64) continue;                                                   // here for another reason (exotic bases, long reads)
@@ -50,6 +55,11 @@ __global__ __launch_bounds__(256) void k_deep_prepare(DevBatch b, DevParams p, W
     }
 }
 
+#ifdef DV_PROF               // per-phase block time of k_vote_deep into the k_vote slots (build with -DVB_PROF -DDV_PROF): 0 setup, 1 staging, 2 votes, 3 flush, 4 decide, 5 write-back
+#define DV_TICK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - dv_prev_); dv_prev_ = now_; } } while (0)
+#else
+#define DV_TICK(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Work w) {
     __shared__ unsigned long long s_acc[5][DV_COLS];      // count (16) | biased score sum (24) << 16 | quality sum (24) << 40
     __shared__ uint32_t s_tq[5][DV_COLS];
@@ -57,12 +67,23 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
     __shared__ uint8_t s_nb[DV_COLS], s_nq[DV_COLS];
     __shared__ int s_minc, s_exotic;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ uint32_t s_next;
     const uint32_t n_deep = w.si->n_deep;
-    for (uint32_t idx = blockIdx.x; idx < n_deep; idx += gridDim.x) {
+    // a block draws its next side when it is done with one, from the END of the list: k_deep_prepare appends a side when it is prepared, the big ones last
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next = atomicAdd(&w.si->deep_next, 1u);
+        __syncthreads();
+        if (s_next >= n_deep) break;
+        const uint32_t idx = n_deep - 1u - s_next;
         const DeepRec rec = ((const DeepRec *)w.deep_list)[idx];
         const uint32_t e = rec.e, gi = e >> 1; const bool is_left = !(e & 1);
         const uint32_t begin = w.g_begin[gi];
         __syncthreads();
+#ifdef DV_PROF
+        unsigned long long dv_prev_ = wall_clock64();
+        if (threadIdx.x == 0) atomicAdd(&w.si->prof[15], 1ull);
+#endif
         for (int k = tid; k < 5 * DV_COLS; k += DV_T) { (&s_acc[0][0])[k] = 0ull; (&s_tq[0][0])[k] = 0u; }
         if (tid == 0) { s_minc = 0; s_exotic = 0; }
         SidePrep sp; sp.out = rec.out; sp.nv = rec.nv; sp.len = (int)(rec.len_mode & 0xFFFFu); sp.left_mode = (rec.len_mode >> 16) & 1u;
@@ -78,7 +99,18 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
         }
         uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
         const int len = sp.len;
-        // ---- votes
+        // ---- votes.  A lane takes SIXTEEN adjacent columns of a voter (two 8-byte quality loads, one 8-byte load of packed bases + the byte behind
+        //      it for an odd start, two 8-byte score loads inside a mate-overlap patch), a wave four voters side by side (sub = lane / 16) and
+        //      DV_UNROLL such rows in flight; the four waves interleave rows.  Votes FOR the template's base -- all but the sequencing errors --
+        //      are tallied in registers, four columns per 32-bit word (counts in byte lanes; score / quality sums and top qualities in 16-bit
+        //      lanes: a lane sees DV_CHUNK / 16 = 16 voters per chunk), and reach the LDS tallies once per chunk; only a vote for another base
+        //      is an LDS atomic of its own.  Four columns per lane (round 2) spent ~125 VALU + ~100 SALU instructions per voter and wave on
+        //      what is per-voter bookkeeping: descriptor, bounds, patch window, addresses.
+        DV_TICK(0);
+        const int sub = lane >> 4, ch = lane & 15;
+        const uint8_t *tseq = b.seq + b.seq_off[rec.out];
+        auto spread4 = [](uint32_t n16) { uint32_t x = n16 & 0xFFFFu; x = (x | (x << 8)) & 0x00FF00FFu; return (x | (x << 4)) & 0x0F0F0F0Fu; };   // nibble i -> byte i
+        auto nib_order = [](uint64_t x) { return ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full); };                        // column i of the word at bits 4 i
         for (uint32_t qb = 0; qb < sp.nv; qb += DV_CHUNK) {
             __syncthreads();
             if (qb + tid < sp.nv) {
@@ -87,124 +119,131 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
                 s_v[tid] = v;
             }
             __syncthreads();
+            DV_TICK(1);
             const int lim = (int)min((uint32_t)DV_CHUNK, sp.nv - qb);
             for (int cb = 0; cb < len; cb += 256) {
-                const int c0 = cb + 4 * lane;
-                // Votes FOR the template's base -- all but the sequencing errors -- are tallied in registers, the lane's four columns side by side
-                // (counts in byte lanes, score / quality sums and top qualities in 16-bit lanes: a wave sees <= DV_CHUNK / 4 = 64 voters of a
-                // chunk, 64 x 255 fits), and reach the LDS tallies once per chunk; only a vote for another base is an LDS atomic of its own.
-                // One 64-bit atomic add + one atomic max per (voter, column) with their operand assembly and four branches were ~245
-                // VALU + ~210 SALU instructions per (voter, 256 columns).
-                uint32_t tb4 = 0;                                                      // the template's four bases, one per byte
+                const int c0 = cb + 16 * ch;
+                uint32_t tb[4] = {0, 0, 0, 0};                                          // the template's bases, one per byte
                 if (c0 < len) {
-                    const uint32_t t2 = *(const u16_unaligned *)(b.seq + b.seq_off[rec.out] + (c0 >> 1));
-                    uint32_t x = ((t2 & 0x0F0Fu) << 4) | ((t2 & 0xF0F0u) >> 4);        // nibble i = column c0 + i
-                    x = (x | (x << 8)) & 0x00FF00FFu; tb4 = (x | (x << 4)) & 0x0F0F0F0Fu;
+                    const uint64_t y = nib_order(*(const u64_unaligned *)(tseq + (c0 >> 1)));
+#pragma unroll
+                    for (int g = 0; g < 4; g++) tb[g] = spread4((uint32_t)(y >> (16 * g)));
                 }
-                uint32_t C4 = 0, S02 = 0, S13 = 0, Q02 = 0, Q13 = 0, T02 = 0, T13 = 0;
-                for (int q0 = wv; q0 < lim; q0 += (DV_T / 64) * DV_UNROLL) {
-                    uint32_t q4[DV_UNROLL], s4[DV_UNROLL], sc4[DV_UNROLL]; int rp0[DV_UNROLL]; bool on[DV_UNROLL], bytewise[DV_UNROLL];
+                uint32_t C4[4] = {0, 0, 0, 0}, S02[4] = {0, 0, 0, 0}, S13[4] = {0, 0, 0, 0}, Q02[4] = {0, 0, 0, 0}, Q13[4] = {0, 0, 0, 0}, T02[4] = {0, 0, 0, 0}, T13[4] = {0, 0, 0, 0};
+                for (int qr = 4 * wv; qr < lim; qr += 4 * (DV_T / 64) * DV_UNROLL) {     // (wave-uniform trips)
+                    uint64_t qa[DV_UNROLL], qc[DV_UNROLL], sq[DV_UNROLL], sa[DV_UNROLL], sc[DV_UNROLL]; uint32_t s9[DV_UNROLL];
+                    int rp0[DV_UNROLL]; bool on[DV_UNROLL], bytewise[DV_UNROLL], patched[DV_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DV_UNROLL; u++) {
-                        const int q = q0 + u * (DV_T / 64);
-                        on[u] = q < lim && c0 < len; bytewise[u] = false; q4[u] = s4[u] = sc4[u] = 0; rp0[u] = 0;
+                        const int q = qr + 4 * (DV_T / 64) * u + sub;
+                        on[u] = q < lim && c0 < len; bytewise[u] = false; patched[u] = false; qa[u] = qc[u] = sq[u] = sa[u] = sc[u] = 0; s9[u] = 0; rp0[u] = 0;
                         if (on[u]) {
                             const DVoter v = s_v[q];
                             rp0[u] = sp.left_mode ? c0 : c0 + v.ld;
-                            if (rp0[u] + 4 <= 0 || rp0[u] >= v.rl) on[u] = false;        // no column of this lane meets the read
+                            if (rp0[u] + 16 <= 0 || rp0[u] >= v.rl) on[u] = false;       // no column of this lane meets the read
                             else if (rp0[u] < 0) bytewise[u] = true;                     // (the first lane of a shorter right-aligned voter)
                             else {
-                                q4[u] = *(const u32_unaligned *)(b.qual + v.qo + rp0[u]);
-                                s4[u] = *(const u32_unaligned *)(b.seq + v.so + (rp0[u] >> 1));
+                                const uint8_t *qp = b.qual + v.qo + rp0[u], *sp_ = b.seq + v.so + (rp0[u] >> 1);
+                                qa[u] = *(const u64_unaligned *)qp; qc[u] = *(const u64_unaligned *)(qp + 8);
+                                sq[u] = *(const u64_unaligned *)sp_; s9[u] = sp_[8];
                                 const uint32_t pt = v.patch;
-                                if (pt != GCE_PATCH_CONST && pt != 0u && rp0[u] < (int)((pt & 0xFFFF) + (pt >> 16)) && rp0[u] + 4 > (int)(pt & 0xFFFF))
-                                    sc4[u] = *(const u32_unaligned *)((const uint8_t *)w.score + v.qo + rp0[u]);
+                                if (pt != GCE_PATCH_CONST && pt != 0u && rp0[u] < (int)((pt & 0xFFFF) + (pt >> 16)) && rp0[u] + 16 > (int)(pt & 0xFFFF)) {
+                                    const uint8_t *cp = (const uint8_t *)w.score + v.qo + rp0[u];
+                                    sa[u] = *(const u64_unaligned *)cp; sc[u] = *(const u64_unaligned *)(cp + 8); patched[u] = true;
+                                }
                             }
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < DV_UNROLL; u++) {
                         if (!on[u]) continue;
-                        const int q = q0 + u * (DV_T / 64);
+                        const int q = qr + 4 * (DV_T / 64) * u + sub;
                         const DVoter v = s_v[q];
                         if (bytewise[u]) {
-                            for (int j = 0; j < 4; j++) {
+                            for (int j = 0; j < 16; j++) {
                                 const int col = c0 + j, rp = rp0[u] + j;
                                 if (col >= len || rp < 0 || rp >= v.rl) continue;        // outside the voter: UB in the reference, skipped (as the oracle)
                                 const int nib = d_nib(b.seq + v.so, rp), qu = b.qual[v.qo + rp];
-                                const int sc = d_score_at(p, w.score + v.qo, v.patch, rp, qu);
+                                const int scv = d_score_at(p, w.score + v.qo, v.patch, rp, qu);
                                 const int k = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : nib == 15 ? 4 : -1;
                                 if (k < 0 || qu >= 128) { s_exotic = 1; continue; }
                                 const int sl = dv_slot(col);
-                                atomicAdd(&s_acc[k][sl], 1ull | ((unsigned long long)(unsigned)(sc + p.score_bias) << 16) | ((unsigned long long)(unsigned)qu << 40));
+                                atomicAdd(&s_acc[k][sl], 1ull | ((unsigned long long)(unsigned)(scv + p.score_bias) << 16) | ((unsigned long long)(unsigned)qu << 40));
                                 atomicMax(&s_tq[k][sl], (uint32_t)qu);
                             }
                             continue;
                         }
-                        // four columns at once: valid ones are j < nval (rp0 >= 0 here)
-                        const int nval = min(min(4, len - c0), v.rl - rp0[u]);
-                        const uint32_t vm = nval >= 4 ? 0xFFFFFFFFu : (1u << (8 * nval)) - 1u;
-                        if (q4[u] & 0x80808080u & vm) { s_exotic = 1; continue; }
-                        uint32_t vb4;                                                      // the voter's four bases, one per byte
-                        {
-                            uint32_t x = ((s4[u] & 0x0F0F0F0Fu) << 4) | ((s4[u] & 0xF0F0F0F0u) >> 4);     // nibble i of the word now at bits 4i
-                            x = (x >> (4 * (rp0[u] & 1))) & 0xFFFFu;
-                            x = (x | (x << 8)) & 0x00FF00FFu; vb4 = (x | (x << 4)) & 0x0F0F0F0Fu;
-                        }
-                        uint32_t sb4;                                                      // biased scores
-                        if (v.patch == GCE_PATCH_CONST) sb4 = 0x01010101u * (uint32_t)(p.s_moderate + p.score_bias);
-                        else {
-                            sb4 = d_q2s4_biased(p, q4[u] & 0x7F7F7F7Fu);
-                            const int ws = (int)(v.patch & 0xFFFF), wl = (int)(v.patch >> 16);
-                            if (v.patch != 0u && rp0[u] < ws + wl && rp0[u] + 4 > ws) {
-                                uint32_t m = 0;
+                        const int nval = min(min(16, len - c0), v.rl - rp0[u]);              // valid columns are j < nval (rp0 >= 0 here)
+                        uint64_t y = nib_order(sq[u]);
+                        if (rp0[u] & 1) y = (y >> 4) | ((uint64_t)(s9[u] >> 4) << 60);
+                        const bool cst = v.patch == GCE_PATCH_CONST;
+                        const int ws = (int)(v.patch & 0xFFFF), wl = (int)(v.patch >> 16);
 #pragma unroll
-                                for (int j = 0; j < 4; j++) if ((unsigned)(rp0[u] + j - ws) < (unsigned)wl) m |= 0xFFu << (8 * j);
-                                sb4 = (sc4[u] & m) | (sb4 & ~m);
+                        for (int g = 0; g < 4; g++) {
+                            const int nv4 = nval - 4 * g;
+                            if (nv4 <= 0) break;
+                            const uint32_t vm = nv4 >= 4 ? 0xFFFFFFFFu : (1u << (8 * nv4)) - 1u;
+                            const uint32_t q4 = (uint32_t)((g < 2 ? qa[u] : qc[u]) >> (32 * (g & 1)));
+                            if (q4 & 0x80808080u & vm) { s_exotic = 1; continue; }
+                            const uint32_t vb4 = spread4((uint32_t)(y >> (16 * g)));
+                            uint32_t sb4;                                                  // biased scores
+                            if (cst) sb4 = 0x01010101u * (uint32_t)(p.s_moderate + p.score_bias);
+                            else {
+                                sb4 = d_q2s4_biased(p, q4 & 0x7F7F7F7Fu);
+                                const int r4 = rp0[u] + 4 * g;
+                                if (patched[u] && r4 < ws + wl && r4 + 4 > ws) {
+                                    const uint32_t sc4 = (uint32_t)((g < 2 ? sa[u] : sc[u]) >> (32 * (g & 1)));
+                                    uint32_t m = 0;
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) if ((unsigned)(r4 + j - ws) < (unsigned)wl) m |= 0xFFu << (8 * j);
+                                    sb4 = (sc4 & m) | (sb4 & ~m);
+                                }
                             }
-                        }
-                        // bytes whose base is the template's (bases are < 16: + 15 reaches bit 4 iff they differ)
-                        const uint32_t ne = (((vb4 ^ tb4) + 0x0F0F0F0Fu) >> 4) & 0x01010101u, eq1 = (ne ^ 0x01010101u) & vm;
-                        const uint32_t m4 = (eq1 << 8) - eq1;
-                        const uint32_t qm = q4[u] & m4, sm = sb4 & m4, qa = qm & 0x00FF00FFu, qb2 = (qm >> 8) & 0x00FF00FFu;
-                        C4 += eq1;
-                        S02 += sm & 0x00FF00FFu; S13 += (sm >> 8) & 0x00FF00FFu;
-                        Q02 += qa; Q13 += qb2;
-                        T02 = pk_max_u16(T02, qa); T13 = pk_max_u16(T13, qb2);
-                        uint32_t rest = vm & ~m4 & 0x01010101u;                           // votes for another base: bit 8 j
-                        if (rest) {
-                            const int slb = ((cb >> 2) + lane) & 127;
-                            do {
+                            // bytes whose base is the template's (bases are < 16: + 15 reaches bit 4 iff they differ)
+                            const uint32_t ne = (((vb4 ^ tb[g]) + 0x0F0F0F0Fu) >> 4) & 0x01010101u, eq1 = (ne ^ 0x01010101u) & vm;
+                            const uint32_t m4 = (eq1 << 8) - eq1;
+                            const uint32_t qm = q4 & m4, sm = sb4 & m4, qlo = qm & 0x00FF00FFu, qhi = (qm >> 8) & 0x00FF00FFu;
+                            C4[g] += eq1;
+                            S02[g] += sm & 0x00FF00FFu; S13[g] += (sm >> 8) & 0x00FF00FFu;
+                            Q02[g] += qlo; Q13[g] += qhi;
+                            T02[g] = pk_max_u16(T02[g], qlo); T13[g] = pk_max_u16(T13[g], qhi);
+                            uint32_t rest = vm & ~m4 & 0x01010101u;                       // votes for another base: bit 8 j
+                            while (rest) {
                                 const int j = (__ffs((int)rest) - 1) >> 3;
                                 rest &= rest - 1;
                                 const uint32_t nib = (vb4 >> (8 * j)) & 15u;
                                 const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;       // A,C,G,T,N -> 0..4, anything else 7
                                 if (k == 7u) { s_exotic = 1; continue; }
-                                const uint32_t qu = (q4[u] >> (8 * j)) & 0xFFu, sb = (sb4 >> (8 * j)) & 0xFFu;
-                                const int sl = (j << 7) | slb;
+                                const uint32_t qu = (q4 >> (8 * j)) & 0xFFu, sb = (sb4 >> (8 * j)) & 0xFFu;
+                                const int sl = dv_slot(c0 + 4 * g + j);
                                 atomicAdd(&s_acc[k][sl], (unsigned long long)(1u | (sb << 16)) | ((unsigned long long)(qu << 8) << 32));
                                 atomicMax(&s_tq[k][sl], qu);
-                            } while (rest);
+                            }
                         }
                     }
                 }
-                // the lane's register tallies -> the template base's bins (a template base outside A,C,G,T,N: the template votes for itself, exotic)
-                if (c0 < len && C4 != 0u) {
-                    const int slb = ((cb >> 2) + lane) & 127;
+                DV_TICK(2);
+                // the lane's register tallies -> the template base's bins (a template base outside A,C,G,T,N: a voter with it is exotic)
+                if (c0 < len) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t cnt = (C4 >> (8 * j)) & 0xFFu;
-                        if (cnt == 0u) continue;
-                        const uint32_t nib = (tb4 >> (8 * j)) & 15u;
-                        const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;
-                        if (k == 7u) { s_exotic = 1; continue; }
-                        const uint32_t ss = ((j & 1) ? S13 : S02) >> (16 * (j >> 1)) & 0xFFFFu, qs = ((j & 1) ? Q13 : Q02) >> (16 * (j >> 1)) & 0xFFFFu;
-                        const uint32_t tq = ((j & 1) ? T13 : T02) >> (16 * (j >> 1)) & 0xFFFFu;
-                        const int sl = (j << 7) | slb;
-                        atomicAdd(&s_acc[k][sl], (unsigned long long)(cnt | (ss << 16)) | ((unsigned long long)(qs << 8) << 32));
-                        atomicMax(&s_tq[k][sl], tq);
+                    for (int g = 0; g < 4; g++) {
+                        if (C4[g] == 0u) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t cnt = (C4[g] >> (8 * j)) & 0xFFu;
+                            if (cnt == 0u) continue;
+                            const uint32_t nib = (tb[g] >> (8 * j)) & 15u;
+                            const uint32_t k = (uint32_t)(0x4777777377727107ull >> (nib * 4)) & 7u;
+                            if (k == 7u) { s_exotic = 1; continue; }
+                            const uint32_t ss = ((j & 1) ? S13[g] : S02[g]) >> (16 * (j >> 1)) & 0xFFFFu, qs = ((j & 1) ? Q13[g] : Q02[g]) >> (16 * (j >> 1)) & 0xFFFFu;
+                            const uint32_t tq = ((j & 1) ? T13[g] : T02[g]) >> (16 * (j >> 1)) & 0xFFFFu;
+                            const int sl = dv_slot(c0 + 4 * g + j);
+                            atomicAdd(&s_acc[k][sl], (unsigned long long)(cnt | (ss << 16)) | ((unsigned long long)(qs << 8) << 32));
+                            atomicMax(&s_tq[k][sl], tq);
+                        }
                     }
                 }
+                DV_TICK(3);
             }
         }
         __syncthreads();
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
         }
         if (minc) atomicAdd(&s_minc, minc);
         __syncthreads();
+        DV_TICK(4);
         minc = s_minc;
         bool restore = false;
         if (minc != 0) {                                                           // group.cpp:528-573
@@ -253,6 +293,7 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
             for (int col = tid; col < len; col += DV_T) oqual[col] = s_nq[col];
         }
         if (tid == 0) { rp_out[gi] = out; w.gen_flag[e] = DV_DONE; }
+        DV_TICK(5);
     }
 }
 

@@ -147,7 +147,7 @@ __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base
     return s;
 }
 
-#ifdef VB_PROF
+#if defined(VB_PROF) && !defined(DV_PROF)
 #define VB_TICK(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&w.si->prof[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
 #elif defined(VB_STOP)                  // cumulative cost of the phases (tools/vote_stop.sh): the kernel ends at tick VB_STOP
 #define VB_TICK(k) do { if ((k) >= VB_STOP) return; } while (0)
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
     const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
     const uint32_t g0 = w.vb_start[blockIdx.x];
     if (g0 == NONE32) return;
-#ifdef VB_PROF
+#if defined(VB_PROF) && !defined(DV_PROF)
     unsigned long long t_prev_ = wall_clock64();
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&w.si->prof[15], 1ull);
 #endif
