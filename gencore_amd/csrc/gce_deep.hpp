@@ -367,13 +367,16 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
     __shared__ uint8_t s_rest[PD_MAX];           // name bytes behind the window
     __shared__ int s_cp, s_flag, s_ngroups;
     const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_li;
     const uint32_t n_list = w.si->n_slow_pair;
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    for (;;) {                                                                     // (a block draws its next cluster when it is done with one: they differ tenfold in size)
+        __syncthreads();
+        if (tid == 0) { s_li = atomicAdd(&w.si->pair_next, 1u); s_cp = 0x7FFFFFFF; s_flag = 0; }
+        __syncthreads();
+        const uint32_t li = s_li;
+        if (li >= n_list) break;
         const uint32_t c = w.slow_list[li];
         const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-        __syncthreads();
-        if (tid == 0) { s_cp = 0x7FFFFFFF; s_flag = 0; }
-        __syncthreads();
         bool take = n > 64 && n <= PD_MAX;
         if (take) {
             int bad = 0;
