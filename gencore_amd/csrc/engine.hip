@@ -78,7 +78,7 @@ struct gce_engine {
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
     int64_t n = 0;
@@ -157,7 +157,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
@@ -627,7 +627,9 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
         compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
         hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
-        hipLaunchKernelGGL(k_pairing_deep, dim3(256), dim3(PD_T), 0, s, b, p, w);             // deep clusters in LDS; the rest -> pq_list
+        hipLaunchKernelGGL(k_pairing_deep<false>, dim3(256), dim3(PD_T), 0, s, b, p, w, (uint8_t *)nullptr);      // deep clusters in LDS; the rest -> pq_list
+        ENS(pd_slab, PD_BIG_BLOCKS * PD_SLAB);
+        hipLaunchKernelGGL(k_pairing_deep<true>, dim3(PD_BIG_BLOCKS), dim3(PD_T), 0, s, b, p, w, e->pd_slab.as<uint8_t>());   // what that left for its size (<= 65 534 reads), arrays in device memory
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
         hipLaunchKernelGGL(k_pairing_slow<2>, dim3(1024), dim3(256), 0, s, b, p, w);

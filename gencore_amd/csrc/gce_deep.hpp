@@ -325,7 +325,7 @@ __device__ __forceinline__ int pd_rest_cmp(const char *a, int la, const char *c,
     }
     return 0;
 }
-template <typename T, typename Less>
+template <bool GMEM, typename T, typename Less>
 __device__ __forceinline__ void pd_bitonic(T *perm, int P, int tid, Less less) {
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -336,7 +336,7 @@ __device__ __forceinline__ void pd_bitonic(T *perm, int P, int tid, Less less) {
                 const bool swap = up ? less(c, a) : less(a, c);
                 if (swap) { perm[i] = c; perm[l] = a; }
             }
-            if (j > 64 || j == 1 && (k << 1) > 128) __syncthreads(); else WAVE_SYNC();
+            if (GMEM || j > 64 || j == 1 && (k << 1) > 128) __syncthreads(); else WAVE_SYNC();      // (arrays in memory: always the block barrier with its fences)
         }
 }
 // exclusive prefix over the block of one value per thread (+ total), s_w: 16 words of scratch
@@ -357,27 +357,46 @@ __device__ __forceinline__ uint32_t pd_scan(uint32_t v, uint32_t *s_w, int tid, 
 #else
 #define PD_TICK(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, Work w) {
-    __shared__ uint64_t s_key[PD_MAX][2];        // name windows of the reads, then UMI words of the pairs, then (u32) layout keys
-    __shared__ uint16_t s_perm[PD_MAX];
-    __shared__ uint16_t s_pl[PD_MAX], s_pr[PD_MAX];       // member index of the left / right read of pair i (qname order)
-    __shared__ uint16_t s_pd[PD_MAX];            // pair -> distinct UMI, then pair -> group
-    __shared__ uint32_t s_x[2 * PD_MAX + PD_MAX / 2];   // steps 1-2: read index and name pointer offset of every member; step 3: the distinct-UMI tables
+// BIG = false: clusters of 65..PD_MAX reads, everything in LDS.  BIG = true: the clusters THAT one left behind for their size (up to 65 534
+// reads: the 16-bit indices), the same algorithm with its arrays in a slab of device memory per block -- O(n log^2 n) instead of the generic
+// kernels' O(n^2 / 64) for an ultra-deep hotspot; taken entries of pq_list are struck out (NONE32), the generic kernels skip them.
+#define PD_BIGMAX 65536
+#define PD_SLAB ((size_t)35 * PD_BIGMAX)       // bytes of device memory per block of the BIG instantiation
+#define PD_BIG_BLOCKS 16
+template <bool BIG>
+__global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, Work w, uint8_t *slab) {
+    constexpr int MAXN = BIG ? PD_BIGMAX : PD_MAX, LN = BIG ? 2 : PD_MAX;
+    __shared__ uint64_t l_key[LN][2];            // name windows of the reads, then UMI words of the pairs, then (u32) layout keys
+    __shared__ uint16_t l_perm[LN];
+    __shared__ uint16_t l_pl[LN], l_pr[LN];      // member index of the left / right read of pair i (qname order)
+    __shared__ uint16_t l_pd[LN];                // pair -> distinct UMI, then pair -> group
+    __shared__ uint32_t l_x[2 * LN + LN / 2];    // steps 1-2: read index and name pointer offset of every member; step 3: the distinct-UMI tables
+    __shared__ uint8_t l_rest[LN];               // name bytes behind the window
     __shared__ uint32_t s_w[PD_T / 64];
-    __shared__ uint8_t s_rest[PD_MAX];           // name bytes behind the window
     __shared__ int s_cp, s_flag, s_ngroups;
+    uint64_t (*s_key)[2]; uint16_t *s_perm, *s_pl, *s_pr, *s_pd; uint32_t *s_x; uint8_t *s_rest;
+    if (BIG) {
+        uint8_t *m = slab + (size_t)blockIdx.x * PD_SLAB;
+        s_key = reinterpret_cast<uint64_t (*)[2]>(m); m += (size_t)16 * MAXN;
+        s_x = reinterpret_cast<uint32_t *>(m); m += (size_t)10 * MAXN;
+        s_perm = reinterpret_cast<uint16_t *>(m); m += (size_t)2 * MAXN;
+        s_pl = reinterpret_cast<uint16_t *>(m); m += (size_t)2 * MAXN;
+        s_pr = reinterpret_cast<uint16_t *>(m); m += (size_t)2 * MAXN;
+        s_pd = reinterpret_cast<uint16_t *>(m); m += (size_t)2 * MAXN;
+        s_rest = m;
+    } else { s_key = l_key; s_perm = l_perm; s_pl = l_pl; s_pr = l_pr; s_pd = l_pd; s_x = l_x; s_rest = l_rest; }
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ uint32_t s_li;
-    const uint32_t n_list = w.si->n_slow_pair;
+    const uint32_t n_list = BIG ? w.si->n_slow_pair2 : w.si->n_slow_pair;
     for (;;) {                                                                     // (a block draws its next cluster when it is done with one: they differ tenfold in size)
         __syncthreads();
-        if (tid == 0) { s_li = atomicAdd(&w.si->pair_next, 1u); s_cp = 0x7FFFFFFF; s_flag = 0; }
+        if (tid == 0) { s_li = atomicAdd(BIG ? &w.si->pair_next2 : &w.si->pair_next, 1u); s_cp = 0x7FFFFFFF; s_flag = 0; }
         __syncthreads();
         const uint32_t li = s_li;
         if (li >= n_list) break;
-        const uint32_t c = w.slow_list[li];
+        const uint32_t c = BIG ? w.pq_list[li] : w.slow_list[li];
         const uint32_t start = w.cl_start[c], n = w.cl_n[c];
-        bool take = n > 64 && n <= PD_MAX;
+        bool take = BIG ? (n > PD_MAX && n <= PD_BIGMAX - 2) : (n > 64 && n <= PD_MAX);      // (BIG: only what the LDS instantiation left for its size)
         if (take) {
             int bad = 0;
             const uint64_t q0 = b.qname_off[w.members[start]];
@@ -389,16 +408,16 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             if (bad) s_flag = 1;
         }
         __syncthreads();
-        if (!take || s_flag) { if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }
+        if (!take || s_flag) { if (!BIG && tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }      // (BIG: the entry stays for the generic kernels)
         const uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
-        if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } continue; }
+        if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; if (BIG) w.pq_list[li] = NONE32; } continue; }
 #ifdef VB_PROF
         unsigned long long pd_prev_ = wall_clock64();
         if (threadIdx.x == 0) atomicAdd(&w.si->prof[30], 1ull);
 #endif
         const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
-        uint32_t *s_rd = s_x; uint32_t *s_qo = s_x + PD_MAX;
-        uint16_t *s_dfirst = reinterpret_cast<uint16_t *>(s_x), *s_dcnt = s_dfirst + PD_MAX, *s_dgrp = s_dcnt + PD_MAX;
+        uint32_t *s_rd = s_x; uint32_t *s_qo = s_x + MAXN;
+        uint16_t *s_dfirst = reinterpret_cast<uint16_t *>(s_x), *s_dcnt = s_dfirst + MAXN, *s_dgrp = s_dcnt + MAXN;
         // ---- 1. name windows + sort
         {
             const char *n0 = d_qname(b, w.members[start]);
@@ -449,7 +468,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             return s_rd[a] < s_rd[c2];
         };
         PD_TICK(0);
-        pd_bitonic(s_perm, P, tid, name_less);
+        pd_bitonic<BIG>(s_perm, P, tid, name_less);
         {
             int toolong = 0;
             for (int sidx = tid; sidx < (int)n; sidx += PD_T) {
@@ -475,16 +494,15 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             if (toolong) s_flag = 1;
         }
         __syncthreads();
-        if (s_flag) { __syncthreads(); if (tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }   // hundreds of names behind one window: generic kernels
+        if (s_flag) { __syncthreads(); if (!BIG && tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }   // hundreds of names behind one window: generic kernels
         PD_TICK(1);
         // ---- 2. pairs
         const int per = (P + PD_T - 1) / PD_T;                                     // sorted positions per thread (contiguous)
         uint32_t firsts = 0;
-        bool isf[PD_MAX / PD_T], isl[PD_MAX / PD_T];
+        uint64_t isf_m = 0, isl_m = 0;                                             // (per <= 64: one bit per position of the thread)
         int any_umi = 0;
         for (int u = 0; u < per; u++) {
             const int sidx = tid * per + u;
-            isf[u] = isl[u] = false;
             if (sidx < (int)n) {
                 const uint16_t m = s_perm[sidx];
                 const uint32_t q = s_rd[m];
@@ -492,9 +510,9 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                     if (s_key[o][0] != s_key[m][0] || s_key[o][1] != s_key[m][1]) return false;
                     return pd_rest_cmp(qbase + (int32_t)s_qo[o], (int)s_rest[o], qbase + (int32_t)s_qo[m], (int)s_rest[m]) == 0;
                 };
-                isf[u] = sidx == 0 || !same(s_perm[sidx - 1]);
-                isl[u] = sidx == (int)n - 1 || !same(s_perm[sidx + 1]);
-                if (!isf[u]) {                                                     // setRight: UMI of the pair so far vs this read's (pair.cpp:201-212)
+                const bool f_ = sidx == 0 || !same(s_perm[sidx - 1]), l_ = sidx == (int)n - 1 || !same(s_perm[sidx + 1]);
+                isf_m |= (uint64_t)f_ << u; isl_m |= (uint64_t)l_ << u;
+                if (!f_) {                                                     // setRight: UMI of the pair so far vs this read's (pair.cpp:201-212)
                     const uint32_t pv = s_rd[s_perm[sidx - 1]];
                     const int lp = w.umi_len[pv], lq = w.umi_len[q];
                     if (lp != 0) {
@@ -503,8 +521,8 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                         if (lp != lq || x[0] != y[0] || x[1] != y[1]) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
                     }
                 }
-                if (isl[u] && w.umi_len[q]) any_umi = 1;
-                firsts += isf[u];
+                if (l_ && w.umi_len[q]) any_umi = 1;
+                firsts += f_;
             }
         }
         uint32_t npairs;
@@ -516,11 +534,12 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             for (int u = 0; u < per; u++) {
                 const int sidx = tid * per + u;
                 if (sidx < (int)n) {
-                    if (isf[u]) pi++;
+                    const bool f_ = (isf_m >> u) & 1, l_ = (isl_m >> u) & 1;
+                    if (f_) pi++;
                     const uint32_t pidx = pi - 1;
                     const uint16_t m = s_perm[sidx];
-                    if (isf[u]) { s_pl[pidx] = m; if (isl[u]) s_pr[pidx] = PD_NONE16; }
-                    if (isl[u] && !isf[u]) s_pr[pidx] = m;
+                    if (f_) { s_pl[pidx] = m; if (l_) s_pr[pidx] = PD_NONE16; }
+                    if (l_ && !f_) s_pr[pidx] = m;
                 }
             }
         }
@@ -554,16 +573,17 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                 return a < c2;
             };
             PD_TICK(3);
-            pd_bitonic(s_perm, P2, tid, umi_less);
+            pd_bitonic<BIG>(s_perm, P2, tid, umi_less);
             PD_TICK(4);
             const int per2 = (P2 + PD_T - 1) / PD_T;
             uint32_t heads = 0;
+            isf_m = 0;
             for (int u = 0; u < per2; u++) {
                 const int sidx = tid * per2 + u;
                 if (sidx < (int)npairs) {
                     const uint16_t m = s_perm[sidx];
                     const bool head = sidx == 0 || s_key[s_perm[sidx - 1]][0] != s_key[m][0] || s_key[s_perm[sidx - 1]][1] != s_key[m][1];
-                    isf[u] = head; heads += head;
+                    isf_m |= (uint64_t)head << u; heads += head;
                 }
             }
             uint32_t D;
@@ -573,7 +593,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                 for (int u = 0; u < per2; u++) {
                     const int sidx = tid * per2 + u;
                     if (sidx < (int)npairs) {
-                        if (isf[u]) { di++; s_dfirst[di - 1] = s_perm[sidx]; s_dcnt[di - 1] = (uint16_t)sidx; s_dgrp[di - 1] = PD_NONE16; }   // dcnt: start for now
+                        if ((isf_m >> u) & 1) { di++; s_dfirst[di - 1] = s_perm[sidx]; s_dcnt[di - 1] = (uint16_t)sidx; s_dgrp[di - 1] = PD_NONE16; }   // dcnt: start for now
                         s_pd[s_perm[sidx]] = (uint16_t)(di - 1);
                     }
                 }
@@ -590,11 +610,11 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             __syncthreads();
             // the greedy loop over the DISTINCT UMIs.  Candidates in the order the reference would pick them if nothing were absorbed:
             // count descending, then UMI ascending (= distinct index ascending) -- one more sort, of (0xFFFF - count) << 16 | index
-            uint32_t *ord = s_x + PD_MAX + PD_MAX / 2;                                       // behind the three u16 tables (3 x PD_MAX x 2 bytes); PD_MAX words
+            uint32_t *ord = s_x + MAXN + MAXN / 2;                                           // behind the three u16 tables (3 x MAXN x 2 bytes); MAXN words
             int P4 = 128; while (P4 < (int)D) P4 <<= 1;
             for (int i = tid; i < P4; i += PD_T) ord[i] = i < (int)D ? ((0xFFFFu - (uint32_t)s_dcnt[i]) << 16 | (uint32_t)i) : 0xFFFFFFFFu;
             __syncthreads();
-            pd_bitonic(ord, P4, tid, [](uint32_t x, uint32_t y) { return x < y; });
+            pd_bitonic<BIG>(ord, P4, tid, [](uint32_t x, uint32_t y) { return x < y; });
             if (thr <= 0) {                                                        // nothing but the UMI itself is within 0: groups = candidates in order
                 for (uint32_t r = tid; r < D; r += PD_T) s_dgrp[ord[r] & 0xFFFFu] = (uint16_t)r;
                 if (tid == 0) s_ngroups = (int)D;
@@ -628,7 +648,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             uint32_t *lk = reinterpret_cast<uint32_t *>(&s_key[0][0]);
             for (int i = tid; i < P3; i += PD_T) { lk[i] = i < (int)npairs ? ((uint32_t)s_pd[i] << 16 | (uint32_t)i) : 0xFFFFFFFFu; }
             __syncthreads();
-            pd_bitonic(lk, P3, tid, [](uint32_t a, uint32_t c2) { return a < c2; });
+            pd_bitonic<BIG>(lk, P3, tid, [](uint32_t a, uint32_t c2) { return a < c2; });
             PD_TICK(6);
             for (uint32_t sidx = tid; sidx < npairs; sidx += PD_T) {
                 const uint32_t key = lk[sidx], g = key >> 16, i = key & 0xFFFFu;
@@ -646,6 +666,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         if (tid == 0) {
             const bool cross = d_key(b.core[w.members[start]], p).right < 0;
             w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0));
+            if (BIG) w.pq_list[li] = NONE32;                                       // done here: struck out of the generic kernels' list
         }
     }
 }

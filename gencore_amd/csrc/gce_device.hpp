@@ -66,7 +66,7 @@ struct StreamInfo {
     unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
-    unsigned int pair_next;              // ... and of k_pairing_deep
+    unsigned int pair_next, pair_next2;  // ... and of k_pairing_deep (LDS / device-memory instantiation)
     unsigned int prep_next, deep_next;   // work counters of k_deep_prepare / k_vote_deep: a wave / a block draws its next side when it is done with one
     int lq_min, lq_max;                  // shortest / longest read that can be emitted (clustered or passed through): k_describe
     unsigned long long n_clusters, n_groups, n_pairs, n_out;

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, W
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n_slow = w.si->n_slow_pair2;                                      // what k_pairing_deep (gce_deep.hpp) left over
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
-        pairing_generic<PHASE>(b, p, w, w.pq_list[idx], lane, blockIdx.y, gridDim.y);
+        const uint32_t c = w.pq_list[idx];
+        if (c != NONE32) pairing_generic<PHASE>(b, p, w, c, lane, blockIdx.y, gridDim.y);      // (NONE32: taken by the device-memory instantiation of k_pairing_deep)
         WAVE_SYNC();
     }
 }

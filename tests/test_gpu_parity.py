@@ -70,6 +70,15 @@ def test_fuzz_deep_cluster(built, seed, deep):
         assert got.fr.max() >= 0
 
 
+@pytest.mark.parametrize("seed,deep,umi_mode", [(210, 2300, "duplex"), (211, 2700, "none"), (212, 5200, "prefix")])
+def test_cluster_beyond_the_lds_pairing_kernel(built, seed, deep, umi_mode):
+    """> 4096 reads in one cluster: k_pairing_deep's LDS instantiation leaves it for its size, the device-memory instantiation (same
+    algorithm, arrays in a slab per block, up to 65 534 reads) takes it -- not the generic O(n^2) kernels."""
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=4, umi_mode=umi_mode, deep=deep)
+    over["skip_low_complexity_cluster_threshold"] = 1000
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
 def synth_case(name, n_pairs, **over):
     from gencore_amd import synth
     from gencore_amd.capi import default_params
