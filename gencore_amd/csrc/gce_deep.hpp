@@ -43,7 +43,13 @@ __global__ __launch_bounds__(256) void k_deep_prepare(DevBatch b, DevParams p, W
         const uint32_t e = w.slow_list[idx], gi = e >> 1; const bool is_left = !(e & 1);
         const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
         if (np <= 64) continue;                                                   // here for another reason (exotic bases, long reads)
+#ifdef DV_PROF
+        const unsigned long long dp_t0_ = wall_clock64();
+#endif
         const SidePrep sp = side_prepare(b, p, w, begin, np, is_left, lane);
+#ifdef DV_PROF
+        if (lane == 0) { atomicAdd(&w.si->prof[6], wall_clock64() - dp_t0_); atomicAdd(&w.si->prof[7], (unsigned long long)np * 100ull); atomicAdd(&w.si->prof[14], 1ull); }
+#endif
         if (lane == 0) {
             if (sp.out == NONE32) { (is_left ? w.rp_left : w.rp_right)[gi] = NONE32; w.gen_flag[e] = DV_DONE; }
             else if (sp.len <= DV_COLS && sp.nv < 65536u) {

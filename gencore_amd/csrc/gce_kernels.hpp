@@ -752,7 +752,15 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     bool left_mode = is_left;
     if (!is_left) {
         int mn = 0x7FFFFFFF, mx = -1;
-        for (uint32_t k = lane; k < np; k += 64) { uint32_t rd = side[begin + k]; if (rd != NONE32) { int ps = b.core[rd].pos; mn = min(mn, ps); mx = max(mx, ps); } }
+        for (uint32_t k0 = lane; k0 < np; k0 += 256) {                          // (four batches in flight: index -> position is two dependent round trips)
+            uint32_t rdv[4]; int psv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t k = k0 + 64u * u; rdv[u] = k < np ? side[begin + k] : NONE32; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) psv[u] = b.core[rdv[u] != NONE32 ? rdv[u] : 0u].pos;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (rdv[u] != NONE32) { mn = min(mn, psv[u]); mx = max(mx, psv[u]); }
+        }
         mn = wave_min(mn); mx = wave_max(mx);
         if (mx < 0 || mn == mx) left_mode = true;
     }
@@ -764,22 +772,37 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     // registers instead of O(reads^2) walks through memory.  One class per lane (<= 64), CIGARs of <= 4 ops; anything else
     // takes the pairwise loop below.
     bool classed = false, lowc_done = false;
-    int lr_lq = 0, lr_pos = 0; uint32_t lr_rd = NONE32;                          // (of the last load_read: read length, position, read)
-    auto load_read = [&](uint32_t k, bool &has, int &n_, int &rr_, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
-        has = false; n_ = 0; rr_ = 0; w0 = w1 = w2 = w3 = 0; lr_rd = NONE32;
-        uint32_t rd = k < np ? side[begin + k] : NONE32;
-        if (rd == NONE32) return;
-        has = true;
-        const ReadDesc d = load_desc(w.rdesc, rd);
-        lr_lq = d.lq; lr_pos = d.pos; lr_rd = rd;
-        n_ = d.nc; rr_ = is_left ? 0 : d.pos + (d.rlen != RLEN_WALK ? d.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], d.nc));
-        if (n_ == 1) w0 = d.c0;
-        else if (n_ >= 2 && n_ <= 4) {                                     // oriented: i-th op from the compared end (bamutil.cpp:213-218)
+    // a read of the side as the class logic sees it: CIGAR length, right end (right sides), the <= 4 CIGAR words ORIENTED from the compared
+    // end (bamutil.cpp:213-218), length, position.  Four reads per lane are fetched at a time (index -> descriptor -> CIGAR words is a
+    // dependent chain of two or three round trips; a wave that walked its side 64 reads per trip spent its life waiting for them).
+    struct RD { bool has; int n, rr, lq, pos; uint32_t w0, w1, w2, w3, rd; };
+    auto fill_rd = [&](RD &r, uint32_t rd, const ReadDesc &d) {
+        r.has = rd != NONE32; r.n = 0; r.rr = 0; r.lq = 0; r.pos = 0; r.w0 = r.w1 = r.w2 = r.w3 = 0; r.rd = rd;
+        if (!r.has) return;
+        r.lq = d.lq; r.pos = d.pos; r.n = d.nc;
+        r.rr = is_left ? 0 : d.pos + (d.rlen != RLEN_WALK ? d.rlen : d_cigar_rlen(b.cigar + b.cigar_off[rd], d.nc));
+        if (r.n == 1) r.w0 = d.c0;
+        else if (r.n >= 2 && r.n <= 4) {
             const uint32_t *cg = b.cigar + b.cigar_off[rd];
-            w0 = left_mode ? cg[0] : cg[n_ - 1]; w1 = left_mode ? cg[1] : cg[n_ - 2];
-            if (n_ >= 3) w2 = left_mode ? cg[2] : cg[n_ - 3];
-            if (n_ >= 4) w3 = left_mode ? cg[3] : cg[0];
+            r.w0 = left_mode ? cg[0] : cg[r.n - 1]; r.w1 = left_mode ? cg[1] : cg[r.n - 2];
+            if (r.n >= 3) r.w2 = left_mode ? cg[2] : cg[r.n - 3];
+            if (r.n >= 4) r.w3 = left_mode ? cg[3] : cg[0];
         }
+    };
+    auto load_read1 = [&](uint32_t k) {
+        RD r; const uint32_t rd = k < np ? side[begin + k] : NONE32;
+        const ReadDesc d = load_desc(w.rdesc, rd != NONE32 ? rd : 0u);
+        fill_rd(r, rd, d);
+        return r;
+    };
+    auto load_read4 = [&](uint32_t base, RD (&r)[4]) {
+        uint32_t rdv[4]; ReadDesc d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = base + 64u * u + lane; rdv[u] = k < np ? side[begin + k] : NONE32; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) d[u] = load_desc(w.rdesc, rdv[u] != NONE32 ? rdv[u] : 0u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) fill_rd(r[u], rdv[u], d[u]);
     };
     auto part_of4 = [&](int pn, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int wn, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
         if (wn < pn) return false;                                      // BamUtil::isPartOf (bamutil.cpp:204-255) on oriented words
@@ -802,9 +825,14 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     if (np > 64) {
         int c_n = 0, c_cnt = 0, c_rr = 0; uint32_t c_w0 = 0, c_w1 = 0, c_w2 = 0, c_w3 = 0;      // lane c = class c
         int nclass = 0; bool fail = false;
-        for (uint32_t base = 0; base < np && !fail; base += 64) {
-            bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
-            load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
+        for (uint32_t base4 = 0; base4 < np && !fail; base4 += 256) {
+          RD r4[4];
+          load_read4(base4, r4);
+#pragma unroll
+          for (int u4 = 0; u4 < 4; u4++) {
+            const uint32_t base = base4 + 64u * u4;
+            if (base >= np || fail) break;
+            const bool has = r4[u4].has; const int n_ = r4[u4].n, rr_ = r4[u4].rr; const uint32_t w0 = r4[u4].w0, w1 = r4[u4].w1, w2 = r4[u4].w2, w3 = r4[u4].w3;
             if (__any(has && n_ > 4)) { fail = true; break; }
             const unsigned long long hm = __ballot(has);
             if (first_read == NONE32 && hm) first_read = side[begin + base + (__ffsll((long long)hm) - 1)];
@@ -832,6 +860,7 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
                     nclass++;
                 }
             }
+          }
         }
         // ---- low-complexity skip for very deep groups (group.cpp:142-175), from the classes: distinct CIGAR strings = classes whose
         //      words differ from every earlier class (a right side keys its classes by right end as well)
@@ -853,16 +882,19 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
             }
         }
         if (!fail) {
-            for (uint32_t base = 0; base < np; base += 64) {
-                bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
-                load_read(base + lane, has, n_, rr_, w0, w1, w2, w3);
-                uint32_t cb = 0;
-                for (int cc = 0; cc < nclass; cc++) {
+            for (uint32_t base4 = 0; base4 < np; base4 += 256) {
+                RD r4[4];
+                load_read4(base4, r4);
+                uint32_t cb[4] = {0, 0, 0, 0};
+                for (int cc = 0; cc < nclass; cc++) {                               // (one broadcast of a class serves the four reads of the lane)
                     const int q_n = rl32(c_n, cc), q_rr = rl32(c_rr, cc), q_cnt = rl32(c_cnt, cc);
                     const uint32_t q0 = (uint32_t)rl32((int)c_w0, cc), q1 = (uint32_t)rl32((int)c_w1, cc), q2 = (uint32_t)rl32((int)c_w2, cc), q3 = (uint32_t)rl32((int)c_w3, cc);
-                    if (has && (is_left || rr_ == q_rr) && part_of4(n_, w0, w1, w2, w3, q_n, q0, q1, q2, q3)) cb += (uint32_t)q_cnt;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (r4[u].has && (is_left || r4[u].rr == q_rr) && part_of4(r4[u].n, r4[u].w0, r4[u].w1, r4[u].w2, r4[u].w3, q_n, q0, q1, q2, q3)) cb[u] += (uint32_t)q_cnt;
                 }
-                if (base + lane < np) contained[begin + base + lane] = has ? cb : 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t k = base4 + 64u * u + lane; if (k < np) { contained[begin + k] = r4[u].has ? cb[u] : 0; vld[begin + k] = (uint32_t)r4[u].lq; } }   // (vld: the read lengths, for the template pick below; the voter list overwrites them later)
             }
             classed = true;
         }
@@ -932,6 +964,18 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     }
     // ---- template = max containedBy, then shorter read, then first in qname order (group.cpp:235-261)
     uint32_t best = NONE32; int bc = -1, blen = 0;
+    if (classed) {                                                          // (lengths next to the counts: two coalesced loads, four batches in flight)
+        for (uint32_t k0 = lane; k0 < np; k0 += 256) {
+            int cbv[4], lnv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t k = k0 + 64u * u; cbv[u] = k < np ? (int)contained[begin + k] : -1; lnv[u] = k < np ? (int)vld[begin + k] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * u;
+                if (k < np && (best == NONE32 || cbv[u] > bc || (cbv[u] == bc && lnv[u] < blen))) { best = k; bc = cbv[u]; blen = lnv[u]; }
+            }
+        }
+    } else
     for (uint32_t k = lane; k < np; k += 64) {
         int cb = (int)contained[begin + k];
         uint32_t rd = side[begin + k];
@@ -956,22 +1000,25 @@ __device__ SidePrep side_prepare(const DevBatch &b, const DevParams &p, const Wo
     if (classed) {
         // the classes' reads have <= 4 CIGAR ops: isPartOf on the oriented words in registers (as containedBy above), length and position
         // from the descriptor -- not a gather of the alignment record and two CIGAR walks through memory per read
-        bool t_has; int t_n, t_rr; uint32_t t0, t1, t2, t3;
-        load_read(best, t_has, t_n, t_rr, t0, t1, t2, t3);                      // (every lane: the template)
-        for (uint32_t base = 0; base < np; base += 64) {
-            const uint32_t j = base + lane;
-            bool has; int n_, rr_; uint32_t w0, w1, w2, w3;
-            load_read(j, has, n_, rr_, w0, w1, w2, w3);
-            const uint32_t rd = lr_rd;
-            bool take = has && j != best && part_of4(t_n, t0, t1, t2, t3, n_, w0, w1, w2, w3);
-            int ld = 0;
-            if (take) {
-                ld = lr_lq - ok.l_qseq;
-                if (ld != 0 && lr_pos == ok.pos && (left_mode || d_is_part_of(ocig, ok.n_cigar, b.cigar + b.cigar_off[rd], n_, true))) ld = 0;
+        const RD t = load_read1(best);                                          // (every lane: the template)
+        for (uint32_t base4 = 0; base4 < np; base4 += 256) {
+            RD r4[4];
+            load_read4(base4, r4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = base4 + 64u * u + lane;
+                if (base4 + 64u * u >= np) break;
+                const RD &r = r4[u];
+                const bool take = r.has && j != best && part_of4(t.n, t.w0, t.w1, t.w2, t.w3, r.n, r.w0, r.w1, r.w2, r.w3);
+                int ld = 0;
+                if (take) {
+                    ld = r.lq - ok.l_qseq;
+                    if (ld != 0 && r.pos == ok.pos && (left_mode || d_is_part_of(ocig, ok.n_cigar, b.cigar + b.cigar_off[r.rd], r.n, true))) ld = 0;
+                }
+                const unsigned long long m = __ballot(take);
+                if (take) { const uint32_t d = begin + nv + lanes_below(m); voters[d] = r.rd; vld[d] = (uint32_t)ld; }
+                nv += __popcll(m);
             }
-            const unsigned long long m = __ballot(take);
-            if (take) { const uint32_t d = begin + nv + lanes_below(m); voters[d] = rd; vld[d] = (uint32_t)ld; }
-            nv += __popcll(m);
         }
     } else
     for (uint32_t base = 0; base < np; base += 64) {
