@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_deep_prepare(DevBatch b, DevParams p, W
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n_slow = (uint32_t)w.si->n_slow;
     // sides differ by two orders of magnitude in size: a wave draws its next one when it is done (a fixed stride gave a few waves three big ones)
+    if (blockIdx.x * WAVES_PER_BLOCK + wv >= n_slow) return;                         // (no more waves at the counter than sides: an empty list costs nothing)
     for (;;) {
         uint32_t idx = 0;
         if (lane == 0) idx = atomicAdd(&w.si->prep_next, 1u);
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(DV_T) void k_vote_deep(DevBatch b, DevParams p, Wor
     __shared__ uint32_t s_next;
     const uint32_t n_deep = w.si->n_deep;
     // a block draws its next side when it is done with one, from the END of the list: k_deep_prepare appends a side when it is prepared, the big ones last
+    if (blockIdx.x >= n_deep) return;
     for (;;) {
         __syncthreads();
         if (tid == 0) s_next = atomicAdd(&w.si->deep_next, 1u);
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ uint32_t s_li;
     const uint32_t n_list = BIG ? w.si->n_slow_pair2 : w.si->n_slow_pair;
+    if (blockIdx.x >= n_list) return;
     for (;;) {                                                                     // (a block draws its next cluster when it is done with one: they differ tenfold in size)
         __syncthreads();
         if (tid == 0) { s_li = atomicAdd(BIG ? &w.si->pair_next2 : &w.si->pair_next, 1u); s_cp = 0x7FFFFFFF; s_flag = 0; }
