@@ -709,6 +709,9 @@ int gce_process(gce_engine *e) {
         fprintf(stderr, "k_vote phases, mean per block (100 MHz ticks -> us), %.0f blocks:", blocks);
         for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
         fprintf(stderr, "\n");
+#ifdef VB_COUNT
+        fprintf(stderr, "k_vote columns in the full vote: %.0f, one base only: %.0f, of those unchanged: %.0f\n", (double)hs.prof[11], (double)hs.prof[12], (double)hs.prof[13]);
+#endif
 #ifdef DV_PROF
         fprintf(stderr, "k_deep_prepare: %.0f sides, mean %.1f us per side, mean %.0f pairs per side\n", (double)hs.prof[14], hs.prof[14] ? hs.prof[6] / (double)hs.prof[14] / 100.0 : 0.0, hs.prof[14] ? hs.prof[7] / (double)hs.prof[14] / 100.0 : 0.0);
 #endif

@@ -426,6 +426,8 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
     for (int kk = 0; kk < VB_IPL; kk++) {
         keep[kk] = make_uint4(0, 0, 0, 0);
         const int it = tid + VB_T * kk;
+        item_side[kk] = 0;
+        if (it - lane >= n_items) continue;                                        // (wave-uniform: the second round is empty for the usual batch of <= 256 items)
         const int s = vb_find_wave(s_ipre, VB_SIDES, it - lane, lane, n_items - 1);
         item_side[kk] = s;
         if (it < n_items) {
@@ -600,6 +602,13 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
                 t.total += t.ss[k];
             }
             const ColOut r = decide_column_packed(t, p, out_base, ref4);
+#ifdef VB_COUNT      // what kind of columns reach the full vote (tools: -DVB_PROF -DVB_COUNT): 11 all, 12 one base only, 13 one base only and nothing but the quick accept
+            {
+                int nb_ = 0; for (int k = 0; k < 5; k++) nb_ += t.cnt[k] > 0;
+                atomicAdd(&w.si->prof[11], 1ull); if (nb_ == 1) atomicAdd(&w.si->prof[12], 1ull);
+                if (nb_ == 1 && r.base == out_base && r.minc == 0) atomicAdd(&w.si->prof[13], 1ull);
+            }
+#endif
             s_cq[ci] = (uint8_t)r.qual; s_cb[ci] = (uint8_t)r.base;
             if (r.minc) atomicAdd(&s_side[s].minc, r.minc);
         }

@@ -7,5 +7,5 @@ if [ "$1" = build ]; then
   mkdir -p ab
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DVB_PROF gencore_amd/csrc/engine.hip gencore_amd/csrc/bamio.cpp -o ab/prof.so -lz -lpthread
 else
-  GCE_LIB=$PWD/ab/prof.so python bench.py --workload ${2:-cfg3} --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep "phases\|k_deep_prepare" | tail -3
+  GCE_LIB=$PWD/ab/prof.so python bench.py --workload ${2:-cfg3} --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep "phases\|k_deep_prepare\|k_vote columns" | tail -4
 fi
