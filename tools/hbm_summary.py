@@ -32,7 +32,7 @@ def main():
     with open(dst + "_hbm_traffic.csv", "w") as f:
         f.write("# HBM traffic per dispatch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only)\n")
         f.write("# %s\n" % note)
-        f.write("# fetch_x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md); WRITE_SIZE and narrow reads are uncalibrated\n")
+        f.write("# fetch_x2 = gfx950 correction (MI355X_MICROARCH.md), calibrated on this engine's access patterns: profiles/r03_fetch_calibration.json\n")
         f.write("kernel,dispatches,fetch_MB,fetch_MB_x2,write_MB\n")
         for k in rows:
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, fe.get(k, (0, 0))[1] or wr.get(k, (0, 0))[1], fe.get(k, (0, 0))[0] / 1e3, 2 * fe.get(k, (0, 0))[0] / 1e3, wr.get(k, (0, 0))[0] / 1e3))
