@@ -1254,8 +1254,15 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     gce_engine *e = nullptr; gce_fasta *fa = nullptr; FILE *fo = nullptr;
     auto done = [&](int code, const char *m) { seterr(m); if (e) gce_destroy(e); if (fa) gce_fasta_free(fa); if (fo) fclose(fo); close(fd); return code; };
     const size_t PIECE = (size_t)(chunk_reads > 0 && chunk_reads < (1 << 16) ? (1 << 20) : (8 << 20));       // compressed bytes per window (tests shrink it through chunk_reads)
-    Raw<uint8_t> comp[2]; comp[0].resize(PIECE + (1 << 17)); comp[1].resize(PIECE + (1 << 17));
-    if (!comp[0].ok() || !comp[1].ok()) return done(GCE_ERR_OOM, "out of host memory");
+    // GCE_BAM_HOST_INFLATE=1: the BGZF members are inflated by the host threads (the path of the first half of round 3); default: they go to
+    // HBM compressed and the GPU inflates them (gce_raw_push_bgzf) -- the host inflates only the window(s) that hold the BAM header
+    const bool gpu_inflate = getenv("GCE_BAM_HOST_INFLATE") == nullptr;
+    const bool tlap = getenv("GCE_RAW_TIMING") != nullptr; double tl0 = now_s();
+    auto lap = [&](const char *what) { if (tlap) { const double x = now_s(); fprintf(stderr, "gce_run_bam %s %.4f s\n", what, x - tl0); tl0 = x; } };
+    Pinned comp[2]; int32_t comp_ticket[2] = {-1, -1};
+    if (!comp[0].ensure(PIECE + (1 << 17)) || !comp[1].ensure(PIECE + (1 << 17))) return done(GCE_ERR_OOM, "out of pinned host memory");
+    std::vector<uint64_t> z_coff; std::vector<uint32_t> z_csize, z_usize;
+    lap("compressed-piece buffers");
     Pinned win[3]; int32_t win_ticket[3] = {-1, -1, -1};
     // reader: piece k of the file into comp[k & 1] behind the carry-over of piece k - 1 (a BGZF block cut by the piece border)
     uint64_t file_off = 0; size_t carry = 0; double t_read = 0, t_inflate = 0, t_wait = 0;
@@ -1268,7 +1275,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     auto start_read = [&](int slot, size_t keep) {
         const uint64_t at = file_off; const size_t want = (size_t)std::min<uint64_t>(PIECE, fsz - at);
         reader_on = true;
-        reader = std::thread([&, slot, keep, at, want] { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, comp[slot].data() + keep + o, want - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } got_next = (ssize_t)o; t_read += now_s() - r0; });
+        reader = std::thread([&, slot, keep, at, want] { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, comp[slot].p + keep + o, want - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } got_next = (ssize_t)o; t_read += now_s() - r0; });
         file_off += want;
     };
     int k = 0;
@@ -1278,7 +1285,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     uint64_t pushed = 0;
     while (have > 0) {
         const int cs = k & 1, ws = k % 3;
-        uint8_t *z = comp[cs].data();
+        uint8_t *z = comp[cs].p;
         // ---- BGZF members of this piece
         blocks.clear();
         size_t off = 0; uint64_t uoff = 0;
@@ -1305,7 +1312,19 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         if (!last && blocks.empty()) return done(GCE_ERR_INVALID, "BGZF block larger than a window");
         // ---- the next piece is read while this one is inflated
         carry = have - off;
-        if (!last) { memcpy(comp[cs ^ 1].data(), z + off, carry); start_read(cs ^ 1, carry); }
+        if (!last) {
+            if (comp_ticket[cs ^ 1] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, comp_ticket[cs ^ 1])) != GCE_OK) return done(rc, gce_last_error(e)); t_wait += now_s() - w0; comp_ticket[cs ^ 1] = -1; }   // (its members are in HBM)
+            memcpy(comp[cs ^ 1].p, z + off, carry); start_read(cs ^ 1, carry);
+        }
+        if (have_header && gpu_inflate) {                                               // this piece's members: to HBM as they are
+            z_coff.clear(); z_csize.clear(); z_usize.clear();
+            for (const Block &bk : blocks) { z_coff.push_back(bk.coff); z_csize.push_back(bk.csize); z_usize.push_back(bk.usize); }
+            if ((rc = gce_raw_push_bgzf(e, z, off, (int32_t)blocks.size(), z_coff.data(), z_csize.data(), z_usize.data(), &comp_ticket[cs])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
+            pushed += uoff;
+            if (reader_on) { reader.join(); reader_on = false; have = carry + (size_t)got_next; } else have = 0;
+            k++;
+            continue;
+        }
         if (win_ticket[ws] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, win_ticket[ws])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); } t_wait += now_s() - w0; win_ticket[ws] = -1; }
         if (!win[ws].ensure((size_t)uoff + 64)) { if (reader_on) reader.join(); return done(GCE_ERR_OOM, "out of pinned host memory"); }
         const double i0 = now_s();
@@ -1346,6 +1365,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
                     if (hdr_end + 36 < n) { const uint32_t lq = u[hdr_end + 12]; if (hdr_end + 36 + lq <= n) gce_detect_umi_prefix((const char *)u + hdr_end + 36, prm.umi_prefix); }
                 }
                 if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS before gce_create %ld MB (entry %ld MB)\n", status_kb("VmRSS:") >> 10, (long)(out->rss_start_kb >> 10));
+                lap("up to the header");
                 if ((rc = gce_create(&prm, &e)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_status_message(rc)); }
                 if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
                 if (fasta_path && *fasta_path) {
@@ -1357,10 +1377,12 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
                             if (names[t] == ids[c] && (rc = gce_set_reference_ascii(e, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
                     gce_fasta_free(fa); fa = nullptr;                                    // (packed in HBM: the host copy goes)
                 }
+                lap("gce_create + reference");
                 if ((rc = gce_raw_begin(e, (size_t)std::max<uint64_t>(fsz * 5, head.size()))) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
                 // what was inflated so far goes up in one piece (normally: this very window)
                 if (old) { int32_t tk; if ((rc = gce_raw_push(e, head.data(), old, &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); } pushed += old; }
                 head.release();
+                lap("gce_raw_begin + first push");
             }
         }
         if (have_header && uoff) {
@@ -1371,6 +1393,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         k++;
     }
     if (!have_header) return done(GCE_ERR_INVALID, fsz ? "truncated header" : "empty file");
+    lap("rest of the input loop");
     out->read_s = t_read; out->inflate_s = t_inflate; out->submit_s = t_wait;
     out->open_s = now_s() - t_start;
     if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after the input pipeline %ld MB\n", status_kb("VmRSS:") >> 10);

@@ -15,6 +15,7 @@
 #include "gce_deep.hpp"
 #include "gce_output.hpp"
 #include "gce_depth.hpp"
+#include "gce_inflate.hpp"
 
 namespace {
 
@@ -75,6 +76,7 @@ struct gce_engine {
     // the raw BAM stream in HBM (gce_bamdev.hpp)
     DevBuf raw, rw_bad, rw_guess, rw_leave, rw_cnt, rw_base, rw_misc, rw_tmp, rw_off, rw_ncig, rw_nmpos, rw_rsize, rw_roff, rw_body;
     size_t raw_n = 0; bool raw_mode = false; int64_t raw_records = 0; uint64_t raw_body_bytes = 0;
+    DevBuf z_comp, z_dir, z_err; size_t z_n = 0; std::vector<InfDir> z_members;      // BGZF members waiting for the GPU inflate (gce_raw_push_bgzf)
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
@@ -160,7 +162,7 @@ void gce_destroy(gce_engine *e) {
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
-    for (DevBuf *b : {&e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
+    for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }

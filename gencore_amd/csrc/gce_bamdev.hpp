@@ -241,7 +241,7 @@ int gce_raw_begin(gce_engine *e, size_t capacity_hint) {
         HIPCHK(e->b_nm.ensure(n1 * 4 + 64)); HIPCHK(e->b_nmt.ensure(n1 + 64)); HIPCHK(e->b_mioff.ensure(n1 * 8 + 64)); HIPCHK(e->rw_ncig.ensure(n1 * 4 + 64)); HIPCHK(e->rw_nmpos.ensure(n1 * 4 + 64));
         HIPCHK(e->b_cigar.ensure(n1 * 8 + 64));
     }
-    e->raw_n = 0; e->raw_mode = true; e->raw_records = 0;
+    e->raw_n = 0; e->raw_mode = true; e->raw_records = 0; e->z_n = 0; e->z_members.clear();
     return GCE_OK;
 }
 
@@ -266,6 +266,97 @@ int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket)
     return GCE_OK;
 }
 
+// BGZF members as they lie in the file (`comp`: host memory, comp_bytes; member k at coff[k], csize[k] bytes, ISIZE usize[k]) -> they are
+// copied to HBM compressed and inflated BY THE GPU (gce_inflate.hpp), in one launch, when gce_raw_finish is called; their bytes follow what
+// has been pushed so far.  Members with usize 0 (the EOF marker) may be passed or left out.  Asynchronous like gce_raw_push.
+int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_t n_members, const uint64_t *coff, const uint32_t *csize, const uint32_t *usize, int32_t *ticket) {
+    if (!e || !e->raw_mode || n_members < 0 || (n_members && (!comp || !coff || !csize || !usize))) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (e->z_n + comp_bytes + 64 > e->z_comp.cap) {
+        DevBuf nb;
+        HIPCHK(nb.ensure((e->z_n + comp_bytes) * 2 + 64));
+        if (e->z_n) HIPCHK(hipMemcpyAsync(nb.p, e->z_comp.p, e->z_n, hipMemcpyDeviceToDevice, e->up_stream));
+        HIPCHK(hipStreamSynchronize(e->up_stream));
+        e->z_comp.release(); e->z_comp = nb; nb.p = nullptr; nb.cap = 0;
+    }
+    if (comp_bytes) HIPCHK(hipMemcpyAsync((char *)e->z_comp.p + e->z_n, comp, comp_bytes, hipMemcpyHostToDevice, e->up_stream));
+    for (int32_t k = 0; k < n_members; k++) {
+        if (coff[k] + csize[k] > comp_bytes || usize[k] > 0x10000u) return fail(e, GCE_ERR_INVALID, "BGZF member outside its buffer");
+        if (usize[k] == 0) continue;
+        InfDir d; d.coff = e->z_n + coff[k]; d.uoff = e->raw_n; d.csize = csize[k]; d.usize = usize[k];
+        e->z_members.push_back(d); e->raw_n += usize[k];
+    }
+    e->z_n += comp_bytes;
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, e->up_stream));
+    e->up_events.push_back(ev);
+    if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    return GCE_OK;
+}
+
+// the launch behind gce_raw_push_bgzf: every member waiting, one lane each
+static int raw_inflate_pending(gce_engine *e) {
+    if (e->z_members.empty()) return GCE_OK;
+    hipStream_t s = e->stream;
+    if (e->raw_n + 256 > e->raw.cap) {                                             // (what host windows pushed so far lies at the front: keep it)
+        DevBuf nb;
+        HIPCHK(nb.ensure(e->raw_n + 256));
+        const size_t keep = (size_t)e->z_members.front().uoff;
+        if (keep) HIPCHK(hipMemcpyAsync(nb.p, e->raw.p, keep, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
+    }
+    const size_t n = e->z_members.size();
+    HIPCHK(e->z_dir.ensure(n * sizeof(InfDir))); HIPCHK(e->z_err.ensure(16));
+    HIPCHK(hipMemcpyAsync(e->z_dir.p, e->z_members.data(), n * sizeof(InfDir), hipMemcpyHostToDevice, s));
+    const unsigned int init[2] = {0u, 0xFFFFFFFFu};
+    HIPCHK(hipMemcpyAsync(e->z_err.p, init, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync((char *)e->z_comp.p + e->z_n, 0, 64, s));                 // (the bit reader looks 8 bytes ahead)
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + INF_T - 1) / INF_T)), dim3(INF_T), 0, s, e->z_comp.as<uint8_t>(), (const InfDir *)e->z_dir.p, (uint32_t)n, e->raw.as<uint8_t>(), e->z_err.as<unsigned int>());
+    unsigned int got[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(got, e->z_err.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    e->z_members.clear(); e->z_n = 0;
+    if (got[0]) { char m[96]; snprintf(m, sizeof m, "inflate / CRC failure in BGZF member %u of the GPU batch", got[1]); return fail(e, GCE_ERR_INVALID, m); }
+    return GCE_OK;
+}
+
+// BGZF members -> bytes, nothing else (tests, tools): the decoder of gce_raw_push_bgzf on buffers of the caller.  first_bad: -1 or the first
+// member that failed a check (its bytes and those of later failures are undefined).
+int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_t n_members, const uint64_t *coff, const uint32_t *csize, const uint32_t *usize, void *out, int32_t *first_bad) {
+    if (n_members < 0 || (n_members && (!comp || !coff || !csize || !usize || !out))) return GCE_ERR_INVALID;
+    if (first_bad) *first_bad = -1;
+    if (hipSetDevice(device) != hipSuccess) return GCE_ERR_NO_DEVICE;
+    std::vector<InfDir> dir; uint64_t total = 0;
+    for (int32_t k = 0; k < n_members; k++) {
+        if (coff[k] + csize[k] > comp_bytes || usize[k] > 0x10000u) return GCE_ERR_INVALID;
+        InfDir d; d.coff = coff[k]; d.uoff = total; d.csize = csize[k]; d.usize = usize[k]; dir.push_back(d); total += usize[k];
+    }
+    if (dir.empty()) return GCE_OK;
+    DevBuf zc, zd, ze, zo;
+    int rc = GCE_OK;
+    auto chk = [&](hipError_t x) { if (x != hipSuccess && rc == GCE_OK) rc = GCE_ERR_HIP; };
+    if (zc.ensure(comp_bytes + 64) != hipSuccess || zd.ensure(dir.size() * sizeof(InfDir)) != hipSuccess || ze.ensure(16) != hipSuccess || zo.ensure(total + 64) != hipSuccess) rc = GCE_ERR_OOM;
+    if (rc == GCE_OK) {
+        chk(hipMemcpy(zc.p, comp, comp_bytes, hipMemcpyHostToDevice)); chk(hipMemset((char *)zc.p + comp_bytes, 0, 64));
+        chk(hipMemcpy(zd.p, dir.data(), dir.size() * sizeof(InfDir), hipMemcpyHostToDevice));
+        const unsigned int init[2] = {0u, 0xFFFFFFFFu};
+        chk(hipMemcpy(ze.p, init, 8, hipMemcpyHostToDevice));
+        if (rc == GCE_OK) {
+            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((dir.size() + INF_T - 1) / INF_T)), dim3(INF_T), 0, 0, zc.as<uint8_t>(), (const InfDir *)zd.p, (uint32_t)dir.size(), zo.as<uint8_t>(), ze.as<unsigned int>());
+            chk(hipDeviceSynchronize()); chk(hipGetLastError());
+            unsigned int got[2] = {0, 0};
+            chk(hipMemcpy(got, ze.p, 8, hipMemcpyDeviceToHost));
+            if (total) chk(hipMemcpy(out, zo.p, total, hipMemcpyDeviceToHost));
+            if (rc == GCE_OK && got[0]) { if (first_bad) *first_bad = (int32_t)got[1]; rc = GCE_ERR_INVALID; }
+        }
+    }
+    zc.release(); zd.release(); ze.release(); zo.release();
+    return rc;
+}
+
 // The whole stream is in HBM: index the records behind `records_begin` (the end of the BAM header), build the batch.  Afterwards the engine is
 // in the state gce_submit_device leaves it in: gce_process, then gce_drain / gce_result_device or gce_raw_build_output.
 int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records) {
@@ -277,6 +368,8 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
     lap("wait for the last copies");
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     e->up_events.clear();
+    { const int zr = raw_inflate_pending(e); if (zr != GCE_OK) return zr; }
+    lap("BGZF members inflated by the GPU");
     hipStream_t s = e->stream;
     const uint8_t *u = e->raw.as<uint8_t>();
     const uint64_t total = e->raw_n;

@@ -396,6 +396,13 @@ int gce_run_bam_hostcodec(const char *in_path, const char *out_path, const char 
  *     copies a piece of it to the host (ticket -> gce_submit_wait). */
 int gce_raw_begin(gce_engine *e, size_t capacity_hint);
 int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket);
+/* BGZF members as they lie in the file: copied to HBM COMPRESSED and inflated by the GPU (one lane per member, CRC-32 and ISIZE checked) when
+ * gce_raw_finish is called -- replaces bgzf_read's inflate under sam_read1 (src/gencore.cpp:205-274 via htslib); member k lies at comp + coff[k],
+ * csize[k] bytes (its BSIZE + 1), usize[k] = its ISIZE.  Their bytes follow what was pushed before.  A damaged member makes gce_raw_finish
+ * fail with GCE_ERR_INVALID. */
+int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_t n_members, const uint64_t *coff, const uint32_t *csize, const uint32_t *usize, int32_t *ticket);
+/* The same decoder on the caller's buffers (tests, tools): out receives the members' bytes back to back; first_bad = -1 or the first damaged member. */
+int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_t n_members, const uint64_t *coff, const uint32_t *csize, const uint32_t *usize, void *out, int32_t *first_bad);
 int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records);
 int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
 int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
