@@ -308,12 +308,12 @@ static int raw_inflate_pending(gce_engine *e) {
         e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
     }
     const size_t n = e->z_members.size();
-    HIPCHK(e->z_dir.ensure(n * sizeof(InfDir))); HIPCHK(e->z_err.ensure(16));
+    HIPCHK(e->z_dir.ensure(n * sizeof(InfDir) + n * INF_NSYM)); HIPCHK(e->z_err.ensure(16));
     HIPCHK(hipMemcpyAsync(e->z_dir.p, e->z_members.data(), n * sizeof(InfDir), hipMemcpyHostToDevice, s));
     const unsigned int init[2] = {0u, 0xFFFFFFFFu};
     HIPCHK(hipMemcpyAsync(e->z_err.p, init, 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync((char *)e->z_comp.p + e->z_n, 0, 64, s));                 // (the bit reader looks 8 bytes ahead)
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + INF_T - 1) / INF_T)), dim3(INF_T), 0, s, e->z_comp.as<uint8_t>(), (const InfDir *)e->z_dir.p, (uint32_t)n, e->raw.as<uint8_t>(), e->z_err.as<unsigned int>());
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + INF_T - 1) / INF_T)), dim3(INF_T), 0, s, e->z_comp.as<uint8_t>(), (const InfDir *)e->z_dir.p, (uint32_t)n, e->raw.as<uint8_t>(), e->z_err.as<unsigned int>(), e->z_dir.as<uint8_t>() + n * sizeof(InfDir));
     unsigned int got[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(got, e->z_err.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -338,14 +338,14 @@ int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_
     DevBuf zc, zd, ze, zo;
     int rc = GCE_OK;
     auto chk = [&](hipError_t x) { if (x != hipSuccess && rc == GCE_OK) rc = GCE_ERR_HIP; };
-    if (zc.ensure(comp_bytes + 64) != hipSuccess || zd.ensure(dir.size() * sizeof(InfDir)) != hipSuccess || ze.ensure(16) != hipSuccess || zo.ensure(total + 64) != hipSuccess) rc = GCE_ERR_OOM;
+    if (zc.ensure(comp_bytes + 64) != hipSuccess || zd.ensure(dir.size() * (sizeof(InfDir) + INF_NSYM)) != hipSuccess || ze.ensure(16) != hipSuccess || zo.ensure(total + 64) != hipSuccess) rc = GCE_ERR_OOM;
     if (rc == GCE_OK) {
         chk(hipMemcpy(zc.p, comp, comp_bytes, hipMemcpyHostToDevice)); chk(hipMemset((char *)zc.p + comp_bytes, 0, 64));
         chk(hipMemcpy(zd.p, dir.data(), dir.size() * sizeof(InfDir), hipMemcpyHostToDevice));
         const unsigned int init[2] = {0u, 0xFFFFFFFFu};
         chk(hipMemcpy(ze.p, init, 8, hipMemcpyHostToDevice));
         if (rc == GCE_OK) {
-            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((dir.size() + INF_T - 1) / INF_T)), dim3(INF_T), 0, 0, zc.as<uint8_t>(), (const InfDir *)zd.p, (uint32_t)dir.size(), zo.as<uint8_t>(), ze.as<unsigned int>());
+            hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((dir.size() + INF_T - 1) / INF_T)), dim3(INF_T), 0, 0, zc.as<uint8_t>(), (const InfDir *)zd.p, (uint32_t)dir.size(), zo.as<uint8_t>(), ze.as<unsigned int>(), zd.as<uint8_t>() + dir.size() * sizeof(InfDir));
             chk(hipDeviceSynchronize()); chk(hipGetLastError());
             unsigned int got[2] = {0, 0};
             chk(hipMemcpy(got, ze.p, 8, hipMemcpyDeviceToHost));

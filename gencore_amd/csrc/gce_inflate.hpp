@@ -31,12 +31,25 @@ __device__ __constant__ uint8_t INF_CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 
 typedef uint64_t inf_u64u __attribute__((aligned(1)));
 
 struct InfBits {
-    const uint8_t *p, *end;                  // next byte to load; end of the member's deflate data
+    const uint8_t *p, *end;                  // next byte to move into the buffer; end of the member's deflate data
     uint64_t buf; int cnt;
+    // the stream is consumed strictly forward, but where a refill reads depends on the bits consumed so far -- one load per symbol on the
+    // critical path, a microsecond each.  Three aligned words ahead are kept in registers (q0 holds *p): the word a refill needs was asked
+    // for two words (five to ten symbols) earlier.
+    uint64_t q0, q1, q2; const uint64_t *wp;
+    __device__ __forceinline__ void start(const uint8_t *at) {
+        const uint64_t *a = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(at) & ~(uintptr_t)7);
+        q0 = a[0]; q1 = a[1]; q2 = a[2]; wp = a + 3; p = at; buf = 0; cnt = 0;
+    }
     __device__ __forceinline__ void refill() {                                       // afterwards cnt >= 56 (bytes past `end` are padding / the next member: never consumed, see over())
-        buf |= *(const inf_u64u *)p << cnt;
+        const int sh = 8 * (int)(reinterpret_cast<uintptr_t>(p) & 7);
+        const uint64_t w = sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
+        buf |= w << cnt;
         const int adv = (63 - cnt) >> 3;
-        p += adv; cnt += adv * 8;
+        cnt += adv * 8;
+        const uint8_t *np = p + adv;
+        if ((reinterpret_cast<uintptr_t>(np) ^ reinterpret_cast<uintptr_t>(p)) & ~(uintptr_t)7) { q0 = q1; q1 = q2; q2 = *wp++; }      // (adv <= 7: at most one word boundary)
+        p = np;
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1ull)); }
     __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
@@ -65,11 +78,11 @@ __device__ __forceinline__ int inf_decode(InfBits &in, const InfCnt &c, const ui
     return -1;
 }
 
-// lengths[0..n) (this lane's column of s_len) -> counts + symbol permutation; false: over-subscribed or (for more than one code) incomplete
+// lengths[0..n) (this member's scratch in device memory) -> counts + symbol permutation; false: over-subscribed or (for more than one code) incomplete
 template <int BITS, int PER>
 __device__ bool inf_construct(const uint8_t *len, int n, InfCnt &c, uint16_t *sym, uint16_t *offs /* 16 entries, column */) {
     for (int l = 0; l <= 15; l++) offs[l * INF_T] = 0;
-    for (int s = 0; s < n; s++) offs[len[s * INF_T] * INF_T]++;                       // (counts, parked in offs)
+    for (int s = 0; s < n; s++) offs[len[s] * INF_T]++;                       // (counts, parked in offs)
     int left = 1; uint32_t cnt[16];
     cnt[0] = offs[0];
 #pragma unroll
@@ -80,7 +93,7 @@ __device__ bool inf_construct(const uint8_t *len, int n, InfCnt &c, uint16_t *sy
     uint32_t o = 0;
 #pragma unroll
     for (int l = 1; l <= 15; l++) { offs[l * INF_T] = (uint16_t)o; o += cnt[l]; }
-    for (int s = 0; s < n; s++) { const int l = len[s * INF_T]; if (l) { sym[offs[l * INF_T] * INF_T] = (uint16_t)s; offs[l * INF_T]++; } }
+    for (int s = 0; s < n; s++) { const int l = len[s]; if (l) { sym[offs[l * INF_T] * INF_T] = (uint16_t)s; offs[l * INF_T]++; } }
     return left == 0 || (int)cnt[0] + 1 >= n;                                         // complete, or a single code (RFC 1951 allows one distance code of one bit)
 }
 
@@ -92,9 +105,10 @@ __device__ __forceinline__ uint32_t inf_crc_word(const uint32_t (*tab)[256], uin
 }  // namespace
 
 // One lane per member.  err[0] |= 1 if any member is damaged (its number goes to err[1] by atomicMin).
-__global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, const InfDir *dir, uint32_t n_members, uint8_t *out, unsigned int *err) {
+// lens: INF_NSYM bytes of scratch per member (the code lengths of a dynamic block while its tables are built: in LDS they were 20 KB of the 70 KB
+// that allowed two workgroups per CU -- 580 workgroups of a 565 MB file then ran in two rounds)
+__global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, const InfDir *dir, uint32_t n_members, uint8_t *out, unsigned int *err, uint8_t *lens) {
     __shared__ uint16_t s_sym[INF_NSYM][INF_T];
-    __shared__ uint8_t s_len[INF_NSYM][INF_T];
     __shared__ uint16_t s_off[16][INF_T];
     __shared__ uint32_t s_crc[8][256];
     const int lane = threadIdx.x;
@@ -118,9 +132,9 @@ __global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, con
         const uint32_t xlen = (uint32_t)src[10] | (uint32_t)src[11] << 8;
         ok = 12u + xlen + 8u <= d.csize;
         if (ok) {
-            InfBits in; in.p = src + 12 + xlen; in.end = src + d.csize - 8; in.buf = 0; in.cnt = 0;
+            InfBits in; in.end = src + d.csize - 8; in.start(src + 12 + xlen);
             uint16_t *sym_l = &s_sym[0][lane], *sym_d = &s_sym[288][lane], *offs = &s_off[0][lane];
-            uint8_t *len = &s_len[0][lane];
+            uint8_t *len = lens + (size_t)m * INF_NSYM;
             InfCnt cl, cd;
             int last = 0;
             while (ok && !last) {
@@ -136,20 +150,20 @@ __global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, con
                     if (q + ln > in.end) { ok = false; break; }
                     for (uint32_t k = 0; k < ln; k++) o[pos + k] = q[k];
                     pos += ln;
-                    in.p = q + ln; in.buf = 0; in.cnt = 0;
+                    in.start(q + ln);
                     continue;
                 }
                 if (type == 3) { ok = false; break; }
                 if (type == 1) {                                                      // fixed codes (RFC 1951 3.2.6)
-                    for (int s = 0; s < 288; s++) len[s * INF_T] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-                    for (int s = 0; s < 30; s++) len[(288 + s) * INF_T] = 5;
+                    for (int s = 0; s < 288; s++) len[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                    for (int s = 0; s < 30; s++) len[(288 + s)] = 5;
                     if (!inf_construct<10, 3>(len, 288, cl, sym_l, offs)) { ok = false; break; }
-                    (void)inf_construct<6, 5>(len + 288 * INF_T, 30, cd, sym_d, offs);
+                    (void)inf_construct<6, 5>(len + 288, 30, cd, sym_d, offs);
                 } else {                                                              // dynamic codes (3.2.7)
                     const int nlen = (int)in.take(5) + 257, ndist = (int)in.take(5) + 1, ncode = (int)in.take(4) + 4;
                     if (nlen > 286 || ndist > 30) { ok = false; break; }
-                    for (int k = 0; k < 19; k++) len[k * INF_T] = 0;
-                    for (int k = 0; k < ncode; k++) { if (in.cnt < 3) in.refill(); len[INF_CLORD[k] * INF_T] = (uint8_t)in.take(3); }
+                    for (int k = 0; k < 19; k++) len[k] = 0;
+                    for (int k = 0; k < ncode; k++) { if (in.cnt < 3) in.refill(); len[INF_CLORD[k]] = (uint8_t)in.take(3); }
                     InfCnt cc;
                     uint16_t *sym_c = sym_d;                                          // the code length code's permutation: in the distance part, which is rebuilt below
                     if (!inf_construct<10, 3>(len, 19, cc, sym_c, offs)) { ok = false; break; }
@@ -158,24 +172,24 @@ __global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, con
                         in.refill();
                         const int s = inf_decode<10, 3>(in, cc, sym_c);
                         if (s < 0) { ok = false; break; }
-                        if (s < 16) len[idx++ * INF_T] = (uint8_t)s;
+                        if (s < 16) len[idx++] = (uint8_t)s;
                         else {
                             int prev = 0, rep;
-                            if (s == 16) { if (idx == 0) { ok = false; break; } prev = len[(idx - 1) * INF_T]; rep = 3 + (int)in.take(2); }
+                            if (s == 16) { if (idx == 0) { ok = false; break; } prev = len[(idx - 1)]; rep = 3 + (int)in.take(2); }
                             else if (s == 17) rep = 3 + (int)in.take(3);
                             else rep = 11 + (int)in.take(7);
                             if (idx + rep > nlen + ndist) { ok = false; break; }
-                            while (rep--) len[idx++ * INF_T] = (uint8_t)prev;
+                            while (rep--) len[idx++] = (uint8_t)prev;
                         }
                     }
                     if (!ok) break;
-                    if (len[256 * INF_T] == 0) { ok = false; break; }                 // no end-of-block code
+                    if (len[256] == 0) { ok = false; break; }                 // no end-of-block code
                     // distance lengths lie behind the literal / length ones: move them to their own place before either table is built
-                    for (int k = ndist - 1; k >= 0; k--) len[(288 + k) * INF_T] = len[(nlen + k) * INF_T];
-                    for (int k = nlen; k < 288; k++) len[k * INF_T] = 0;
-                    for (int k = ndist; k < 30; k++) len[(288 + k) * INF_T] = 0;
+                    for (int k = ndist - 1; k >= 0; k--) len[(288 + k)] = len[(nlen + k)];
+                    for (int k = nlen; k < 288; k++) len[k] = 0;
+                    for (int k = ndist; k < 30; k++) len[(288 + k)] = 0;
                     if (!inf_construct<10, 3>(len, 288, cl, sym_l, offs)) { ok = false; break; }
-                    if (!inf_construct<6, 5>(len + 288 * INF_T, 30, cd, sym_d, offs)) { ok = false; break; }
+                    if (!inf_construct<6, 5>(len + 288, 30, cd, sym_d, offs)) { ok = false; break; }
                 }
                 // ---- the block's symbols
                 for (;;) {
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, con
                 }
             }
             ok = ok && !in.over() && pos == usize;
+#ifndef INF_NO_CRC
             if (ok) {                                                                 // CRC-32 over what was written
                 uint32_t crc = 0xFFFFFFFFu, k = 0;
                 for (; k + 8 <= usize; k += 8) crc = inf_crc_word(s_crc, crc, *(const inf_u64u *)(o + k));
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(INF_T) void k_bgzf_inflate(const uint8_t *comp, con
                 const uint32_t want = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
                 ok = crc == want;
             }
+#endif
         }
     }
     if (!ok) { atomicOr(&err[0], 1u); atomicMin(&err[1], m); }
