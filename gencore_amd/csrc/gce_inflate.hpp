@@ -2,7 +2,7 @@
 // src/gencore.cpp:205-274): the file goes over PCIe compressed (a quarter of the bytes) and the host inflates nothing but the header.
 //
 // A BGZF member is an independent raw-deflate stream of <= 64 KB (RFC 1951 inside the gzip framing of SAM spec 4.1), so the file is tens
-// of thousands of independent serial problems: ONE LANE PER MEMBER, a workgroup = one wave of 64 members.  Per lane:
+// of thousands of independent serial problems: ONE LANE PER MEMBER, a workgroup = 32 members (half a wave).  Per lane:
 //   * a 64-bit bit buffer refilled with one unaligned 8-byte load per symbol (a literal / length code, its extra bits, a distance code and
 //     its extra bits are at most 48 bits);
 //   * canonical Huffman decoding without lookup tables (the count of codes per length, 15 x 10 bits and 15 x 6 bits, lives in registers;
@@ -16,7 +16,9 @@
 // Every input read is bounded by the member (the staging buffer is padded by 16 bytes), every output write by ISIZE.
 #pragma once
 
-#define INF_T 64
+#ifndef INF_T
+#define INF_T 32            // members per workgroup (half a wave: less divergence than 64, measured 49.7 vs 53.7 ms on the cfg3 file; 16: 79.7)
+#endif
 #define INF_NSYM 320                         // 288 literal / length symbols, then 32 distance symbols
 struct InfDir { uint64_t coff, uoff; uint32_t csize, usize; };
 
