@@ -1275,7 +1275,16 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     auto start_read = [&](int slot, size_t keep) {
         const uint64_t at = file_off; const size_t want = (size_t)std::min<uint64_t>(PIECE, fsz - at);
         reader_on = true;
-        reader = std::thread([&, slot, keep, at, want] { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, comp[slot].p + keep + o, want - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } got_next = (ssize_t)o; t_read += now_s() - r0; });
+        reader = std::thread([&, slot, keep, at, want] {                                    // the piece in up to four parts, read side by side (one pread stream copies ~7 GB/s out of the page cache)
+            const double r0 = now_s();
+            const int R = (int)std::max<size_t>(1, std::min<size_t>({(size_t)4, (size_t)T, want >> 20}));
+            std::vector<size_t> done_(R, 0); std::vector<std::thread> sub;
+            auto part = [&](int r) { const size_t a = want * (size_t)r / R, z2 = want * (size_t)(r + 1) / R; size_t o = a; while (o < z2) { const ssize_t g = pread(fd, comp[slot].p + keep + o, z2 - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } done_[r] = o - a; };
+            for (int r = 1; r < R; r++) sub.emplace_back(part, r);
+            part(0);
+            for (auto &t : sub) t.join();
+            size_t o = 0; for (int r = 0; r < R; r++) { const size_t a = want * (size_t)r / R, z2 = want * (size_t)(r + 1) / R; o += done_[r]; if (done_[r] != z2 - a) break; }      // (bytes in order up to the first short part)
+            got_next = (ssize_t)o; t_read += now_s() - r0; });
         file_off += want;
     };
     int k = 0;

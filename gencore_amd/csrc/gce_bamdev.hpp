@@ -274,7 +274,7 @@ int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_
     (void)hipSetDevice(e->prm.device);
     if (e->z_n + comp_bytes + 64 > e->z_comp.cap) {
         DevBuf nb;
-        HIPCHK(nb.ensure((e->z_n + comp_bytes) * 2 + 64));
+        HIPCHK(nb.ensure(std::max<size_t>((e->z_n + comp_bytes) * 2, e->raw.cap / 4) + 64));     // (gce_raw_begin sized the raw stream for ~5 x the file: a quarter of it holds the file, no second growth)
         if (e->z_n) HIPCHK(hipMemcpyAsync(nb.p, e->z_comp.p, e->z_n, hipMemcpyDeviceToDevice, e->up_stream));
         HIPCHK(hipStreamSynchronize(e->up_stream));
         e->z_comp.release(); e->z_comp = nb; nb.p = nullptr; nb.cap = 0;
