@@ -307,19 +307,31 @@ static int raw_inflate_pending(gce_engine *e) {
         HIPCHK(hipStreamSynchronize(s));
         e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
     }
-    const size_t n = e->z_members.size();
-    HIPCHK(e->z_dir.ensure(n * sizeof(InfDir) + n * INF_NSYM)); HIPCHK(e->z_err.ensure(16));
+    const size_t n = e->z_members.size(), LAUNCH = (size_t)1 << 18;                // members per launch: bounds the code-length scratch (320 bytes per member of a launch)
+    HIPCHK(e->z_dir.ensure(n * sizeof(InfDir) + std::min(n, LAUNCH) * INF_NSYM)); HIPCHK(e->z_err.ensure(16));
     HIPCHK(hipMemcpyAsync(e->z_dir.p, e->z_members.data(), n * sizeof(InfDir), hipMemcpyHostToDevice, s));
     const unsigned int init[2] = {0u, 0xFFFFFFFFu};
     HIPCHK(hipMemcpyAsync(e->z_err.p, init, 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync((char *)e->z_comp.p + e->z_n, 0, 64, s));                 // (the bit reader looks 8 bytes ahead)
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + INF_T - 1) / INF_T)), dim3(INF_T), 0, s, e->z_comp.as<uint8_t>(), (const InfDir *)e->z_dir.p, (uint32_t)n, e->raw.as<uint8_t>(), e->z_err.as<unsigned int>(), e->z_dir.as<uint8_t>() + n * sizeof(InfDir));
-    unsigned int got[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(got, e->z_err.p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemsetAsync((char *)e->z_comp.p + e->z_n, 0, 64, s));                 // (the bit reader looks up to 32 bytes ahead)
+    unsigned int got[2] = {0, 0}; uint32_t bad_member = 0xFFFFFFFFu;
+    for (size_t base = 0; base < n; base += LAUNCH) {
+        const size_t m = std::min(LAUNCH, n - base);
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((m + INF_T - 1) / INF_T)), dim3(INF_T), 0, s, e->z_comp.as<uint8_t>(), (const InfDir *)e->z_dir.p + base, (uint32_t)m, e->raw.as<uint8_t>(), e->z_err.as<unsigned int>(),
+                           e->z_dir.as<uint8_t>() + n * sizeof(InfDir));
+        if (base + LAUNCH < n) {                                                   // (the member number of a failure is relative to its launch: fetch it per launch when there are several)
+            HIPCHK(hipMemcpyAsync(got, e->z_err.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            if (got[0]) { bad_member = (uint32_t)base + got[1]; break; }
+        }
+    }
+    if (bad_member == 0xFFFFFFFFu) {
+        HIPCHK(hipMemcpyAsync(got, e->z_err.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (got[0]) bad_member = (uint32_t)((n - 1) / LAUNCH * LAUNCH) + got[1];
+    }
     HIPCHK(hipGetLastError());
+    e->z_comp.release();                                                           // (the compressed copy of the file: not needed while the stream is processed)
     e->z_members.clear(); e->z_n = 0;
-    if (got[0]) { char m[96]; snprintf(m, sizeof m, "inflate / CRC failure in BGZF member %u of the GPU batch", got[1]); return fail(e, GCE_ERR_INVALID, m); }
+    if (bad_member != 0xFFFFFFFFu) { char m[96]; snprintf(m, sizeof m, "inflate / CRC failure in BGZF member %u of the GPU batch", bad_member); return fail(e, GCE_ERR_INVALID, m); }
     return GCE_OK;
 }
 
