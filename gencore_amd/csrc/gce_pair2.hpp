@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
         if (rounds > 0) {
             const int src = hb + (plane < 0 ? hl : plane);
-            const uint64_t q0 = shfl64(ruw[0], src), q1 = shfl64(ruw[1], src), q2 = shfl64(ruw[2], src);
+            const uint64_t q0 = shfl64(ruw[0], src);
             const int qul = __shfl(ul, src);
-            if (plane >= 0 && qul != 0 && !(qul == ul && q0 == ruw[0] && q1 == ruw[1] && q2 == ruw[2])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
+            bool same = qul == ul && q0 == ruw[0];
+            if (wave_max_u(act2 ? ul : 0) > 8) { const uint64_t q1 = shfl64(ruw[1], src), q2 = shfl64(ruw[2], src); same = same && q1 == ruw[1] && q2 == ruw[2]; }     // (wave-uniform)
+            if (plane >= 0 && qul != 0 && !same) raise_error(w.si, GCE_ERR_UMI_MISMATCH, my);
         }
     }
     const bool any_umi = sub_ballot<SUB>(act2 && last && ul > 0, hb) != 0;
@@ -242,8 +244,9 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             const int best = sub_max<SUB>(key);
             const uint32_t bm = sub_ballot<SUB>(key == best && key >= 0, hb);
             const int tl = hb + (bm ? __ffs((int)bm) - 1 : hl);
-            const uint64_t t0 = shfl64(uw[0], tl), t1 = shfl64(uw[1], tl), t2 = shfl64(uw[2], tl);
-            const int diff = popc_nonzero_bytes(t0 ^ uw[0]) + popc_nonzero_bytes(t1 ^ uw[1]) + popc_nonzero_bytes(t2 ^ uw[2]);   // Cluster::umiDiff
+            const uint64_t t0 = shfl64(uw[0], tl);
+            int diff = popc_nonzero_bytes(t0 ^ uw[0]);                                           // Cluster::umiDiff
+            if (!one_word) { const uint64_t t1 = shfl64(uw[1], tl), t2 = shfl64(uw[2], tl); diff += popc_nonzero_bytes(t1 ^ uw[1]) + popc_nonzero_bytes(t2 ^ uw[2]); }   // (wave-uniform: UMIs of <= 8 bytes end in the first word)
             const bool take = open && pact && g_of == NONE32 && diff <= thr;
             if (take) g_of = ngroups;
             remaining &= ~sub_ballot<SUB>(take, hb);
