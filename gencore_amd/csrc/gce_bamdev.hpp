@@ -299,10 +299,10 @@ int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_
 static int raw_inflate_pending(gce_engine *e) {
     if (e->z_members.empty()) return GCE_OK;
     hipStream_t s = e->stream;
-    if (e->raw_n + 256 > e->raw.cap) {                                             // (what host windows pushed so far lies at the front: keep it)
+    if (e->raw_n + 256 > e->raw.cap) {
         DevBuf nb;
         HIPCHK(nb.ensure(e->raw_n + 256));
-        const size_t keep = (size_t)e->z_members.front().uoff;
+        const size_t keep = std::min(e->raw_n, e->raw.cap);                        // (everything so far: host windows may lie between the members' places)
         if (keep) HIPCHK(hipMemcpyAsync(nb.p, e->raw.p, keep, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
