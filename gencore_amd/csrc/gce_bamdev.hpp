@@ -252,7 +252,8 @@ int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket)
     if (e->raw_n + bytes + 256 > e->raw.cap) {                                     // grow: the copies so far are in flight on the same stream, the move queues behind them
         DevBuf nb;
         HIPCHK(nb.ensure((e->raw_n + bytes) * 2 + 256));
-        if (e->raw_n) HIPCHK(hipMemcpyAsync(nb.p, e->raw.p, e->raw_n, hipMemcpyDeviceToDevice, e->up_stream));
+        const size_t keep = std::min(e->raw_n, e->raw.cap);                        // (members waiting for the GPU inflate have places, not bytes yet: they may lie past the old buffer)
+        if (keep) HIPCHK(hipMemcpyAsync(nb.p, e->raw.p, keep, hipMemcpyDeviceToDevice, e->up_stream));
         HIPCHK(hipStreamSynchronize(e->up_stream));
         e->raw.release(); e->raw = nb; nb.p = nullptr; nb.cap = 0;
     }
