@@ -507,3 +507,28 @@ def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, workload, n_p
     assert t1 == t2 and len(g1) == len(g2)
     for a, b in zip(g1, g2):                                                 # record by record, in file order
         assert a == b
+
+
+def test_stats_blocks_in_device_memory_equal_the_drained_ones(built):
+    """gce_stats_device: the two Stats blocks as they lie in HBM (what a multi-GPU run all-reduces, bench.py) are the ones gce_drain returns."""
+    import ctypes as C
+    from gencore_amd import capi
+    from gencore_amd.engine import Engine
+    batch, over, reference, contig_len = fuzzgen.make_case(77, n_mol=120, umi_mode="duplex")
+    E = Engine(fuzzgen.make_params(over, contig_len))
+    try:
+        E.run(batch, reference)
+        rows, pre, post = E.rows()
+        ptr = C.c_void_p()
+        assert E.lib.gce_stats_device(E._h, C.byref(ptr)) == 0 and ptr.value
+        hip = None
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                hip = C.CDLL(line.split()[-1]); break
+        assert hip is not None
+        host = np.zeros(2 * capi.GCE_STATS_WORDS, np.int64)
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), ptr, C.c_size_t(host.nbytes), 2) == 0
+        assert np.array_equal(host[:capi.GCE_STATS_WORDS], pre.as_array()) and np.array_equal(host[capi.GCE_STATS_WORDS:], post.as_array())
+        assert host[0] == batch.n
+    finally:
+        E.close()
