@@ -120,6 +120,24 @@ def write_batch_as_bam(path, batch, target_len, target_name=None, text="@HD\tVN:
         raise GceError(rc, "gce_bam_from_batch")
 
 
+def sam_to_bam(sam_path, bam_path, threads=0, level=6):
+    """gce_sam_to_bam: SAM text -> BAM on the host (what sam_read1 does with text under the reference, src/gencore.cpp:164,205)."""
+    lib = capi.load_library()
+    err = (C.c_char * 256)()
+    rc = lib.gce_sam_to_bam(str(sam_path).encode(), str(bam_path).encode(), threads, level, err)
+    if rc != 0:
+        raise GceError(rc, err.value.decode(errors="replace"))
+
+
+def bam_to_sam(bam_path, sam_path, threads=0):
+    """gce_bam_to_sam: BAM -> SAM text on the host (what sam_write1 prints for an output name that ends in "sam", src/gencore.cpp:170-173)."""
+    lib = capi.load_library()
+    err = (C.c_char * 256)()
+    rc = lib.gce_bam_to_sam(str(bam_path).encode(), str(sam_path).encode(), threads, err)
+    if rc != 0:
+        raise GceError(rc, err.value.decode(errors="replace"))
+
+
 def load_bed(path, target_names):
     """Bed::loadFromFile (src/bed.cpp:111-168): list of (tid, start, end, name) in file order; tid -1 = contig not in the header."""
     lib = capi.load_library()

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "gce_pack_reference", "gce_set_flush_events", "gce_submit", "gce_submit_device", "gce_process", "gce_drain", "gce_result_device",
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
-    "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch",
+    "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch", "gce_sam_to_bam", "gce_bam_to_sam",
     "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_raw_begin", "gce_raw_push", "gce_raw_push_bgzf", "gce_bgzf_inflate", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
 
 
@@ -185,6 +185,8 @@ def load_library(path=None, mode=C.RTLD_GLOBAL):
     lib.gce_bam_chunk.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(GceBatch)]
     lib.gce_bam_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(GceResult), C.c_int, C.c_int]
     lib.gce_bam_from_batch.argtypes = [C.c_char_p, C.POINTER(GceBatch), C.c_int32, C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.c_int]
+    lib.gce_sam_to_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+    lib.gce_bam_to_sam.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
     lib.gce_fasta_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.gce_fasta_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
     lib.gce_fasta_free.argtypes = [C.c_void_p]

@@ -27,6 +27,7 @@
 #include <unordered_map>
 #include <vector>
 #include "../../include/gencore_amd.h"
+#include "gce_samtext.hpp"
 
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
@@ -944,6 +945,76 @@ int gce_bam_from_batch(const char *path, const gce_batch *b, int32_t n_targets, 
     return write_bgzf(path, body, T, level);
 }
 
+// SAM text -> BAM and back on the host alone (no engine, no GPU): what sam_read1 / sam_write1 do when the reference is given SAM text
+// (src/gencore.cpp:164-173,205,104 via htslib); gce_run_bam takes and writes SAM text through the same line functions (gce_samtext.hpp).
+int gce_sam_to_bam(const char *sam_path, const char *bam_path, int threads, int level, char err[256]) {
+    auto fail = [&](const char *m) { if (err) { strncpy(err, m, 255); err[255] = 0; } return GCE_ERR_INVALID; };
+    if (err) err[0] = 0;
+    if (!sam_path || !bam_path) return GCE_ERR_INVALID;
+    const int T = threads > 0 ? threads : default_threads();
+    std::vector<char> tx;
+    if (!read_file(sam_path, tx)) return fail("cannot read the input SAM");
+    if (!tx.empty() && tx.back() != '\n') tx.push_back('\n');
+    const char *d = tx.data(); const size_t lim = tx.size();
+    size_t p = 0; std::string text;
+    while (p < lim && d[p] == '@') { const char *q = (const char *)memchr(d + p, '\n', lim - p); const size_t z = (size_t)(q - d) + 1; text.append(d + p, z - p); p = z; }
+    std::vector<std::string> names; std::vector<uint32_t> lens;
+    if (!samtext::parse_header_text(text, names, lens)) return fail("bad @SQ line");
+    samtext::NameMap nmap; nmap.build(names);
+    std::vector<std::vector<uint8_t>> parts((size_t)T); std::vector<std::string> perr((size_t)T);
+    std::vector<size_t> cut((size_t)T + 1, lim); cut[0] = p;
+    for (int t = 1; t < T; t++) { size_t c = p + (lim - p) * (size_t)t / (size_t)T; if (c > p) { const char *q = (const char *)memchr(d + c - 1, '\n', lim - (c - 1)); c = q ? (size_t)(q - d) + 1 : lim; } cut[(size_t)t] = std::max(c, cut[(size_t)t - 1]); }
+    std::atomic<int> bad{0};
+    parallel_for(T, T, [&](int, int64_t a, int64_t b2) {
+        for (int64_t t = a; t < b2; t++) {
+            size_t x = cut[(size_t)t]; const size_t xe = cut[(size_t)t + 1];
+            while (x < xe) {
+                const char *q = (const char *)memchr(d + x, '\n', lim - x); const size_t le = q ? (size_t)(q - d) : lim;
+                if (le > x && !(le == x + 1 && d[x] == '\r') && !samtext::line_to_bam(d + x, d + le, nmap, parts[(size_t)t], perr[(size_t)t])) { bad = 1; return; }
+                x = le + 1;
+            }
+        }
+    });
+    if (bad) { for (auto &m : perr) if (!m.empty()) return fail(m.c_str()); return fail("malformed SAM line"); }
+    std::vector<uint8_t> hdr;
+    auto put32 = [&](uint32_t x) { const uint8_t *q = (const uint8_t *)&x; hdr.insert(hdr.end(), q, q + 4); };
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32((uint32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end());
+    put32((uint32_t)lens.size());
+    for (size_t r = 0; r < lens.size(); r++) { put32((uint32_t)names[r].size() + 1); hdr.insert(hdr.end(), names[r].begin(), names[r].end()); hdr.push_back(0); put32(lens[r]); }
+    size_t tot = hdr.size(); for (auto &v : parts) tot += v.size();
+    Raw<uint8_t> body; body.resize(tot);
+    if (!body.ok()) return GCE_ERR_OOM;
+    memcpy(body.data(), hdr.data(), hdr.size());
+    size_t o = hdr.size(); for (auto &v : parts) { if (!v.empty()) memcpy(body.data() + o, v.data(), v.size()); o += v.size(); }
+    const int rc = write_bgzf(bam_path, body, T, level);
+    if (rc != GCE_OK) fail("cannot write the output BAM");
+    return rc;
+}
+
+int gce_bam_to_sam(const char *bam_path, const char *sam_path, int threads, char err[256]) {
+    auto fail = [&](const char *m) { if (err) { strncpy(err, m, 255); err[255] = 0; } return GCE_ERR_INVALID; };
+    if (err) err[0] = 0;
+    if (!bam_path || !sam_path) return GCE_ERR_INVALID;
+    const int T = threads > 0 ? threads : default_threads();
+    gce_bam *f = nullptr;
+    const int rc = gce_bam_open(bam_path, T, &f);
+    if (rc != GCE_OK) { fail(f ? f->err.c_str() : "cannot open the input BAM"); if (f) gce_bam_close(f); return rc; }
+    FILE *fo = fopen(sam_path, "w");
+    if (!fo) { gce_bam_close(f); return fail("cannot open the output SAM"); }
+    const std::string ht = samtext::header_text_for_sam(f->text, f->names, f->lens);
+    bool ok = fwrite(ht.data(), 1, ht.size(), fo) == ht.size();
+    std::vector<std::string> lines((size_t)T);
+    std::atomic<int> bad{0};
+    const size_t nr = f->rec.size();
+    parallel_for(T, T, [&](int, int64_t x, int64_t y) { for (int64_t t = x; t < y; t++) { std::string &L = lines[(size_t)t]; const size_t ra = nr * (size_t)t / (size_t)T, rb = nr * (size_t)(t + 1) / (size_t)T; for (size_t q = ra; q < rb; q++) if (!samtext::bam_to_line(f->u.data() + f->rec[q], f->names, L)) { bad = 1; return; } } });
+    for (int t = 0; t < T && ok && !bad; t++) ok = fwrite(lines[(size_t)t].data(), 1, lines[(size_t)t].size(), fo) == lines[(size_t)t].size();
+    ok = (fclose(fo) == 0) && ok;
+    gce_bam_close(f);
+    if (bad) return fail("bad record in the input BAM");
+    return ok ? GCE_OK : fail("cannot write the output SAM");
+}
+
 // ------------------------------------------------------------------------------------------------------------ FASTA
 // FastaReader(file) + readAll (src/fastareader.cpp:7-41,57-104,157-168) with its quirks: the FIRST character of every line is
 // taken by get(c) and appended without the validity filter of str_keep_valid_sequence (util.h:194-210) -- an empty line inside a
@@ -1287,11 +1358,121 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
             got_next = (ssize_t)o; t_read += now_s() - r0; });
         file_off += want;
     };
+    int rc = GCE_OK;
+    std::string emsg;
+    // the contig table is known (BAM header / SAM header lines): engine, reference, raw stream.  first_qname: the first record's name or NULL
+    auto setup_engine = [&](const char *first_qname, size_t capacity) -> int {
+        have_header = true;
+        prm.n_targets = (int32_t)lens.size(); prm.target_len = lens.data();
+        if (strcmp(prm.umi_prefix, "auto") == 0) {                                       // src/gencore.cpp:207-220: the first record's name
+            memset(prm.umi_prefix, 0, sizeof prm.umi_prefix);
+            if (first_qname) gce_detect_umi_prefix(first_qname, prm.umi_prefix);
+        }
+        if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS before gce_create %ld MB (entry %ld MB)\n", status_kb("VmRSS:") >> 10, (long)(out->rss_start_kb >> 10));
+        lap("up to the header");
+        int r2;
+        if ((r2 = gce_create(&prm, &e)) != GCE_OK) { emsg = gce_status_message(r2); return r2; }
+        if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
+        if (fasta_path && *fasta_path) {
+            if ((r2 = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) { emsg = "cannot read the FASTA file"; return r2; }
+            int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *flen;
+            gce_fasta_get(fa, &nc, &ids, &seqs, &flen);
+            for (size_t t = 0; t < lens.size(); t++)                                     // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+                for (int32_t c = 0; c < nc; c++)
+                    if (names[t] == ids[c] && (r2 = gce_set_reference_ascii(e, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { emsg = gce_last_error(e); return r2; }
+            gce_fasta_free(fa); fa = nullptr;                                            // (packed in HBM: the host copy goes)
+        }
+        lap("gce_create + reference");
+        if ((r2 = gce_raw_begin(e, capacity)) != GCE_OK) { emsg = gce_last_error(e); return r2; }
+        return GCE_OK;
+    };
+    auto bam_header_bytes = [&]() {                                                       // BAM magic, text, contig table (SAMv1 4.2)
+        std::vector<uint8_t> hdr;
+        auto put32 = [&](uint32_t x) { const uint8_t *p = (const uint8_t *)&x; hdr.insert(hdr.end(), p, p + 4); };
+        hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+        put32((uint32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end());
+        put32((uint32_t)lens.size());
+        for (size_t r = 0; r < lens.size(); r++) { put32((uint32_t)names[r].size() + 1); hdr.insert(hdr.end(), names[r].begin(), names[r].end()); hdr.push_back(0); put32(lens[r]); }
+        return hdr;
+    };
+    uint64_t pushed = 0;
+    // sam_open(in, "r") takes either format (src/gencore.cpp:164): a file that does not start with the gzip magic is SAM text
+    bool is_sam = false;
+    { uint8_t m2[2] = {0, 0}; is_sam = fsz > 0 && !(fsz >= 2 && pread(fd, m2, 2, 0) == 2 && m2[0] == 0x1f && m2[1] == 0x8b); }
+    if (is_sam) {
+        // Pieces of the text are cut at line feeds; the '@' lines in front give the header text and the contig table; alignment lines become BAM
+        // records on all host threads (gce_samtext.hpp) in a pinned window that goes to HBM like an inflated BAM window, behind BAM header bytes
+        // made from the SAM header: from there on the stream is the one a BAM file gives.
+        std::vector<char> tb; size_t tcarry = 0; uint64_t at = 0; bool in_header = true; samtext::NameMap nmap; int wk = 0;
+        std::vector<std::vector<uint8_t>> parts((size_t)T); std::vector<std::string> perr((size_t)T);
+        const size_t TP = PIECE * 4;
+        while (at < fsz || tcarry) {
+            const size_t want = (size_t)std::min<uint64_t>(TP, fsz - at);
+            tb.resize(tcarry + want + 1);
+            { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, tb.data() + tcarry + o, want - o, (off_t)(at + o)); if (g <= 0) return done(GCE_ERR_INVALID, "cannot read the input SAM"); o += (size_t)g; } t_read += now_s() - r0; }
+            at += want;
+            const size_t n = tcarry + want; const bool last = at >= fsz;
+            size_t lim = n;
+            if (!last) {
+                const char *nl = (const char *)memrchr(tb.data(), '\n', n);
+                if (!nl) { if (n > ((size_t)256 << 20)) return done(GCE_ERR_INVALID, "SAM line longer than 256 MB"); tcarry = n; continue; }
+                lim = (size_t)(nl - tb.data()) + 1;
+            } else if (n && tb[n - 1] != '\n') { tb[n] = '\n'; lim = n + 1; }
+            size_t p = 0;
+            if (in_header) {
+                while (p < lim && tb[p] == '@') { const char *q = (const char *)memchr(tb.data() + p, '\n', lim - p); const size_t z2 = (size_t)(q - tb.data()) + 1; text.append(tb.data() + p, z2 - p); p = z2; }
+                if (p < lim || last) {
+                    in_header = false;
+                    if (!samtext::parse_header_text(text, names, lens) || lens.empty()) return done(GCE_ERR_INVALID, "this SAM file has no header");      // src/gencore.cpp:186-189
+                    nmap.build(names);
+                    std::string fq;
+                    if (p < lim) { const char *q = tb.data() + p; const char *t = (const char *)memchr(q, '\t', lim - p); if (t) fq.assign(q, t); }
+                    if ((rc = setup_engine(fq.empty() ? nullptr : fq.c_str(), (size_t)std::max<uint64_t>(fsz + (1u << 20), 1u << 20))) != GCE_OK) return done(rc, emsg.c_str());
+                    const std::vector<uint8_t> hb = bam_header_bytes();
+                    hdr_end = hb.size();
+                    int32_t tk; if ((rc = gce_raw_push(e, hb.data(), hb.size(), &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) return done(rc, gce_last_error(e));
+                    pushed += hb.size();
+                }
+            }
+            if (!in_header && p < lim) {
+                const double i0 = now_s();
+                const char *d = tb.data();
+                std::vector<size_t> cut((size_t)T + 1, lim);                              // thread t converts the lines that START in [cut[t], cut[t + 1])
+                cut[0] = p;
+                for (int t = 1; t < T; t++) { size_t c = p + (lim - p) * (size_t)t / (size_t)T; if (c > p) { const char *q = (const char *)memchr(d + c - 1, '\n', lim - (c - 1)); c = q ? (size_t)(q - d) + 1 : lim; } cut[(size_t)t] = std::max(c, cut[(size_t)t - 1]); }
+                std::atomic<int> bad{0};
+                parallel_for(T, T, [&](int, int64_t a, int64_t b2) {
+                    for (int64_t t = a; t < b2; t++) {
+                        std::vector<uint8_t> &o = parts[(size_t)t]; o.clear();
+                        size_t x = cut[(size_t)t]; const size_t xe = cut[(size_t)t + 1];
+                        while (x < xe) {
+                            const char *q = (const char *)memchr(d + x, '\n', lim - x); const size_t le = q ? (size_t)(q - d) : lim;
+                            if (le > x && !(le == x + 1 && d[x] == '\r') && !samtext::line_to_bam(d + x, d + le, nmap, o, perr[(size_t)t])) { bad = 1; return; }
+                            x = le + 1;
+                        }
+                    }
+                });
+                t_inflate += now_s() - i0;
+                if (bad) { for (auto &m : perr) if (!m.empty()) return done(GCE_ERR_INVALID, m.c_str()); return done(GCE_ERR_INVALID, "malformed SAM line"); }
+                size_t tot = 0; std::vector<size_t> po((size_t)T + 1, 0);
+                for (int t = 0; t < T; t++) { po[(size_t)t] = tot; tot += parts[(size_t)t].size(); }
+                if (tot) {
+                    const int ws = wk % 3;
+                    if (win_ticket[ws] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, win_ticket[ws])) != GCE_OK) return done(rc, gce_last_error(e)); t_wait += now_s() - w0; win_ticket[ws] = -1; }
+                    if (!win[ws].ensure(tot + 64)) return done(GCE_ERR_OOM, "out of pinned host memory");
+                    parallel_for(T, T, [&](int, int64_t a, int64_t b2) { for (int64_t t = a; t < b2; t++) if (!parts[(size_t)t].empty()) memcpy(win[ws].p + po[(size_t)t], parts[(size_t)t].data(), parts[(size_t)t].size()); });
+                    if ((rc = gce_raw_push(e, win[ws].p, tot, &win_ticket[ws])) != GCE_OK) return done(rc, gce_last_error(e));
+                    pushed += tot; wk++;
+                }
+            }
+            tcarry = lim >= n ? 0 : n - lim;
+            if (tcarry) memmove(tb.data(), tb.data() + lim, tcarry);
+            if (last) break;
+        }
+    } else {
     int k = 0;
     size_t have = 0;                                    // bytes in comp[k & 1]: carry + piece
     if (fsz) { start_read(0, 0); reader.join(); reader_on = false; have = (size_t)got_next; }
-    int rc = GCE_OK;
-    uint64_t pushed = 0;
     while (have > 0) {
         const int cs = k & 1, ws = k % 3;
         uint8_t *z = comp[cs].p;
@@ -1367,27 +1548,9 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
             }
             if (!complete && last) { if (reader_on) reader.join(); return done(GCE_ERR_INVALID, "truncated header"); }
             if (complete) {
-                have_header = true;
-                prm.n_targets = (int32_t)lens.size(); prm.target_len = lens.data();
-                if (strcmp(prm.umi_prefix, "auto") == 0) {                               // src/gencore.cpp:207-220: the first record's name
-                    memset(prm.umi_prefix, 0, sizeof prm.umi_prefix);
-                    if (hdr_end + 36 < n) { const uint32_t lq = u[hdr_end + 12]; if (hdr_end + 36 + lq <= n) gce_detect_umi_prefix((const char *)u + hdr_end + 36, prm.umi_prefix); }
-                }
-                if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS before gce_create %ld MB (entry %ld MB)\n", status_kb("VmRSS:") >> 10, (long)(out->rss_start_kb >> 10));
-                lap("up to the header");
-                if ((rc = gce_create(&prm, &e)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_status_message(rc)); }
-                if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
-                if (fasta_path && *fasta_path) {
-                    if ((rc = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, "cannot read the FASTA file"); }
-                    int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *flen;
-                    gce_fasta_get(fa, &nc, &ids, &seqs, &flen);
-                    for (size_t t = 0; t < lens.size(); t++)                             // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
-                        for (int32_t c = 0; c < nc; c++)
-                            if (names[t] == ids[c] && (rc = gce_set_reference_ascii(e, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
-                    gce_fasta_free(fa); fa = nullptr;                                    // (packed in HBM: the host copy goes)
-                }
-                lap("gce_create + reference");
-                if ((rc = gce_raw_begin(e, (size_t)std::max<uint64_t>(fsz * 5, head.size()))) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); }
+                const char *fq = nullptr;                                                 // src/gencore.cpp:207-220: the first record's name
+                if (hdr_end + 36 < n) { const uint32_t lq = u[hdr_end + 12]; if (hdr_end + 36 + lq <= n) fq = (const char *)u + hdr_end + 36; }
+                if ((rc = setup_engine(fq, (size_t)std::max<uint64_t>(fsz * 5, head.size()))) != GCE_OK) { if (reader_on) reader.join(); return done(rc, emsg.c_str()); }
                 // what was inflated so far goes up in one piece (normally: this very window)
                 if (old) { int32_t tk; if ((rc = gce_raw_push(e, head.data(), old, &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) { if (reader_on) reader.join(); return done(rc, gce_last_error(e)); } pushed += old; }
                 head.release();
@@ -1401,6 +1564,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         if (reader_on) { reader.join(); reader_on = false; have = carry + (size_t)got_next; } else have = 0;
         k++;
     }
+    }   // (BAM input)
     if (!have_header) return done(GCE_ERR_INVALID, fsz ? "truncated header" : "empty file");
     lap("rest of the input loop");
     out->read_s = t_read; out->inflate_s = t_inflate; out->submit_s = t_wait;
@@ -1423,12 +1587,43 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after process + output records %ld MB\n", status_kb("VmRSS:") >> 10);
     }
     // ---- the output file: header bytes + the record stream from HBM, in pieces; deflate by all threads, written in order
-    std::vector<uint8_t> hdr;
-    auto put32 = [&](uint32_t x) { const uint8_t *p = (const uint8_t *)&x; hdr.insert(hdr.end(), p, p + 4); };
-    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
-    put32((uint32_t)text.size()); hdr.insert(hdr.end(), text.begin(), text.end());
-    put32((uint32_t)lens.size());
-    for (size_t r = 0; r < lens.size(); r++) { put32((uint32_t)names[r].size() + 1); hdr.insert(hdr.end(), names[r].begin(), names[r].end()); hdr.push_back(0); put32(lens[r]); }
+    const size_t opl = strlen(out_path);
+    if (opl >= 3 && strcmp(out_path + opl - 3, "sam") == 0) {
+        // an output name that ends in "sam" is written as SAM text (src/gencore.cpp:170-173: sam_open(out, "w")): the header text (with @SQ
+        // lines from the contig table if it has none), then the record stream piece by piece, records -> lines on all host threads
+        fo = fopen(out_path, "w");
+        if (!fo) return done(GCE_ERR_INVALID, "cannot open the output SAM");
+        const std::string ht = samtext::header_text_for_sam(text, names, lens);
+        if (fwrite(ht.data(), 1, ht.size(), fo) != ht.size()) return done(GCE_ERR_INVALID, "cannot write the output SAM");
+        const uint64_t OC = PIECE < ((size_t)8 << 20) ? ((uint64_t)64 << 10) : ((uint64_t)16 << 20);       // (tests: pieces that cut records)
+        const int64_t npieces = (int64_t)((body + OC - 1) / OC);
+        Pinned obuf[2]; int32_t otk[2] = {-1, -1};
+        auto fetch = [&](int64_t pc) -> int { const uint64_t a2 = (uint64_t)pc * OC, z2 = std::min<uint64_t>(body, a2 + OC); if (!obuf[pc & 1].ensure((size_t)(z2 - a2) + 64)) return GCE_ERR_OOM; return gce_raw_read_output_async(e, a2, obuf[pc & 1].p, (size_t)(z2 - a2), &otk[pc & 1]); };
+        std::vector<uint8_t> cur; std::vector<uint64_t> ro; std::vector<std::string> lines((size_t)T);
+        if (npieces > 0 && (rc = fetch(0)) != GCE_OK) return done(rc, "output piece");
+        for (int64_t pc = 0; pc < npieces; pc++) {
+            if (otk[pc & 1] >= 0 && (rc = gce_submit_wait(e, otk[pc & 1])) != GCE_OK) return done(rc, gce_last_error(e));
+            const uint64_t a2 = (uint64_t)pc * OC, z2 = std::min<uint64_t>(body, a2 + OC);
+            cur.insert(cur.end(), obuf[pc & 1].p, obuf[pc & 1].p + (z2 - a2));                // behind the record a piece border cut
+            if (pc + 1 < npieces && (rc = fetch(pc + 1)) != GCE_OK) return done(rc, "output piece");
+            ro.clear();
+            uint64_t o = 0;
+            while (o + 4 <= cur.size()) { const uint32_t bs = rd32(cur.data() + o); if (bs < 32) return done(GCE_ERR_INVALID, "bad record in the output stream"); if (o + 4 + bs > cur.size()) break; ro.push_back(o); o += 4ull + bs; }
+            std::atomic<int> bad{0};
+            parallel_for(T, T, [&](int, int64_t x, int64_t y) { for (int64_t t = x; t < y; t++) { std::string &L = lines[(size_t)t]; L.clear(); const size_t ra = ro.size() * (size_t)t / (size_t)T, rb = ro.size() * (size_t)(t + 1) / (size_t)T; for (size_t q = ra; q < rb; q++) if (!samtext::bam_to_line(cur.data() + ro[q], names, L)) { bad = 1; return; } } });
+            if (bad) return done(GCE_ERR_INVALID, "bad record in the output stream");
+            for (int t = 0; t < T; t++) if (!lines[(size_t)t].empty() && fwrite(lines[(size_t)t].data(), 1, lines[(size_t)t].size(), fo) != lines[(size_t)t].size()) return done(GCE_ERR_INVALID, "cannot write the output SAM");
+            cur.erase(cur.begin(), cur.begin() + (ptrdiff_t)o);
+        }
+        if (!cur.empty()) return done(GCE_ERR_INVALID, "truncated record at the end of the output stream");
+        const bool closed = fclose(fo) == 0; fo = nullptr;
+        if (!closed) return done(GCE_ERR_INVALID, "cannot write the output SAM");
+        out->write_s = now_s() - t0;
+        out->total_s = now_s() - t_start;
+        out->peak_rss_kb = status_kb("VmHWM:"); out->rss_end_kb = status_kb("VmRSS:");
+        return done(GCE_OK, "");
+    }
+    const std::vector<uint8_t> hdr = bam_header_bytes();
     fo = fopen(out_path, "wb");
     if (!fo) return done(GCE_ERR_INVALID, "cannot open the output BAM");
     const uint64_t BS = 0xff00, OC = BS * 256, total = hdr.size() + body;

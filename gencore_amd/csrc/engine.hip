@@ -426,6 +426,16 @@ static int read_si(gce_engine *e) {
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+#ifdef GCE_SI_CANARY      // debugging build: after every phase of gce_process, is a word of the Stats blocks that no kernel of that phase writes non-zero?
+static void si_canary(gce_engine *e, const char *phase) {
+    StreamInfo hs; (void)hipStreamSynchronize(e->stream); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
+    for (int k = 14; k < GCE_STATS_WORDS; k++) if ((k != 15 && hs.post[k] != 0) || hs.pre[k] < 0 || hs.post[k] < 0) { fprintf(stderr, "SI_CANARY after %s: pre[%d] = %lld post[%d] = %lld\n", phase, k, hs.pre[k], k, hs.post[k]); break; }
+}
+#define CANARY(x) si_canary(e, x)
+#else
+#define CANARY(x) do { } while (0)
+#endif
+
 // Every clusterByUMI of the stream (src/gencore.cpp:355 periodic, :409 end of file) + outputPair bookkeeping + the output order.
 int gce_process(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
@@ -579,6 +589,7 @@ int gce_process(gce_engine *e) {
     }
 #endif
     HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
+    CANARY("EV_CLUSTER");
     if (N > 0) {
         if (!e->have_tick) {
             hipLaunchKernelGGL(k_blk_scan, dim3(1), dim3(1024), 0, s, w, p);
@@ -592,6 +603,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, N, w);
     }
     HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
+    CANARY("EV_CSR");
     // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote
     if (N > 0) {
 #ifndef GCE_DESCRIBE_BLOCKS
@@ -602,6 +614,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_describe, dim3(cdiv(n_tiles, tpb)), dim3(256), 0, s, b, p, w, tpb);
     }
     HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
+    CANARY("EV_DESCRIBE");
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
     e->tab_clean = true;                          // k_scatter ran to the end
@@ -652,6 +665,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_groups, &w.si->vote_weight);
         hipLaunchKernelGGL(k_vote_batches, dim3(nblk_N), dim3(256), 0, s, w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);
         HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
+        CANARY("EV_PAIRING");
         if ((rc = read_si(e)) != GCE_OK) return rc;
         HIPCHK(hipGetLastError());
         NG = (uint32_t)e->h_si.n_groups;
@@ -681,6 +695,7 @@ int gce_process(gce_engine *e) {
 #endif
         hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
         HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        CANARY("EV_SCORE");
         hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
         {   // compact the flagged sides into gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
@@ -693,6 +708,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
+        CANARY("EV_CONSENSUS");
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
         if (!p.disable_duplex) {                                                                  // duplex stage: flagged clusters, compacted, a wave each
             const unsigned nbc = cdiv(C, SCAN_TILE);
@@ -725,6 +741,7 @@ int gce_process(gce_engine *e) {
     }
 #endif
     HIPCHK(hipEventRecord(e->ev[EV_FINISH], s));
+    CANARY("EV_FINISH");
     // ---- the output set: emitted reads in bamComp order (gencore.h:19-47) as one compact table.  Capacities are worst case
     //      (every read emitted): nothing here needs a host round trip.
     OutTable o{};
@@ -738,18 +755,42 @@ int gce_process(gce_engine *e) {
         o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
         o.key = e->o_key.as<OutKey>(); o.rec = e->o_rec.as<OutRec>(); o.ksoff = e->o_ksoff.as<uint64_t>(); o.kqoff = e->o_kqoff.as<uint64_t>(); o.krow = e->o_krow.as<uint32_t>(); o.part3 = e->o_part3.as<uint64_t>();
         hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups
+        CANARY("k_stats");
         hipLaunchKernelGGL(k_out_reduce, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
+        CANARY("k_out_reduce");
         hipLaunchKernelGGL(k_out_partials, dim3(1), dim3(1024), 0, s, o, (uint64_t)nblk_O, w);
+        CANARY("k_out_partials");
         hipLaunchKernelGGL(k_out_meta, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
+        CANARY("k_out_meta");
         const unsigned og = std::min<unsigned>(cdiv(n1, 256), 8192u);
         hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, w, o);
+        CANARY("k_out_rows");
         hipLaunchKernelGGL(k_out_mate, dim3(og), dim3(256), 0, s, w, o);
+        CANARY("k_out_mate");
         hipLaunchKernelGGL(k_out_gather, dim3(std::min<unsigned>(cdiv(n1, 16), 16384u)), dim3(256), 0, s, b, w, o);
+        CANARY("k_out_gather");
     }
     HIPCHK(hipEventRecord(e->ev[EV_OUTPUT], s));
+    CANARY("EV_OUTPUT");
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, s, w.si);          // (outside the timed step: a convenience of gce_stats_device)
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
+#ifdef GCE_SI_CHECK       // debugging build: the post block's histogram only ever has entry 1 (outputPair: addMolecule(1, PE)) -- anything else is a stray write
+    {
+        bool badw = false;
+        for (int k = 14; k < GCE_STATS_WORDS; k++) if ((k != 15 && e->h_si.post[k] != 0) || e->h_si.pre[k] < 0) badw = true;
+        if (badw) {
+            StreamInfo again; (void)hipMemcpy(&again, e->si.p, sizeof again, hipMemcpyDeviceToHost);
+            fprintf(stderr, "SI_CHECK: N %lld NG %u C %u n_out %llu\n post:", (long long)N, NG, C, (unsigned long long)e->h_si.n_out);
+            for (int k = 0; k < 30; k++) fprintf(stderr, " %lld", e->h_si.post[k]);
+            fprintf(stderr, "\n post again:"); for (int k = 0; k < 30; k++) fprintf(stderr, " %lld", again.post[k]);
+            fprintf(stderr, "\n pre:"); for (int k = 0; k < 30; k++) fprintf(stderr, " %lld", e->h_si.pre[k]);
+            fprintf(stderr, "\n other nonzero post words:"); for (int k = 30; k < GCE_STATS_WORDS; k++) if (e->h_si.post[k]) fprintf(stderr, " [%d]=%lld", k, e->h_si.post[k]);
+            fprintf(stderr, "\n post_slot col 0..7 sums:"); for (int k = 0; k < 8; k++) { long long a = 0; for (int q = 0; q < GCE_PRE_SLOTS; q++) a += e->h_si.post_slot[q][k]; fprintf(stderr, " %lld", a); }
+            fprintf(stderr, "\n scalars: n_clustered %llu n_slow %u n_deep %u n_slow_pair %u n_gen %llu n_pf %llu n_pq %llu vote_weight %llu\n", e->h_si.n_clustered, e->h_si.n_slow, e->h_si.n_deep, e->h_si.n_slow_pair, e->h_si.n_gen_items, e->h_si.n_pf_items, e->h_si.n_pq_items, e->h_si.vote_weight);
+        }
+    }
+#endif
     e->h_si.n_groups = NG;
     float ms = 0;
     auto el = [&](int a, int c) { ms = 0; (void)hipEventElapsedTime(&ms, e->ev[a], e->ev[c]); return (double)ms; };

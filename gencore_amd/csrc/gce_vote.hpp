@@ -46,6 +46,9 @@
 #define VB_CCAP 192
 #endif
 //   VB_CCAP: contested columns voted per round (LDS tallies)
+#ifndef VB_WPE
+#define VB_WPE 7
+#endif
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #define VB_RCAP (VB_SIDES * VB_SMAX)
 
@@ -155,7 +158,7 @@ __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base
 #define VB_TICK(k) do { } while (0)
 #endif
 #define gb_ gb_
-__global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
+__global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8))) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
     __shared__ VRead s_rd[2][VB_MAXP];
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];

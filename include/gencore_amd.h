@@ -346,6 +346,16 @@ int gce_bam_write(const char *path, const gce_bam *in, const gce_result *res, in
 int gce_bam_from_batch(const char *path, const gce_batch *batch, int32_t n_targets, const uint32_t *target_len,
                        const char *const *target_name, const char *text, int threads, int level);
 
+/* Replaces: the SAM TEXT side of htslib under the reference -- sam_open(in, "r") takes BAM or SAM, sam_read1 parses text lines; an output
+ * name that ends in "sam" is opened with sam_open(out, "w") and sam_write1 prints text (src/gencore.cpp:164-173,180,187,205,104).
+ * gce_run_bam does the same: an input that does not start with the gzip magic is read as SAM text (header lines, then one alignment per
+ * line, converted to BAM records on the host threads and pushed to the GPU like an inflated BAM window), an output name that ends in
+ * "sam" is written as text.  The two functions below are the conversion alone, on the host (no engine, no GPU).  Conventions of htslib
+ * that the path can see are kept: an integer tag is stored in the smallest type that holds it ('C' for NM 0..255: src/group.cpp:569
+ * patches NM only as 'C'), bin = reg2bin(pos, pos + reference length), QUAL '*' = 0xFF bytes, an unknown RNAME = -1. */
+int gce_sam_to_bam(const char *sam_path, const char *bam_path, int threads, int level, char err[256]);
+int gce_bam_to_sam(const char *bam_path, const char *sam_path, int threads, char err[256]);
+
 /* Replaces: Reference::Reference -> FastaReader(file) + readAll (src/reference.cpp:13-24, src/fastareader.cpp:7-41,57-104,157-168),
  * including its quirks (first character of every line unfiltered, lower case folded, ID = header up to the first blank, a later
  * contig of the same name wins).  Contigs come back as ASCII for gce_set_reference_ascii. */

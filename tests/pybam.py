@@ -18,10 +18,16 @@ def bgzf_block(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
 EOF_BLOCK = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
+BFMT = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+
+
 def aux_bytes(tag, typ, val):
     t = tag.encode()
-    if typ == "Z":
-        return t + b"Z" + val.encode() + b"\0"
+    if typ in ("Z", "H"):
+        return t + typ.encode() + val.encode() + b"\0"
+    if typ == "B":                                             # val = (subtype, [values])
+        sub, vals = val
+        return t + b"B" + sub.encode() + struct.pack("<I", len(vals)) + b"".join(struct.pack(BFMT[sub], v) for v in vals)
     fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "A": "<c", "f": "<f"}[typ]
     return t + typ.encode() + struct.pack(fmt, val)
 
@@ -88,8 +94,11 @@ def read_bam(path):
         aux, order = {}, []
         while q < e:
             tag, typ = u[q:q + 2].decode(), chr(u[q + 2]); q += 3
-            if typ == "Z":
+            if typ in ("Z", "H"):
                 z = u.index(b"\0", q); val = u[q:z].decode(); q = z + 1
+            elif typ == "B":
+                sub = chr(u[q]); (cnt,) = struct.unpack_from("<I", u, q + 1); q += 5
+                val = (sub, [struct.unpack_from(BFMT[sub], u, q + k * struct.calcsize(BFMT[sub]))[0] for k in range(cnt)]); q += cnt * struct.calcsize(BFMT[sub])
             else:
                 fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "A": "<c", "f": "<f"}[typ]
                 (val,) = struct.unpack_from(fmt, u, q); q += struct.calcsize(fmt)
@@ -99,3 +108,89 @@ def read_bam(path):
                          qual=qual, aux=aux, aux_order=order))
         p = e
     return text, targets, recs
+
+
+# ---------------------------------------------------------------- SAM text, independently of gencore_amd/csrc/gce_samtext.hpp (SAMv1 1.4, 1.5, 5.3)
+def reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def cigar_ref_len(words):
+    return sum(w >> 4 for w in words if (w & 15) in (0, 2, 3, 7, 8))
+
+
+def expected_bin(r):
+    """the bin htslib's SAM parser gives a record: reg2bin(pos, pos + reference length), length 1 for unmapped reads / empty CIGARs"""
+    cig = parse_cigar(r.get("cigar", "*")) if isinstance(r.get("cigar", "*"), str) else r["cigar"]
+    ln = 1 if (r["flag"] & 4) else cigar_ref_len(cig)
+    return reg2bin(r["pos"], r["pos"] + (ln or 1))            # (pos -1: floor shifts, bin 4680)
+
+
+def _aux_text(tag, typ, val):
+    if typ in "cCsSiI":
+        return "%s:i:%d" % (tag, val)
+    if typ == "A":
+        return "%s:A:%s" % (tag, val.decode() if isinstance(val, bytes) else val)
+    if typ == "f":
+        return "%s:f:%g" % (tag, val)
+    if typ in "ZH":
+        return "%s:%s:%s" % (tag, typ, val)
+    sub, vals = val
+    return "%s:B:%s" % (tag, sub) + "".join(",%g" % v if sub == "f" else ",%d" % v for v in vals)
+
+
+def sam_line(r, targets):
+    """r: a record dict as record_bytes takes (cigar as text)"""
+    def name(t):
+        return targets[t][0] if 0 <= t < len(targets) else "*"
+    qual = r["qual"]
+    if not isinstance(qual, str):
+        qual = "*" if (len(qual) and qual[0] == 0xFF) or not len(qual) else "".join(chr(q + 33) for q in qual)
+    aux = [_aux_text(*a) for a in r.get("aux_pre", [])]
+    if r.get("nm") is not None:
+        aux.append("NM:i:%d" % r["nm"])
+    if r.get("mi") is not None:
+        aux.append("MI:Z:%s" % r["mi"])
+    aux += [_aux_text(*a) for a in r.get("aux_post", [])]
+    rnext = "*" if r["mtid"] < 0 else "=" if r["mtid"] == r["tid"] else name(r["mtid"])
+    f = [r["qname"], str(r["flag"]), name(r["tid"]), str(r["pos"] + 1), str(r.get("mapq", 60)), r.get("cigar", "*") or "*", rnext, str(r["mpos"] + 1),
+         str(r["isize"]), r["seq"] or "*", qual] + aux
+    return "\t".join(f)
+
+
+def write_sam(path, records, targets, text="@HD\tVN:1.6\tSO:coordinate\n", sq_lines=True, newline="\n"):
+    with open(path, "w", newline="") as f:
+        f.write(text.replace("\n", newline))
+        if sq_lines:
+            for nm, ln in targets:
+                f.write("@SQ\tSN:%s\tLN:%d%s" % (nm, ln, newline))
+        for r in records:
+            f.write(sam_line(r, targets) + newline)
+
+
+def read_sam(path):
+    """-> (header text, alignment lines split into fields)"""
+    text, recs = "", []
+    for ln in open(path).read().split("\n"):
+        if not ln:
+            continue
+        if ln.startswith("@"):
+            text += ln + "\n"
+        else:
+            recs.append(ln.split("\t"))
+    return text, recs
+
+
+def sam_fields_of_read(g, targets):
+    """the SAM fields of a record as read_bam returns it (CIGAR words, aux dict): what a SAM writer must print for it"""
+    def name(t):
+        return targets[t][0] if 0 <= t < len(targets) else "*"
+    cig = "".join("%d%s" % (w >> 4, "MIDNSHP=X"[w & 15]) for w in g["cigar"]) or "*"
+    qual = "*" if not g["qual"] or g["qual"][0] == 0xFF else "".join(chr(q + 33) for q in g["qual"])
+    rnext = "*" if g["mtid"] < 0 else "=" if g["mtid"] == g["tid"] else name(g["mtid"])
+    aux = [_aux_text(t, *g["aux"][t]) for t in g["aux_order"]]
+    return [g["qname"], str(g["flag"]), name(g["tid"]), str(g["pos"] + 1), str(g["mapq"]), cig, rnext, str(g["mpos"] + 1), str(g["isize"]), g["seq"] or "*", qual] + aux
