@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--level", type=int, default=1, help="deflate level of the OUTPUT file (htslib's default is 6)")
     ap.add_argument("--chunk", type=int, default=1 << 21)
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--c-caller", action="store_true", help="also run the files through tools/run_bam.c (a plain C process) and report its times and peak RSS")
     for k_ in ("--child", "--make-s", "--npairs", "--nreads", "--sreq", "--unc"):
         ap.add_argument(k_, default=None)
     args = ap.parse_args()
@@ -92,6 +93,21 @@ def main():
                                "--level", str(args.level), "--chunk", str(args.chunk), "--make-s", "%.2f" % t_make, "--npairs", str(d.info["n_pairs"]), "--nreads", str(batch.n),
                                "--sreq", str(d.info["supporting_reads"]), "--unc", str(int(batch.seq.size + batch.qual.size + batch.qname.size + 4 * batch.cigar.size + 40 * batch.n))], stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in outp.stdout.splitlines() if ln.startswith("{")]
+        if lines and args.c_caller:                             # the same files through a plain C process: the path's own resident memory
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            exe = os.path.join(tmp, "run_bam")
+            subprocess.run(["gcc", "-std=c11", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "run_bam.c"), "-L" + os.path.join(root, "gencore_amd", "csrc"),
+                            "-lgencore_amd", "-Wl,-rpath," + os.path.join(root, "gencore_amd", "csrc"), "-o", exe], check=True)
+            c = subprocess.run([exe, src, os.path.join(tmp, "out_c.bam"), "-" if os.environ.get("GCE_BENCH_NO_FASTA") else fa, str(args.threads), str(args.level), str(d.info["supporting_reads"]), "2"],
+                               stdout=subprocess.PIPE, text=True)
+            cl = [ln for ln in c.stdout.splitlines() if ln.startswith("{")]
+            res = json.loads(lines[-1]); res["c_caller"] = json.loads(cl[-1]) if cl else {"error": c.stdout[-300:]}
+            same = cl and open(out, "rb").read() == open(os.path.join(tmp, "out_c.bam"), "rb").read()
+            res["c_caller"]["output_identical_to_python_run"] = bool(same)
+            c2 = subprocess.run([exe, src, os.path.join(tmp, "out_c2.bam"), "-", str(args.threads), str(args.level), str(d.info["supporting_reads"]), "1"], stdout=subprocess.PIPE, text=True)
+            cl2 = [ln for ln in c2.stdout.splitlines() if ln.startswith("{")]
+            res["c_caller_fresh_process_no_fasta"] = json.loads(cl2[-1]) if cl2 else {"error": c2.stdout[-300:]}      # one run, cold allocations, no reference on the host: the path's own footprint
+            lines[-1] = json.dumps(res)
         sys.stdout.write((lines[-1] + "\n") if lines else outp.stdout)
         return
 
