@@ -360,6 +360,19 @@ def main():
                 "parallelism": ("key-range shards x%d (cluster key (tid,left), global ticks + flush events), Stats all-reduce" % world) if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity,
         }
+        # the whole stream's Stats: at N > 1 the blocks every rank holds after the all-reduce (sums over the key-range shards), at N = 1 the
+        # engine's own -- the same stream cut into 1 or N ranges must give the same numbers (tests/test_bench_ranks.py)
+        names = ("reads", "bases", "reads_unmapped", "bases_unmapped", "base_mismatches", "reads_with_mismatches", "clusters", "multi_molecule_clusters",
+                 "molecules", "molecules_se", "molecules_pe", "sscs", "dcs", "uncounted_supporting_reads")
+        if dist:
+            sv = stats_dev.cpu().tolist()
+            W = capi.GCE_STATS_WORDS
+            out["stats_whole_stream"] = {"pre": dict(zip(names, sv[:14])), "post": dict(zip(names, sv[W:W + 14])), "pre_hist_sum": int(sum(sv[14:W])), "post_hist_sum": int(sum(sv[W + 14:])),
+                                         "how": "one all-reduce(sum) of 2 x %d int64 straight from device memory (gce_stats_device)" % W}
+        else:
+            po = last_res.get("post", {})
+            out["stats_whole_stream"] = {"pre": {k: pre.get(k) for k in names}, "post": {k: po.get(k) for k in names}, "pre_hist_sum": int(sum(pre.get("supporting_hist", []))),
+                                         "post_hist_sum": int(sum(po.get("supporting_hist", []))), "how": "single engine"}
         if cpu:
             out["speedup_vs_cpu_port"] = round(value / cpu["value"], 2)
         print(json.dumps(out))

@@ -1403,40 +1403,59 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         // Pieces of the text are cut at line feeds; the '@' lines in front give the header text and the contig table; alignment lines become BAM
         // records on all host threads (gce_samtext.hpp) in a pinned window that goes to HBM like an inflated BAM window, behind BAM header bytes
         // made from the SAM header: from there on the stream is the one a BAM file gives.
-        std::vector<char> tb; size_t tcarry = 0; uint64_t at = 0; bool in_header = true; samtext::NameMap nmap; int wk = 0;
+        Raw<char> tbuf[2]; uint64_t at = 0; bool in_header = true; samtext::NameMap nmap; int wk = 0, kb = 0;
         std::vector<std::vector<uint8_t>> parts((size_t)T); std::vector<std::string> perr((size_t)T);
-        const size_t TP = PIECE * 4;
-        while (at < fsz || tcarry) {
-            const size_t want = (size_t)std::min<uint64_t>(TP, fsz - at);
-            tb.resize(tcarry + want + 1);
-            { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, tb.data() + tcarry + o, want - o, (off_t)(at + o)); if (g <= 0) return done(GCE_ERR_INVALID, "cannot read the input SAM"); o += (size_t)g; } t_read += now_s() - r0; }
-            at += want;
-            const size_t n = tcarry + want; const bool last = at >= fsz;
+        const size_t TP = PIECE < ((size_t)8 << 20) ? PIECE : ((size_t)64 << 20);          // text bytes per piece (tests: 1 MB pieces that cut lines)
+        std::thread rd; bool rd_on = false; ssize_t rd_got = 0;
+        auto read_into = [&](char *dst, size_t want, uint64_t off) { const double r0 = now_s(); size_t o = 0; while (o < want) { const ssize_t g = pread(fd, dst + o, want - o, (off_t)(off + o)); if (g <= 0) break; o += (size_t)g; } rd_got = (ssize_t)o; t_read += now_s() - r0; };
+        auto bail = [&](int code, const char *m) { if (rd_on) { rd.join(); rd_on = false; } return done(code, m); };
+        size_t n = 0;                                                                      // bytes in tbuf[kb]: what the last piece left over + this piece
+        {
+            const size_t want = (size_t)std::min<uint64_t>(TP, fsz);
+            tbuf[0].resize(want + 1); if (!tbuf[0].ok()) return done(GCE_ERR_OOM, "out of host memory");
+            read_into(tbuf[0].data(), want, 0);
+            if ((size_t)rd_got != want) return done(GCE_ERR_INVALID, "cannot read the input SAM");
+            at = want; n = want;
+        }
+        for (;;) {
+            char *cur = tbuf[kb].data();
+            const bool last = at >= fsz;
             size_t lim = n;
             if (!last) {
-                const char *nl = (const char *)memrchr(tb.data(), '\n', n);
-                if (!nl) { if (n > ((size_t)256 << 20)) return done(GCE_ERR_INVALID, "SAM line longer than 256 MB"); tcarry = n; continue; }
-                lim = (size_t)(nl - tb.data()) + 1;
-            } else if (n && tb[n - 1] != '\n') { tb[n] = '\n'; lim = n + 1; }
+                const char *nl = (const char *)memrchr(cur, '\n', n);
+                lim = nl ? (size_t)(nl - cur) + 1 : 0;
+                if (!nl && n > ((size_t)256 << 20)) return done(GCE_ERR_INVALID, "SAM line longer than 256 MB");
+            } else if (n && cur[n - 1] != '\n') { cur[n] = '\n'; lim = n + 1; }
+            // the next piece is read behind what this one leaves over (the line its end cut) while this one is converted
+            size_t want2 = 0, left = lim >= n ? 0 : n - lim;
+            if (!last) {
+                want2 = (size_t)std::min<uint64_t>(TP, fsz - at);
+                Raw<char> &nx = tbuf[kb ^ 1];
+                nx.resize(left + want2 + 1); if (!nx.ok()) return done(GCE_ERR_OOM, "out of host memory");
+                if (left) memcpy(nx.data(), cur + lim, left);
+                char *dst = nx.data() + left; const uint64_t off = at;
+                rd_on = true; rd = std::thread([&, dst, off, want2] { read_into(dst, want2, off); });
+                at += want2;
+            }
             size_t p = 0;
             if (in_header) {
-                while (p < lim && tb[p] == '@') { const char *q = (const char *)memchr(tb.data() + p, '\n', lim - p); const size_t z2 = (size_t)(q - tb.data()) + 1; text.append(tb.data() + p, z2 - p); p = z2; }
+                while (p < lim && cur[p] == '@') { const char *q = (const char *)memchr(cur + p, '\n', lim - p); const size_t z2 = (size_t)(q - cur) + 1; text.append(cur + p, z2 - p); p = z2; }
                 if (p < lim || last) {
                     in_header = false;
-                    if (!samtext::parse_header_text(text, names, lens) || lens.empty()) return done(GCE_ERR_INVALID, "this SAM file has no header");      // src/gencore.cpp:186-189
+                    if (!samtext::parse_header_text(text, names, lens) || lens.empty()) return bail(GCE_ERR_INVALID, "this SAM file has no header");      // src/gencore.cpp:186-189
                     nmap.build(names);
                     std::string fq;
-                    if (p < lim) { const char *q = tb.data() + p; const char *t = (const char *)memchr(q, '\t', lim - p); if (t) fq.assign(q, t); }
-                    if ((rc = setup_engine(fq.empty() ? nullptr : fq.c_str(), (size_t)std::max<uint64_t>(fsz + (1u << 20), 1u << 20))) != GCE_OK) return done(rc, emsg.c_str());
+                    if (p < lim) { const char *q = cur + p; const char *t = (const char *)memchr(q, '\t', lim - p); if (t) fq.assign(q, t); }
+                    if ((rc = setup_engine(fq.empty() ? nullptr : fq.c_str(), (size_t)std::max<uint64_t>(fsz + (1u << 20), 1u << 20))) != GCE_OK) return bail(rc, emsg.c_str());
                     const std::vector<uint8_t> hb = bam_header_bytes();
                     hdr_end = hb.size();
-                    int32_t tk; if ((rc = gce_raw_push(e, hb.data(), hb.size(), &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) return done(rc, gce_last_error(e));
+                    int32_t tk; if ((rc = gce_raw_push(e, hb.data(), hb.size(), &tk)) != GCE_OK || (rc = gce_submit_wait(e, tk)) != GCE_OK) return bail(rc, gce_last_error(e));
                     pushed += hb.size();
                 }
             }
             if (!in_header && p < lim) {
                 const double i0 = now_s();
-                const char *d = tb.data();
+                const char *d = cur;
                 std::vector<size_t> cut((size_t)T + 1, lim);                              // thread t converts the lines that START in [cut[t], cut[t + 1])
                 cut[0] = p;
                 for (int t = 1; t < T; t++) { size_t c = p + (lim - p) * (size_t)t / (size_t)T; if (c > p) { const char *q = (const char *)memchr(d + c - 1, '\n', lim - (c - 1)); c = q ? (size_t)(q - d) + 1 : lim; } cut[(size_t)t] = std::max(c, cut[(size_t)t - 1]); }
@@ -1452,22 +1471,23 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
                         }
                     }
                 });
-                t_inflate += now_s() - i0;
-                if (bad) { for (auto &m : perr) if (!m.empty()) return done(GCE_ERR_INVALID, m.c_str()); return done(GCE_ERR_INVALID, "malformed SAM line"); }
+                if (bad) { for (auto &m : perr) if (!m.empty()) return bail(GCE_ERR_INVALID, m.c_str()); return bail(GCE_ERR_INVALID, "malformed SAM line"); }
                 size_t tot = 0; std::vector<size_t> po((size_t)T + 1, 0);
                 for (int t = 0; t < T; t++) { po[(size_t)t] = tot; tot += parts[(size_t)t].size(); }
                 if (tot) {
                     const int ws = wk % 3;
-                    if (win_ticket[ws] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, win_ticket[ws])) != GCE_OK) return done(rc, gce_last_error(e)); t_wait += now_s() - w0; win_ticket[ws] = -1; }
-                    if (!win[ws].ensure(tot + 64)) return done(GCE_ERR_OOM, "out of pinned host memory");
+                    if (win_ticket[ws] >= 0) { const double w0 = now_s(); if ((rc = gce_submit_wait(e, win_ticket[ws])) != GCE_OK) return bail(rc, gce_last_error(e)); t_wait += now_s() - w0; win_ticket[ws] = -1; }
+                    if (!win[ws].ensure(tot + 64)) return bail(GCE_ERR_OOM, "out of pinned host memory");
                     parallel_for(T, T, [&](int, int64_t a, int64_t b2) { for (int64_t t = a; t < b2; t++) if (!parts[(size_t)t].empty()) memcpy(win[ws].p + po[(size_t)t], parts[(size_t)t].data(), parts[(size_t)t].size()); });
-                    if ((rc = gce_raw_push(e, win[ws].p, tot, &win_ticket[ws])) != GCE_OK) return done(rc, gce_last_error(e));
+                    if ((rc = gce_raw_push(e, win[ws].p, tot, &win_ticket[ws])) != GCE_OK) return bail(rc, gce_last_error(e));
                     pushed += tot; wk++;
                 }
+                t_inflate += now_s() - i0;                                                 // (lines -> records: reported where a BAM input reports its inflate)
             }
-            tcarry = lim >= n ? 0 : n - lim;
-            if (tcarry) memmove(tb.data(), tb.data() + lim, tcarry);
             if (last) break;
+            rd.join(); rd_on = false;
+            if ((size_t)rd_got != want2) return done(GCE_ERR_INVALID, "cannot read the input SAM");
+            n = left + want2; kb ^= 1;
         }
     } else {
     int k = 0;

@@ -121,15 +121,19 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
     if (!(fe(9) - fb(9) == 1 && *fb(9) == '*')) {
         lseq = (size_t)(fe(9) - fb(9));
         const uint8_t *t16 = nt16_table(); const char *q = fb(9);
-        for (size_t k = 0; k + 1 < lseq; k += 2) out.push_back((uint8_t)(t16[(uint8_t)q[k]] << 4 | t16[(uint8_t)q[k + 1]]));
-        if (lseq & 1) out.push_back((uint8_t)(t16[(uint8_t)q[lseq - 1]] << 4));
+        const size_t o0 = out.size(); out.resize(o0 + (lseq + 1) / 2);                      // (written in place: a push_back per base was most of the parse)
+        uint8_t *wp = &out[o0];
+        for (size_t k = 0; k + 1 < lseq; k += 2) *wp++ = (uint8_t)(t16[(uint8_t)q[k]] << 4 | t16[(uint8_t)q[k + 1]]);
+        if (lseq & 1) *wp = (uint8_t)(t16[(uint8_t)q[lseq - 1]] << 4);
     }
     {
         const char *q = fb(10), *z = fe(10);
         if (z - q == 1 && *q == '*') out.insert(out.end(), lseq, (uint8_t)0xFF);
         else {
             if ((size_t)(z - q) != lseq) { msg = "SEQ and QUAL of different length"; return false; }
-            for (size_t k = 0; k < lseq; k++) out.push_back((uint8_t)(q[k] - 33));
+            const size_t o0 = out.size(); out.resize(o0 + lseq);
+            uint8_t *wp = lseq ? &out[o0] : nullptr;
+            for (size_t k = 0; k < lseq; k++) wp[k] = (uint8_t)(q[k] - 33);
         }
     }
     // optional fields
@@ -209,10 +213,10 @@ inline bool bam_to_line(const uint8_t *r, const std::vector<std::string> &names,
     if (mtid < 0) o.push_back('*'); else if (mtid == tid) o.push_back('='); else if ((size_t)mtid < names.size()) o += names[(size_t)mtid]; else o.push_back('*');
     o.push_back('\t'); put_num(o, (long long)mpos + 1); o.push_back('\t'); put_num(o, tlen); o.push_back('\t');
     if (lseq == 0) o.push_back('*');
-    else for (int32_t k = 0; k < lseq; k++) o.push_back("=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> ((~k & 1) << 2)) & 15]);
+    else { const size_t o0 = o.size(); o.resize(o0 + (size_t)lseq); char *wp = &o[o0]; for (int32_t k = 0; k < lseq; k++) wp[k] = "=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> ((~k & 1) << 2)) & 15]; }
     o.push_back('\t');
     if (lseq == 0 || ql[0] == 0xFF) o.push_back('*');
-    else for (int32_t k = 0; k < lseq; k++) o.push_back((char)(ql[k] + 33));
+    else { const size_t o0 = o.size(); o.resize(o0 + (size_t)lseq); char *wp = &o[o0]; for (int32_t k = 0; k < lseq; k++) wp[k] = (char)(ql[k] + 33); }
     for (const uint8_t *p = ax; p + 3 <= end;) {
         const uint8_t type = p[2]; const uint8_t *v = p + 3;
         o.push_back('\t'); o.push_back((char)p[0]); o.push_back((char)p[1]); o.push_back(':');

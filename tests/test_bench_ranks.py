@@ -1,0 +1,34 @@
+"""bench.py's N > 1 path on a one-GPU box: two ranks on cuda:0 (torch.distributed over gloo, `--test-one-gpu`) cut ONE stream into two key
+ranges -- global ticks, flush events, no data-path collective, one all-reduce of the Stats blocks -- and must report the Stats of the same
+stream run through a single engine."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+def test_two_ranks_equal_one_engine(built):
+    common = ["--workload", "cfg4s", "--scale", "0.02", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = run([sys.executable, "bench.py", "--pairs", "300000"] + common)
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+               "bench.py", "--gpus", "2", "--pairs", "150000", "--test-one-gpu"] + common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    a, b = one["stats_whole_stream"], two["stats_whole_stream"]
+    assert a["pre"]["reads"] == 600000 or a["pre"]["reads"] > 0
+    for blk in ("pre", "post"):
+        assert a[blk] == b[blk], (blk, a[blk], b[blk])
+    assert a["pre_hist_sum"] == b["pre_hist_sum"] and a["post_hist_sum"] == b["post_hist_sum"]
+    assert two["value"] > 0 and two["config"]["pairs_per_gpu"] > 0

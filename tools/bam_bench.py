@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--level", type=int, default=1, help="deflate level of the OUTPUT file (htslib's default is 6)")
     ap.add_argument("--chunk", type=int, default=1 << 21)
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--sam", action="store_true", help="with --c-caller: also time SAM text in / out")
     ap.add_argument("--c-caller", action="store_true", help="also run the files through tools/run_bam.c (a plain C process) and report its times and peak RSS")
     for k_ in ("--child", "--make-s", "--npairs", "--nreads", "--sreq", "--unc"):
         ap.add_argument(k_, default=None)
@@ -104,9 +105,21 @@ def main():
             res = json.loads(lines[-1]); res["c_caller"] = json.loads(cl[-1]) if cl else {"error": c.stdout[-300:]}
             same = cl and open(out, "rb").read() == open(os.path.join(tmp, "out_c.bam"), "rb").read()
             res["c_caller"]["output_identical_to_python_run"] = bool(same)
-            c2 = subprocess.run([exe, src, os.path.join(tmp, "out_c2.bam"), "-", str(args.threads), str(args.level), str(d.info["supporting_reads"]), "1"], stdout=subprocess.PIPE, text=True)
+            c2 = subprocess.run([exe, src, os.path.join(tmp, "out_c2.bam"), "-", str(args.threads), str(args.level), str(d.info["supporting_reads"]), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                env=dict(os.environ, GCE_RAW_TIMING="1"))
             cl2 = [ln for ln in c2.stdout.splitlines() if ln.startswith("{")]
             res["c_caller_fresh_process_no_fasta"] = json.loads(cl2[-1]) if cl2 else {"error": c2.stdout[-300:]}      # one run, cold allocations, no reference on the host: the path's own footprint
+            res["c_caller_fresh_process_no_fasta"]["rss_trace"] = [ln.strip() for ln in c2.stderr.splitlines() if "RSS" in ln]
+            if args.sam:                                        # the same stream as SAM text: in and out (and SAM in -> BAM out)
+                from gencore_amd.bamio import bam_to_sam
+                sam_in = os.path.join(tmp, "in.sam")
+                t1 = time.time(); bam_to_sam(src, sam_in, threads=args.threads); conv = time.time() - t1
+                res["sam"] = {"in_sam_bytes": os.path.getsize(sam_in), "bam_to_sam_s": round(conv, 3)}
+                for tag, outp2 in (("sam_to_sam", os.path.join(tmp, "out_c.sam")), ("sam_to_bam", os.path.join(tmp, "out_c3.bam"))):
+                    c3 = subprocess.run([exe, sam_in, outp2, "-", str(args.threads), str(args.level), str(d.info["supporting_reads"]), "2"], stdout=subprocess.PIPE, text=True)
+                    cl3 = [ln for ln in c3.stdout.splitlines() if ln.startswith("{")]
+                    res["sam"][tag] = json.loads(cl3[-1]) if cl3 else {"error": c3.stdout[-300:]}
+                res["sam"]["out_sam_bytes"] = os.path.getsize(os.path.join(tmp, "out_c.sam")) if os.path.exists(os.path.join(tmp, "out_c.sam")) else None
             lines[-1] = json.dumps(res)
         sys.stdout.write((lines[-1] + "\n") if lines else outp.stdout)
         return
