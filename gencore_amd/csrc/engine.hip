@@ -64,6 +64,7 @@ struct gce_engine {
     bool have_mi = false, have_tick = false, have_events = false, host_mode = false, device_mode = false, processed = false;
     // streamed submission (gce_reserve): batches go straight to HBM on their own stream while the caller prepares the next one
     bool reserved = false; hipStream_t up_stream = nullptr; std::vector<hipEvent_t> up_events;
+    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2]{};      // deep streams: k_score2 beside the hand-on + k_deep_prepare (gce_process)
     size_t rs_n = 0, rs_q = 0, rs_c = 0, rs_s = 0, rs_l = 0, st_n = 0, st_q = 0, st_c = 0, st_s = 0, st_l = 0;
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
@@ -166,6 +167,8 @@ void gce_destroy(gce_engine *e) {
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }
+    if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+    for (auto &v : e->aux_ev) if (v) (void)hipEventDestroy(v);
     for (auto &b : e->ref_buf) b.release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -696,15 +699,34 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
         HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
         CANARY("EV_SCORE");
-        hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
-        {   // compact the flagged sides into gen_list
+        // A stream of deep groups (mean depth beyond 24 pairs: the deep kernels carry the consensus phase, cfg5) runs Pair::computeScore for the
+        // handed-on groups (k_score2: bandwidth) on a second HIP stream BESIDE the compaction, the hand-on of the deep sides and their template /
+        // voter preparation (k_deep_prepare: a wave per side, latency) -- none of those reads a score or a quality; the votes wait for both.
+        const bool deep_stream = (double)N > 48.0 * (double)NG && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
+        const unsigned cf_grid = cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u;
+        auto compact_gen = [&]() {   // the flagged sides -> gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
             hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
             hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
             hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
+        };
+        if (deep_stream) {
+            if (!e->aux_stream) { HIPCHK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming)); }
+            HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand
+            HIPCHK(hipStreamWaitEvent(e->aux_stream, e->aux_ev[0], 0));
+            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, e->aux_stream, b, p, w, (uint32_t)N, 1);
+            HIPCHK(hipEventRecord(e->aux_ev[1], e->aux_stream));
+            compact_gen();
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 1);        // the deep sides -> slow_list
+            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
+            HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));                                // the scores (and the rewritten qualities) stand
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 2);        // everything else on gen_list
+        } else {
+            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
+            compact_gen();
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 0);
+            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
         }
-        hipLaunchKernelGGL(k_consensus_fast, dim3(cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u), dim3(256), 0, s, b, p, w);
-        hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
         HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));

@@ -1312,14 +1312,19 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
 // This is the kernel behind the group kernel (gce_vote.hpp): it takes the group sides that one flags (gen_flag -> gen_list).
-__device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
+// mode 0: everything; mode 1: only the hand-on of the deep sides (needs no scores: it runs, with k_deep_prepare behind it, beside k_score2 on a
+// second stream when the stream is a deep one); mode 2: everything but the deep sides (they were handed on by a mode-1 launch)
+__device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane, int mode) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
+    const bool deep_side = !(np == 1 && w.gpr[begin] == NONE32) && (np > 64 || (int)np > p.skip_low_complexity_thr);
+    if (mode == 1 && !deep_side) return;
+    if (mode == 2 && deep_side) return;
     if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
         if (lane == 0) rp_out[gi] = is_left ? w.gpl[begin] : NONE32;
         return;
     }
-    if (np > 64 || (int)np > p.skip_low_complexity_thr) {
+    if (deep_side) {
         if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
@@ -1634,7 +1639,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
 }
 
 // global-memory consensus, one wave per (group, side): the sides on gen_list (grid-stride, count read on the device)
-__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w, int mode) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     // the count only exists on the device: a capped grid strides over the list (a wave takes one or two entries when the list is
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams
     const uint32_t n = (uint32_t)w.si->n_gen_items;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t e = w.gen_list[idx];
-        consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
+        consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane, mode);
         WAVE_SYNC();
     }
 }
