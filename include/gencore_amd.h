@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCE_ABI_VERSION 3
+#define GCE_ABI_VERSION 3              /* (struct layouts and the meaning of every v3 entry point are unchanged; gce_sam_to_bam / gce_bam_to_sam and SAM text in gce_run_bam were ADDED under v3) */
 #define GCE_NONE 0xFFFFFFFFu           /* "no record" marker in uint32 index arrays */
 #define GCE_MAX_SUPPORTING_READS 100   /* src/stats.h:15 MAX_SUPPORTING_READS */
 
