@@ -874,6 +874,9 @@ int gce_drain(gce_engine *e, gce_result *out) {
     out->fr = e->r_fr.data(); out->rr = e->r_rr.data(); out->mate = e->r_mate.data();
     out->seq_off = e->r_soff.data(); out->qual_off = e->r_qoff.data(); out->seq = e->r_seq.data(); out->qual = e->r_qual.data();
     out->seq_bytes = e->out_seq_bytes; out->qual_bytes = e->out_qual_bytes;
+#ifdef GCE_SI_CHECK
+    for (int k = 14; k < GCE_STATS_WORDS; k++) if (k != 15 && e->h_si.post[k] != 0) fprintf(stderr, "SI_CHECK(gce_drain): the engine's host copy has post[%d] = %lld\n", k, e->h_si.post[k]);
+#endif
     fill_stats(&out->pre, e->h_si.pre); fill_stats(&out->post, e->h_si.post);
     return GCE_OK;
 }

@@ -9,7 +9,7 @@ import torch
 import fuzzgen
 from parity_helpers import check_output_order, diff_results
 from gencore_amd.capi import GceError
-from gencore_amd.engine import run_stream
+from gencore_amd.engine import Engine
 from gencore_amd.shard import shard_by_contig
 from oracle import oracle_py
 
@@ -30,8 +30,10 @@ for it in range(n_iter):
     if it % 3 == 0:
         g = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").fill_(0xA5 + it % 11); del g; torch.cuda.empty_cache()
     for name, b, p, ref, want in prepared:
+        eng = None
         try:
-            got = run_stream(b, p, ref); st = 0
+            eng = Engine(p)
+            got = eng.run(b, ref); st = 0
         except GceError as e:
             got, st = None, e.status
         if st != want.status:
@@ -39,5 +41,14 @@ for it in range(n_iter):
         elif got is not None:
             d = diff_results(b, got, want) + check_output_order(b, got.rows)
             if d:
-                bad_n += 1; print("ITER", it, name, "DIFF", d[:4], flush=True)
+                bad_n += 1; print("ITER", it, name, "DIFF", [x[:400] for x in d[:4]], flush=True)
+                # where does the wrong word live?  Drain the same engine again: a clean second copy means the engine's own host copy of the Stats was
+                # right and the FIRST result struct (this process's heap) was written to behind our back; the same wrong word means the engine's copy has it
+                _, pre2, post2 = eng.rows()
+                import numpy as _np
+                w1, w2, ww = got.post.as_array(), post2.as_array(), want.post.as_array()
+                print("   second drain of the same engine: post equals the oracle's: %s; equals the first drain's: %s; wrong words first drain %s, second drain %s" % (
+                    bool(_np.array_equal(w2, ww)), bool(_np.array_equal(w2, w1)), _np.nonzero(w1 != ww)[0].tolist(), _np.nonzero(w2 != ww)[0].tolist()), flush=True)
+        if eng is not None:
+            eng.close()
 print("stress_shard done: %d iterations x %d cases, %d mismatches" % (n_iter, len(prepared), bad_n))
