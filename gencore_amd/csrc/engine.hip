@@ -429,6 +429,14 @@ static int read_si(gce_engine *e) {
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// the second HIP stream of an engine (and its two events): made when a step first wants it
+static int aux_ready(gce_engine *e) {
+    if (e->aux_stream) return GCE_OK;
+    HIPCHK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming));
+    return GCE_OK;
+}
+
 #ifdef GCE_SI_CANARY      // debugging build: after every phase of gce_process, is a word of the Stats blocks that no kernel of that phase writes non-zero?
 static void si_canary(gce_engine *e, const char *phase) {
     StreamInfo hs; (void)hipStreamSynchronize(e->stream); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
@@ -702,7 +710,7 @@ int gce_process(gce_engine *e) {
         // A stream of deep groups (mean depth beyond 24 pairs: the deep kernels carry the consensus phase, cfg5) runs Pair::computeScore for the
         // handed-on groups (k_score2: bandwidth) on a second HIP stream BESIDE the compaction, the hand-on of the deep sides and their template /
         // voter preparation (k_deep_prepare: a wave per side, latency) -- none of those reads a score or a quality; the votes wait for both.
-        const bool deep_stream = (double)N > 48.0 * (double)NG && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
+        const bool deep_stream = ((double)N > 48.0 * (double)NG || getenv("GCE_FORCE_AUX_STREAM")) && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
         const unsigned cf_grid = cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u;
         auto compact_gen = [&]() {   // the flagged sides -> gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
@@ -711,7 +719,7 @@ int gce_process(gce_engine *e) {
             hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
         };
         if (deep_stream) {
-            if (!e->aux_stream) { HIPCHK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming)); }
+            if ((rc = aux_ready(e)) != GCE_OK) return rc;
             HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand
             HIPCHK(hipStreamWaitEvent(e->aux_stream, e->aux_ev[0], 0));
             hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, e->aux_stream, b, p, w, (uint32_t)N, 1);

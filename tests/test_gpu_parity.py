@@ -532,3 +532,15 @@ def test_stats_blocks_in_device_memory_equal_the_drained_ones(built):
         assert host[0] == batch.n
     finally:
         E.close()
+
+
+@pytest.mark.parametrize("seed", [3, 8, 17, 26, 31, 44, 601, 606])
+def test_two_stream_order_on_small_streams(built, seed, monkeypatch):
+    """A stream of deep groups runs Pair::computeScore (k_score2) on a second HIP stream beside the hand-on and the preparation of the deep sides
+    (gce_process).  GCE_FORCE_AUX_STREAM takes that order on the suite's small streams, deep or not."""
+    monkeypatch.setenv("GCE_FORCE_AUX_STREAM", "1")
+    kw = dict(exotic=seed >= 600)
+    if seed % 2:
+        kw["deep"] = 80
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, **kw)
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
