@@ -178,3 +178,28 @@ def test_sam_end_to_end(built, tmp_path, workload, n_pairs):
         assert lines == want_lines, k
     _, tg2, got2 = pybam.read_bam(outs[("sam", "bam")])
     assert tg2 == tg and [pybam.sam_fields_of_read(g, tg2) for g in got2] == want_lines
+
+
+@pytest.mark.gpu
+def test_sam_without_contigs_and_header_only(built, tmp_path):
+    """src/gencore.cpp:186-189: a SAM file whose header names no contig is refused ("this SAM file has no header"); a header without
+    alignments gives an output that holds the header and nothing else."""
+    from gencore_amd.capi import default_params
+    prm = default_params(umi_prefix="auto")
+    bad = tmp_path / "nohdr.sam"
+    open(bad, "w").write("a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\n")
+    with pytest.raises(GceError) as ei:
+        bamio.run_bam(str(bad), str(tmp_path / "o.bam"), prm, threads=2)
+    assert "no header" in str(ei.value)
+    only = tmp_path / "only.sam"
+    open(only, "w").write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:1000\n")
+    for ext in ("sam", "bam"):
+        out = str(tmp_path / ("o2." + ext))
+        r = bamio.run_bam(str(only), out, prm, threads=2)
+        assert r.n_reads == 0 and r.n_out == 0
+        if ext == "sam":
+            text, lines = pybam.read_sam(out)
+            assert text == "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:1000\n" and lines == []
+        else:
+            _, tg, recs = pybam.read_bam(out)
+            assert tg == [("c1", 1000)] and recs == []
