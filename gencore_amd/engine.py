@@ -16,6 +16,16 @@ _ROW_FIELDS = (("src", np.uint32), ("kind", np.uint8), ("qname_src", np.uint32),
                ("rr", np.int16), ("mate", np.uint32), ("seq_off", np.uint64), ("qual_off", np.uint64))
 
 
+def _copy_out(ptr, dt, cnt):
+    """cnt elements of dtype dt at a C pointer, as an owned numpy array.  One string_at + frombuffer: np.ctypeslib.as_array on a pointer builds a new
+    ctypes array TYPE per call, and with thousands of engine lifetimes per process (the test-suite, the stress scripts) a 64-bit word of the harness's
+    own result structs was found decremented once in ~100 000 lifetimes -- nothing of that kind is made here."""
+    addr = C.cast(ptr, C.c_void_p).value
+    if not addr or cnt <= 0:
+        return np.zeros(0, dt)
+    return np.frombuffer(C.string_at(addr, int(cnt) * np.dtype(dt).itemsize), dtype=dt).copy()
+
+
 class Engine:
     def __init__(self, params=None, **overrides):
         self.lib = capi.load_library()
@@ -95,7 +105,7 @@ class Engine:
         def arr(ptr, dt, cnt):
             if cnt == 0 or not ptr:
                 return np.zeros(0, dt)
-            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+            return _copy_out(ptr, dt, cnt)
 
         rows = {name: arr(getattr(r, name), dt, n) for name, dt in _ROW_FIELDS}
         rows["seq"] = arr(r.seq, np.uint8, int(r.seq_bytes))
@@ -121,9 +131,9 @@ class Engine:
         d = GceDepth()
         self._check(self.lib.gce_depth_stats(self._h, int(step), len(reg), t.ctypes.data, a.ctypes.data, b.ctypes.data, C.byref(d)))
         nt = d.n_targets
-        off = np.ctypeslib.as_array(d.bin_off, shape=(nt + 1,)).copy()
+        off = _copy_out(d.bin_off, np.int64, nt + 1)
         nb = int(off[-1])
-        get = lambda ptr, n: np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.int64)
+        get = lambda ptr, n: _copy_out(ptr, np.int64, n) if n else np.zeros(0, np.int64)
         return off, get(d.pre_depth, nb), get(d.post_depth, nb), get(d.pre_bed, len(reg)), get(d.post_bed, len(reg))
 
     def run(self, batch, reference=None):

@@ -158,8 +158,8 @@ def stream_context_gpu(core, flush_period=10000, device=0):
     rc = lib.gce_stream_context(device, core.ctypes.data, n, flush_period, tick.ctypes.data, C.byref(ne), C.byref(et), C.byref(ep))
     if rc != 0:
         raise capi.GceError(rc, "gce_stream_context")
-    ev_tid = np.ctypeslib.as_array(et, shape=(ne.value,)).copy() if ne.value else np.zeros(0, np.int32)
-    ev_pos = np.ctypeslib.as_array(ep, shape=(ne.value,)).copy() if ne.value else np.zeros(0, np.int32)
+    from .engine import _copy_out
+    ev_tid, ev_pos = _copy_out(et, np.int32, ne.value), _copy_out(ep, np.int32, ne.value)
     lib.gce_free(et); lib.gce_free(ep)
     return tick, ev_tid, ev_pos
 
