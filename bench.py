@@ -4,7 +4,8 @@ HBM roofline, the CPU baseline (oracle port, 1 thread and all host cores) and a 
 points in the same JSON line.
 
     python bench.py --gpus 1 --steps 5 --warmup 2                       # default workload: cfg3 (10 M pairs, UMI, depth 8, -s 2)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...                                        # starts its own N ranks (torch.distributed.run, one per GPU, RCCL)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # the driver's form
 
 A "step" = one gce_process() pass of the whole hot path (clustering scan -> pairing/UMI grouping -> scoring ->
 template pick + column vote -> duplex/filter/tags -> Stats -> output order + compaction) over one synthetic
@@ -111,7 +112,23 @@ def main():
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks here (one process per GPU under torch.distributed.run, RCCL) and become
+        # the launcher -- the line rank 0 prints is this command's output
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    if world > 1 and not args.test_one_gpu and torch.cuda.is_available() and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP devices are visible (use --test-one-gpu to put every rank on cuda:0)" % (world, torch.cuda.device_count()))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.test_one_gpu:
@@ -339,7 +356,9 @@ def main():
             ok = all(o[1] == 0 for o in outs) and np.array_equal(sum(o[3] for o in outs), res.pre.as_array()) and np.array_equal(sum(o[4] for o in outs), res.post.as_array())
             multi = dict(value=round(sd.info["n_pairs"] / ms_, 1), processes=len(procs), host_cores=cores, seconds=round(ms_, 2),
                          slowest_process_seconds=round(max(o[2] for o in outs), 2), stats_equal_single=bool(ok))
+        oflags = [ln.split("?=", 1)[1].strip() for ln in open(os.path.join(ROOT, "oracle", "Makefile")) if ln.startswith("CFLAGS")]
         cpu = dict(value=round(sd.info["n_pairs"] / cs, 1), unit="read-pairs/s", cores=1, kind="port", port_vs_reference=None,
+                   compiler="gcc " + (oflags[0] if oflags else "?") + " (oracle/Makefile; the reference builds -O3, /root/reference/Makefile:20)",
                    why_no_reference="reference gencore links htslib (Makefile:17), absent from this image and not to be stubbed: oracle/_ref holds only util.h's split; the port restates the reference function by function at -O3 and was never calibrated against it",
                    sample="%s generator, %d pairs, oracle/gencore_oracle.c single thread, %.1f s" % (workload, sd.info["n_pairs"], cs),
                    all_cores=multi)

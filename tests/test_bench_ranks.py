@@ -23,8 +23,8 @@ def run(cmd):
 def test_two_ranks_equal_one_engine(built):
     common = ["--workload", "cfg4s", "--scale", "0.02", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
     one = run([sys.executable, "bench.py", "--pairs", "300000"] + common)
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-               "bench.py", "--gpus", "2", "--pairs", "150000", "--test-one-gpu"] + common)
+    # `bench.py --gpus 2` by itself: it starts its own two ranks (torch.distributed.run) -- the form the driver uses for N = 1
+    two = run([sys.executable, "bench.py", "--gpus", "2", "--pairs", "150000", "--test-one-gpu"] + common)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
     a, b = one["stats_whole_stream"], two["stats_whole_stream"]
     assert a["pre"]["reads"] == 600000 or a["pre"]["reads"] > 0
@@ -32,3 +32,15 @@ def test_two_ranks_equal_one_engine(built):
         assert a[blk] == b[blk], (blk, a[blk], b[blk])
     assert a["pre_hist_sum"] == b["pre_hist_sum"] and a["post_hist_sum"] == b["post_hist_sum"]
     assert two["value"] > 0 and two["config"]["pairs_per_gpu"] > 0
+
+
+def test_driver_form_under_the_launcher(built):
+    """the driver's N > 1 form: bench.py under torch.distributed.run; --gpus must agree with the ranks the launcher started"""
+    common = ["--workload", "cfg4s", "--scale", "0.02", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--pairs", "60000", "--test-one-gpu"]
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+               "bench.py", "--gpus", "2"] + common)
+    assert two["n_gpus"] == 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+                        "bench.py", "--gpus", "4"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and "--gpus 4 but the launcher started 2 ranks" in (p.stdout + p.stderr)
