@@ -1563,6 +1563,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
                         if (ln == 0 || p + ln + 4 > n) { ok = false; break; }
                         names.emplace_back((const char *)u + p, ln - 1); p += ln; lens.push_back(rd32(u + p)); p += 4;
                     }
+                    if (ok && lens.empty()) { if (reader_on) reader.join(); return done(GCE_ERR_INVALID, "this SAM file has no header"); }      // src/gencore.cpp:186-189 (n_targets == 0), as the SAM-text branch does
                     if (ok) { complete = true; hdr_end = p; text.assign((const char *)u + tp, l_text); }
                 }
             }

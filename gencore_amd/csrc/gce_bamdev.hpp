@@ -127,6 +127,7 @@ __device__ __forceinline__ uint64_t raw_aux_size(uint8_t type, const uint8_t *p,
 }
 struct RawSoA {
     gce_core *core; uint64_t *qoff, *soff, *loff, *mioff; uint32_t *ncig, *nm_pos; int32_t *nm; uint8_t *nmt; unsigned int *have_mi;
+    unsigned int *bad_rec; int32_t n_ref;      // first record whose fields do not fit its block_size (atomicMin; NONE32 = none)
 };
 // one thread per record: the 32-byte key record, the offsets of name / bases / qualities INSIDE the raw stream, NM (first match, value as
 // bam_aux2i gives it) and MI:Z from the aux area (bamio.cpp scan_aux), the place of NM's value byte for the writer
@@ -140,6 +141,14 @@ __global__ __launch_bounds__(256) void k_raw_fill(const uint8_t *u, const uint64
     for (int k = 0; k < 8; k++) t.w[k] = rb32(r + 4 * k);
     reinterpret_cast<uint4 *>(o.core + i)[0] = t.q[0]; reinterpret_cast<uint4 *>(o.core + i)[1] = t.q[1];
     const uint32_t lq = t.c.l_qname, nc = t.c.n_cigar; const int32_t ls = t.c.l_qseq;
+    // The chain of block_size fields says where records start, not that their fields fit: the test gce_bam_open applies on the host
+    // (bamio.cpp, "inconsistent record lengths") -- a name, l_seq >= 0, name + CIGAR + bases + qualities inside block_size, contig ids
+    // inside the header's.  A record that fails it gets empty fields here (nothing downstream follows its lengths) and fails the stream.
+    if (lq == 0 || ls < 0 || 32ull + lq + 4ull * nc + (uint64_t)(ls + 1) / 2 + (uint64_t)ls > bs || t.c.tid < -1 || t.c.tid >= o.n_ref || t.c.mtid < -1 || t.c.mtid >= o.n_ref) {
+        atomicMin(o.bad_rec, (unsigned int)i);
+        o.qoff[i] = ro + 4; o.soff[i] = ro + 4; o.loff[i] = ro + 4; o.ncig[i] = 0; o.nm[i] = 0; o.nmt[i] = 0; o.nm_pos[i] = 0; o.mioff[i] = ~0ull;
+        return;
+    }
     const uint64_t q0 = ro + 36, c0 = q0 + lq, s0 = c0 + 4ull * nc, l0 = s0 + (uint64_t)(ls + 1) / 2, a0 = l0 + (uint64_t)ls;
     o.qoff[i] = q0; o.soff[i] = s0; o.loff[i] = l0; o.ncig[i] = nc;
     uint8_t nmt = 0; int32_t nm = 0; uint32_t nm_pos = 0; uint64_t mi = ~0ull;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void k_raw_cigar(const uint8_t *u, const uint6
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     const uint8_t *r = u + rec_off[i] + 4;
-    const uint32_t lq = r[8], nc = rb16(r + 12);
+    const uint32_t lq = r[8], nc = (uint32_t)(coff[i + 1] - coff[i]);           // (the count k_raw_fill accepted, not the record's own field)
     const uint8_t *c = r + 32 + lq;
     uint32_t *dst = cigar + coff[i];
     for (uint32_t k = 0; k < nc; k++) dst[k] = rb32(c + 4 * k);
@@ -272,6 +281,8 @@ int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket)
 // has been pushed so far.  Members with usize 0 (the EOF marker) may be passed or left out.  Asynchronous like gce_raw_push.
 int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_t n_members, const uint64_t *coff, const uint32_t *csize, const uint32_t *usize, int32_t *ticket) {
     if (!e || !e->raw_mode || n_members < 0 || (n_members && (!comp || !coff || !csize || !usize))) return GCE_ERR_INVALID;
+    for (int32_t k = 0; k < n_members; k++)                                             // every member is looked at before anything is queued or counted
+        if (coff[k] > comp_bytes || csize[k] > comp_bytes - coff[k] || usize[k] > 0x10000u) return fail(e, GCE_ERR_INVALID, "BGZF member outside its buffer");
     (void)hipSetDevice(e->prm.device);
     if (e->z_n + comp_bytes + 64 > e->z_comp.cap) {
         DevBuf nb;
@@ -282,7 +293,6 @@ int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_
     }
     if (comp_bytes) HIPCHK(hipMemcpyAsync((char *)e->z_comp.p + e->z_n, comp, comp_bytes, hipMemcpyHostToDevice, e->up_stream));
     for (int32_t k = 0; k < n_members; k++) {
-        if (coff[k] + csize[k] > comp_bytes || usize[k] > 0x10000u) return fail(e, GCE_ERR_INVALID, "BGZF member outside its buffer");
         if (usize[k] == 0) continue;
         InfDir d; d.coff = e->z_n + coff[k]; d.uoff = e->raw_n; d.csize = csize[k]; d.usize = usize[k];
         e->z_members.push_back(d); e->raw_n += usize[k];
@@ -344,7 +354,7 @@ int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_
     if (hipSetDevice(device) != hipSuccess) return GCE_ERR_NO_DEVICE;
     std::vector<InfDir> dir; uint64_t total = 0;
     for (int32_t k = 0; k < n_members; k++) {
-        if (coff[k] + csize[k] > comp_bytes || usize[k] > 0x10000u) return GCE_ERR_INVALID;
+        if (coff[k] > comp_bytes || csize[k] > comp_bytes - coff[k] || usize[k] > 0x10000u) return GCE_ERR_INVALID;
         InfDir d; d.coff = coff[k]; d.uoff = total; d.csize = csize[k]; d.usize = usize[k]; dir.push_back(d); total += usize[k];
     }
     if (dir.empty()) return GCE_OK;
@@ -439,7 +449,8 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
     unsigned int have_mi = 0;
     if (n_rec) {
         RawSoA o{e->b_core.as<gce_core>(), e->b_qoff.as<uint64_t>(), e->b_soff.as<uint64_t>(), e->b_loff.as<uint64_t>(), e->b_mioff.as<uint64_t>(), e->rw_ncig.as<uint32_t>(), e->rw_nmpos.as<uint32_t>(),
-                 e->b_nm.as<int32_t>(), e->b_nmt.as<uint8_t>(), e->rw_misc.as<unsigned int>() + 2};
+                 e->b_nm.as<int32_t>(), e->b_nmt.as<uint8_t>(), e->rw_misc.as<unsigned int>() + 2, e->rw_misc.as<unsigned int>() + 4, n_ref};
+        HIPCHK(hipMemsetAsync(e->rw_misc.as<unsigned int>() + 4, 0xFF, 4, s));
         const unsigned nbr = (unsigned)((n_rec + 255) / 256);
         hipLaunchKernelGGL(k_raw_fill, dim3(nbr), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, n_rec, o);
         size_t tb = 0;
@@ -451,7 +462,10 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, it, e->b_coff.as<uint64_t>(), (int)(n_rec + 1), s));
         HIPCHK(hipMemcpyAsync(&cig_words, e->b_coff.as<uint64_t>() + n_rec, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&have_mi, e->rw_misc.as<unsigned int>() + 2, 4, hipMemcpyDeviceToHost, s));
+        unsigned int bad_rec = NONE32;
+        HIPCHK(hipMemcpyAsync(&bad_rec, e->rw_misc.as<unsigned int>() + 4, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (bad_rec != NONE32) { char m[96]; snprintf(m, sizeof m, "inconsistent record lengths (record %u)", bad_rec); return fail(e, GCE_ERR_INVALID, m); }
         HIPCHK(e->b_cigar.ensure((size_t)cig_words * 4 + 64));
         hipLaunchKernelGGL(k_raw_cigar, dim3(nbr), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, n_rec, (const uint64_t *)e->b_coff.p, e->b_cigar.as<uint32_t>());
     } else HIPCHK(e->b_cigar.ensure(64));

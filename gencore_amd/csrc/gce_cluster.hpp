@@ -578,7 +578,10 @@ __global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Wo
                 if (k.l_qseq > 65535) raise_error(w.si, GCE_ERR_INVALID, (uint32_t)i);      // the 16-bit fields of the descriptor (and of the overlap patches)
                 if (p.ref_win && k.isize != 0 && k.tid < p.n_ref && p.ref_data[k.tid]) {    // per-shard reference windows: what the vote may look up must be staged
                     const int64_t rl = k.n_cigar == 1 ? (int64_t)cig_len(c0w) * consumes_ref(cig_op(c0w)) : (int64_t)d_cigar_rlen(cg, k.n_cigar);
-                    if ((int64_t)k.pos < p.ref_win[2 * k.tid] || (int64_t)k.pos + rl > p.ref_win[2 * k.tid + 1]) raise_error(w.si, GCE_ERR_REF_WINDOW, (uint32_t)i);
+                    // (a read that overhangs the contig's end is never looked up -- Reference::getData returns NULL, reference.cpp:40,60 -- and the
+                    //  staged window cannot reach past the contig: only the bases inside the contig must be there)
+                    const int64_t end_in = min((int64_t)k.pos + rl, p.ref_len[k.tid]);
+                    if ((int64_t)k.pos < p.ref_win[2 * k.tid] || end_in > p.ref_win[2 * k.tid + 1]) raise_error(w.si, GCE_ERR_REF_WINDOW, (uint32_t)i);
                 }
                 store_desc(w.rdesc, (uint64_t)i, b.seq_off[i], b.qual_off[i], c0w, k.pos, k.isize != 0, k.l_qseq, mo_, ml_, k.n_cigar, k.tid, k.n_cigar > 1 ? cg[k.n_cigar - 1] : c0w);
                 // Pair::setLeft/setRight -> BamUtil::getUMI, bamutil.cpp:23-38

@@ -12,7 +12,8 @@
 //   * output straight into the raw stream in HBM: literals byte by byte, matches eight bytes at a time when the distance allows it (a lane
 //     reads back what it wrote itself: ordinary program order);
 //   * CRC-32 of the member (slicing-by-8, tables in LDS, shared by the wave) and its ISIZE are checked; a member that fails any check raises
-//     the launch's error flag and the caller falls back to the host decoder for the file.
+//     the launch's error flag and the run fails (GCE_ERR_INVALID from gce_raw_finish; gce_run_bam with GCE_BAM_HOST_INFLATE=1 or
+//     gce_run_bam_hostcodec decode the same file on the host, with zlib as arbiter).
 // Every input read is bounded by the member (the staging buffer is padded by 16 bytes), every output write by ISIZE.
 #pragma once
 

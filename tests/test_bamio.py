@@ -419,3 +419,96 @@ def test_bam_end_to_end_with_mi_tags(built, oracle, tmp_path):
     for g, e in zip(sorted(got, key=key), exp):
         assert (g["qname"], g["flag"], g["pos"], g["seq"], g["qual"]) == (e["qname"], e["flag"], e["pos"], e["seq"], e["qual"])
         assert g["aux"].get("FR", (None, -1))[1] == e["fr"] and g["aux"]["MI"][0] == "Z"
+
+
+def _small_pairs(n=12, L=20, ref_len=2000):
+    import random
+    rng = random.Random(3)
+    ref = "".join(rng.choice("ACGT") for _ in range(ref_len))
+    recs = []
+    for m in range(n):
+        left = 50 + 31 * m
+        right = left + 120
+        isz = right + L - left
+        q = [rng.choice([37, 25, 11]) for _ in range(L)]
+        recs.append(dict(qname="p%02d" % m, flag=99, tid=0, pos=left, cigar="%dM" % L, mtid=0, mpos=right, isize=isz, seq=ref[left:left + L], qual=q, nm=0))
+        recs.append(dict(qname="p%02d" % m, flag=147, tid=0, pos=right, cigar="%dM" % L, mtid=0, mpos=left, isize=-isz, seq=ref[right:right + L], qual=q, nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    return ref, recs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damage", ["l_read_name_0", "l_seq_negative", "n_cigar_65535", "tid_out_of_range", "mtid_out_of_range", "l_seq_past_block"])
+def test_damaged_record_fields_fail_the_gpu_codec(built, tmp_path, damage):
+    """A record whose fields do not fit its block_size (CRCs fine: written that way) must fail gce_run_bam's GPU path with
+    GCE_ERR_INVALID and the record's index, as gce_bam_open's "inconsistent record lengths" does on the host -- not read out of range."""
+    import struct
+    import zlib
+    from gencore_amd.bamio import run_bam
+    from gencore_amd.capi import GceError
+    ref, recs = _small_pairs()
+    blobs = [bytearray(pybam.record_bytes(r)) for r in recs]
+    k = 5
+    b = blobs[k]                                               # [block_size][tid pos l_read_name mapq bin n_cigar flag l_seq mtid mpos isize]...
+    if damage == "l_read_name_0":
+        b[4 + 8] = 0
+    elif damage == "l_seq_negative":
+        struct.pack_into("<i", b, 4 + 16, -7)
+    elif damage == "n_cigar_65535":
+        struct.pack_into("<H", b, 4 + 12, 65535)
+    elif damage == "tid_out_of_range":
+        struct.pack_into("<i", b, 4 + 0, 3)
+    elif damage == "mtid_out_of_range":
+        struct.pack_into("<i", b, 4 + 20, 9)
+    elif damage == "l_seq_past_block":
+        struct.pack_into("<i", b, 4 + 16, 4000)
+    text = "@HD\tVN:1.6\tSO:coordinate\n"
+    stream = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + struct.pack("<i", 3) + b"c0\0" + struct.pack("<i", len(ref))
+    stream += b"".join(bytes(x) for x in blobs)
+    src, out = tmp_path / "in.bam", tmp_path / "out.bam"
+    src.write_bytes(pybam.bgzf_block(stream) + pybam.EOF_BLOCK)
+    with pytest.raises(GceError) as ei:
+        run_bam(str(src), str(out), default_params(), threads=2)
+    assert ei.value.status == -1 and "inconsistent record lengths (record %d)" % k in str(ei.value), str(ei.value)
+    # and the same stream undamaged runs
+    good = tmp_path / "good.bam"
+    pybam.write_bam(str(good), recs, [("c0", len(ref))])
+    run = run_bam(str(good), str(out), default_params(), threads=2)
+    assert run.n_reads == len(recs)
+
+
+@pytest.mark.gpu
+def test_bam_without_contigs_is_refused(built, tmp_path):
+    """src/gencore.cpp:186-189: n_targets == 0 -> "this SAM file has no header"; the BAM branch of gce_run_bam as the SAM-text one."""
+    from gencore_amd.bamio import run_bam
+    from gencore_amd.capi import GceError
+    src = tmp_path / "in.bam"
+    pybam.write_bam(str(src), [dict(qname="a", flag=4, tid=-1, pos=-1, cigar="*", mtid=-1, mpos=-1, isize=0, seq="ACGT", qual=[1] * 4, nm=None)], [])
+    with pytest.raises(GceError) as ei:
+        run_bam(str(src), str(tmp_path / "out.bam"), default_params(), threads=2)
+    assert "no header" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_sharded_run_with_a_read_over_the_contig_end(built, tmp_path):
+    """A read that overhangs the end of its FASTA contig (the FASTA contig is shorter than @SQ LN): gce_run_bam skips the reference lookup
+    (Reference::getData returns NULL, reference.cpp:40,60); the sharded runner's per-shard windows must not fail it either."""
+    from gencore_amd.bamio import run_bam, run_bam_sharded
+    ref, recs = _small_pairs(n=14, L=20, ref_len=700)
+    # the FASTA holds 20 bases less than the header says: the last pair's right read [504+..] stays inside, so push one pair to the very end
+    last_left, last_right = 400, 670
+    isz = last_right + 20 - last_left
+    q = [37] * 20
+    recs.append(dict(qname="zz", flag=99, tid=0, pos=last_left, cigar="20M", mtid=0, mpos=last_right, isize=isz, seq=ref[last_left:last_left + 20], qual=q, nm=0))
+    recs.append(dict(qname="zz", flag=147, tid=0, pos=last_right, cigar="20M", mtid=0, mpos=last_left, isize=-isz, seq=ref[last_right:last_right + 20], qual=q, nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    src, fa = tmp_path / "in.bam", tmp_path / "ref.fa"
+    pybam.write_bam(str(src), recs, [("c0", len(ref))])
+    fa.write_text(">c0\n" + ref[:680] + "\n")                  # pos 670 + 20 = 690 > 680: overhang
+    one, two = tmp_path / "one.bam", tmp_path / "two.bam"
+    prm = default_params(flush_period=7)
+    r1 = run_bam(str(src), str(one), prm, fasta=str(fa), threads=2)
+    r2 = run_bam_sharded(str(src), str(two), default_params(flush_period=7), [0, 0, 0], fasta=str(fa), threads=2)
+    assert r1.n_out == r2.n_out and bytes(r1.pre) == bytes(r2.pre) and bytes(r1.post) == bytes(r2.post)
+    a, b = pybam.read_bam(str(one))[2], pybam.read_bam(str(two))[2]
+    assert [(x["qname"], x["flag"], x["pos"], x["seq"], x["qual"], x["aux"]) for x in a] == [(x["qname"], x["flag"], x["pos"], x["seq"], x["qual"], x["aux"]) for x in b]

@@ -72,7 +72,7 @@ def test_oracle_matches_hand_derivation(oracle, name):
 
 
 def test_vectors_present():
-    assert len(CASES) >= 23
+    assert len(CASES) >= 27
 
 
 @pytest.mark.gpu
