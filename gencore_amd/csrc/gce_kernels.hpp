@@ -68,6 +68,9 @@ struct Work {
 };
 
 enum : uint8_t { RP_PENDING = 0, RP_OUT_SSCS = 1, RP_OUT_DCS = 2, RP_DROPPED = 3, RP_CONSUMED = 4 };
+// rp_nm: >= 0 the new NM byte, -1 untouched, NM_DEFER + mismatchInc (k_vote): the delta of a template whose NM tag has not been looked at yet
+#define NM_DEFER (-0x40000000)
+#define NM_IS_DEFERRED(v) ((v) < -0x20000000)
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -1725,6 +1728,21 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
     const uint32_t c = w.gl_cluster[gi];
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t left = w.rp_left[gi], right = w.rp_right[gi];
+    {   // the NM patches k_vote deferred (group.cpp:528-573): mismatchInc != 0 reads the template's NM tag -- absent: the reference crashes (quirk Q9);
+        // mismatchInc > 5: the template was restored, NM stays; else NM + mismatchInc goes into the tag if it is stored as type 'C' and stays a byte
+        const int2 nv = *reinterpret_cast<const int2 *>(w.rp_nm + 2 * (size_t)gi);
+        if (NM_IS_DEFERRED(nv.x) || NM_IS_DEFERRED(nv.y)) {
+            int2 o = nv;
+            auto resolve = [&](int v, uint32_t out) -> int {
+                if (!NM_IS_DEFERRED(v)) return v;
+                const int minc = v - NM_DEFER, ty = b.nm_type[out], nn = b.nm[out] + minc;
+                if (ty == 0) { raise_error(w.si, GCE_ERR_NM_MISSING, out); return -1; }
+                return (minc <= 5 && ty == 'C' && nn >= 0 && nn <= 255) ? nn : -1;
+            };
+            o.x = resolve(nv.x, left); o.y = resolve(nv.y, right);
+            *reinterpret_cast<int2 *>(w.rp_nm + 2 * (size_t)gi) = o;
+        }
+    }
     const uint8_t cflags = w.cl_hasumi[c];
     const uint32_t G = w.cl_ngroups[c];
     const bool single = np == 1 && w.gpr[begin] == NONE32;

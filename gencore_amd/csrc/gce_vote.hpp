@@ -170,6 +170,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ uint16_t s_jpre[VB_SIDES + 1];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
     __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
+    __shared__ uint16_t s_wbase[VB_SIDES][VB_COLS / 32];                           // place in the contested-column list of the first column of every 32-column word (P5b -> P7)
     __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng, s_np;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             if (s_cpre[s + 1] > s_cpre[s]) {
                 int base = s_cpre[s];
                 for (int x = 0; x < k; x++) base += __popc(word(x));
+                s_wbase[s][k] = (uint16_t)base;
                 for (uint32_t m = mk; m; m &= m - 1) s_ccol[base++] = (uint8_t)(32 * k + __ffs((int)m) - 1);
             }
         }
@@ -621,13 +623,16 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (s_cpre[s0] >= n_cont) break;
     }
     VB_TICK(8);
-    // ---------------------------------------------------------------- P6: results per (group, side); NM patch or restore (group.cpp:528-573)
+    // ---------------------------------------------------------------- P6: results per (group, side)   (group.cpp:528-573)
+    // Stores only, and no barrier behind it: what the write-back needs -- "handed on" (s_gflag) and "restore" (mismatchInc > 5) -- every P7 lane
+    // derives itself from the side's final minc (side_state below).  The NM patch is DEFERRED: the template's NM tag (two dependent global
+    // loads in a phase where the whole block waited for them: 0.33 ms of the kernel for 2 % of its instructions) is looked at by k_group_tail,
+    // a thread per group with nothing waiting on it; here only the mismatch delta is noted (NM_DEFER + mismatchInc).
     if (tid < 2 * ng) {
         const int j = tid >> 1, side = tid & 1;
         const uint32_t gi = s_ggi[j];
-        VSide *sd = &s_side[tid];
+        const VSide *sd = &s_side[tid];
         if (s_gflag[j] == 2) {                                                          // found out of scope on the way: the whole group goes on, untouched
-            if (sd->state == VS_ACTIVE || sd->state == VS_FINAL) sd->state = VS_GEN;
             if (side == 0) {
                 w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
                 for (int k = 0; k < (int)s_gnp[j]; k++) w.slot_flag[s_gbeg[j] + k] = 1;
@@ -635,21 +640,17 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         } else if (s_gflag[j] == 0) {
             uint32_t *rp_out = side ? w.rp_right : w.rp_left;
             if (sd->state == VS_ACTIVE) {
-                const uint32_t out = sd->result;
-                const int minc = sd->minc;
-                bool restore = false;
-                if (minc != 0) {
-                    const int o_nm_type = b.nm_type[out], o_nm = b.nm[out];
-                    if (o_nm_type == 0) { raise_error(w.si, GCE_ERR_NM_MISSING, out); restore = true; }
-                    else if (minc > 5) restore = true;
-                    else { const int nn = o_nm + minc; if (o_nm_type == 'C' && nn >= 0 && nn <= 255) w.rp_nm[2 * gi + side] = nn; }
-                }
-                if (restore) sd->state = VS_RESTORE;
-                rp_out[gi] = out;
+                if (sd->minc != 0) w.rp_nm[2 * gi + side] = NM_DEFER + sd->minc;         // -> k_group_tail: NM missing is fatal (quirk Q9), > 5 leaves NM alone, else the patch of group.cpp:569-571
+                rp_out[gi] = sd->result;
             } else if (sd->state == VS_FINAL) rp_out[gi] = sd->result;
         }
     }
-    __syncthreads();
+    // the state of a side as the write-back sees it
+    auto side_state = [&](const VSide &sd) -> int {
+        if (s_gflag[sd.grp] == 2) return (sd.state == VS_ACTIVE || sd.state == VS_FINAL) ? (int)VS_GEN : (int)sd.state;
+        if (s_gflag[sd.grp] == 0 && sd.state == VS_ACTIVE && sd.minc > 5) return (int)VS_RESTORE;
+        return (int)sd.state;
+    };
     VB_TICK(9);
     // ---------------------------------------------------------------- P7: the templates go back (the only writes to the reads)
     // (a) a restored template (mismatchInc > 5, group.cpp:528-558): seq and qual come back from the backup taken AFTER computeScore
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (it < n_items) {
             const int s = item_side[kk];
             const VSide sd = s_side[s];
-            if (sd.state == VS_RESTORE) {
+            if (side_state(sd) == VS_RESTORE) {
                 any_restore = true;
                 const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16), side = s & 1;
                 const int lp = sd.lp0 + sd.tmpl;
@@ -690,17 +691,17 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (it < n_items) {
             const int s = item_side[kk];
             const VSide sd = s_side[s];
-            if (sd.state != VS_ACTIVE && sd.state != VS_RESTORE) continue;
+            const int st = side_state(sd);
+            if (st != VS_ACTIVE && st != VS_RESTORE) continue;
             const int chunk = it - (int)sd.item0, c16 = 16 * chunk, nval = min(16, (int)sd.len - c16);
             const VRead *r = &s_rd[s & 1][sd.lp0 + sd.tmpl];
             uint8_t *oq = b.qual + r->qo + c16, *os = b.seq + r->so + 8 * chunk;
             uint64_t qlo = (uint64_t)keep[kk].x | ((uint64_t)keep[kk].y << 32), qhi = (uint64_t)keep[kk].z | ((uint64_t)keep[kk].w << 32);
-            uint32_t cm = sd.state == VS_ACTIVE ? (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu : 0u;
+            uint32_t cm = st == VS_ACTIVE ? (s_cmask[s][chunk >> 1] >> (16 * (chunk & 1))) & 0xFFFFu : 0u;
             uint64_t x = 0, x0 = 0; int nbytes = 0;
             if (cm) {
                 // the voted columns of this chunk: their place in the side's list = contested columns in front of them
-                int ci = s_cpre[s];
-                for (int q = 0; q < (chunk >> 1); q++) ci += __popc(s_cmask[s][q]);
+                int ci = s_wbase[s][chunk >> 1];                                        // (P5b: columns of the side in front of this 32-column word)
                 if (chunk & 1) ci += __popc(s_cmask[s][chunk >> 1] & 0xFFFFu);
                 nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
                 x = ld8_unaligned(os);                                                  // (blobs are readable past a read's last byte)
@@ -724,7 +725,10 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
                 if (nval & 2) { *(u16u *)(oq + o) = (uint16_t)v; v >>= 16; o += 2; }
                 if (nval & 1) oq[o] = (uint8_t)v;
             }
-            if (x != x0) for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
+            if (x != x0) {                                                               // (the lane owns the chunk's bytes: one store when all eight are the read's)
+                if (nbytes == 8) *(u64u *)os = x;
+                else for (int k = 0; k < nbytes; k++) if ((uint8_t)(x >> (8 * k)) != (uint8_t)(x0 >> (8 * k))) os[k] = (uint8_t)(x >> (8 * k));
+            }
         }
     }
     VB_TICK(10);
