@@ -666,12 +666,12 @@ int gce_process(gce_engine *e) {
         // the compact group list and the batches of k_vote: sized by N (groups <= pairs <= reads) so that all of it runs before the one
         // host round trip that fetches the group count and the batch count together
         ENS(gl_cluster, n1 * 4); ENS(g_begin, n1 * 4); ENS(g_np, n1 * 4); ENS(gw, n1 * 8); ENS(g_wbase, n1 * 4);
-        const size_t vb_cap = (7 * n1) / VB_W + 8;                 // sum of weights <= 4 x groups + pairs + 64 x deep groups
+        const size_t vb_cap = ((VB_MINW + 3) * n1) / VB_W + 8;     // sum of weights <= VB_MINW x groups + pairs + VB_W x deep groups (> 32 pairs each)
         ENS(vb_start, vb_cap * 4);
         w.gl_cluster = e->gl_cluster.as<uint32_t>(); w.g_begin = e->g_begin.as<uint32_t>(); w.g_np = e->g_np.as<uint32_t>();
         w.gw = e->gw.as<uint64_t>(); w.g_wbase = e->g_wbase.as<uint32_t>(); w.vb_start = e->vb_start.as<uint32_t>();
         HIPCHK(hipMemsetAsync(e->vb_start.p, 0xFF, vb_cap * 4, s));
-        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr, (uint32_t)VB_W);
+        hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr, (uint32_t)VB_W, (uint32_t)VB_MINW);
         hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)w.gw, (const unsigned long long *)&w.si->n_groups, w.scan_part);
         hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_groups, &w.si->vote_weight);
         hipLaunchKernelGGL(k_vote_batches, dim3(nblk_N), dim3(256), 0, s, w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_pairing_fast(DevBatch b, DevParams p, W
 }
 
 // exclusive scan helper over a uint32 array (small-ish n): element = v[i]; reuses the table-scan kernels via tab_elem's low word
-__global__ void k_group_fill(Work w, uint32_t n_clusters, int skip_thr, uint32_t deep_weight) {
+__global__ void k_group_fill(Work w, uint32_t n_clusters, int skip_thr, uint32_t deep_weight, uint32_t min_weight) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_clusters) return;
     uint32_t g0 = w.cl_gbase[c], ng = w.cl_ngroups[c];
@@ -519,8 +519,8 @@ __global__ void k_group_fill(Work w, uint32_t n_clusters, int skip_thr, uint32_t
     for (uint32_t g = 0; g < ng; g++) {
         const uint32_t np = w.grp_n[cs + g];
         w.gl_cluster[g0 + g] = c; w.g_begin[g0 + g] = w.grp_begin[cs + g]; w.g_np[g0 + g] = np;
-        // k_vote batches (gce_vote.hpp): a group weighs its pairs (at least 4: <= 16 groups per batch); a deep group is handed on by a batch of its own
-        w.gw[g0 + g] = (np > 32u || (int)np > skip_thr) ? (uint64_t)deep_weight : (uint64_t)(np < 4u ? 4u : np);
+        // k_vote batches (gce_vote.hpp): a group weighs its pairs (at least VB_MINW: <= 16 groups per batch); a deep group is handed on by a batch of its own
+        w.gw[g0 + g] = (np > 32u || (int)np > skip_thr) ? (uint64_t)deep_weight : (uint64_t)(np < min_weight ? min_weight : np);
     }
 }
 // scan of cl_ngroups -> cl_gbase : same 3-phase scheme on the plain counts

@@ -35,22 +35,28 @@
 #define VB_T 256           // threads per batch
 #endif
 #ifndef VB_W
-#define VB_W 64            // batch capacity in weight units (weight of a group = max(pairs, 4); a handed-on deep group takes a whole batch)
+#define VB_W 96            // batch capacity in weight units (weight of a group = max(pairs, VB_MINW); a handed-on deep group takes a whole batch).  64 -> 96 in round 4:
+                           // a batch's fixed phases and barriers carry half as many pairs again and pass A fills its lanes (k_vote 3.07 -> 2.89 ms)
 #endif
-#define VB_MINW 4
+static_assert(VB_W + 32 <= 128, "P1 finds a pair's group by a bytewise compare of 7-bit pair indices");
+#define VB_MINW (VB_W / 16) // smallest weight of a group: <= 16 groups per batch (P1's bytewise group search, one lane per (group, side) in a wave)
 #define VB_MAXG (VB_W / VB_MINW)
 #define VB_MAXP (VB_W + 32)                // a batch's last group may reach over the end: < VB_W + 32 pairs
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
 #ifndef VB_CCAP
-#define VB_CCAP 192
+#define VB_CCAP 184        // (with VB_RCAP: LDS stays within 22.5 KB = seven workgroups per CU; 168 / 640: 2.86 ms, 184 / 512: 2.82 ms)
 #endif
 //   VB_CCAP: contested columns voted per round (LDS tallies)
 #ifndef VB_WPE
 #define VB_WPE 7
 #endif
+#ifndef VB_SMAX
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
-#define VB_RCAP (VB_SIDES * VB_SMAX)
+#endif
+#ifndef VB_RCAP
+#define VB_RCAP 512        // contested columns of a whole batch (all rounds): a side that does not fit any more hands its group on (32 sides x VB_SMAX would be 1024)
+#endif
 
 struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
 static_assert(sizeof(VRead) == 32, "VRead must stay 32 bytes");
@@ -495,9 +501,18 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         const int over = cnt > VB_SMAX, other_over = __shfl_xor(over, 1);
         if (over && lane < VB_SIDES) s_gflag[s_side[lane].grp] = 2;
         if (over || other_over || !act) cnt = 0;
+        int pre = cnt;
+        pre = wave_scan_incl(pre);
+        if (__any(pre > VB_RCAP)) {                                                     // (rare) the batch's column lists are full: the sides behind go on as well
+            const int over2 = cnt > 0 && pre > VB_RCAP, other2 = __shfl_xor(over2, 1);
+            if (over2 && lane < VB_SIDES) s_gflag[s_side[lane].grp] = 2;
+            if (over2 || other2) cnt = 0;
+            pre = cnt;
+            pre = wave_scan_incl(pre);                                                  // (dropping sides only lowers the prefixes of the others)
+        }
         const int nit = act ? cnt * (int)s_side[lane].nvot : 0;
-        int pre = cnt, pre2 = nit;
-        pre = wave_scan_incl(pre); pre2 = wave_scan_incl(pre2);
+        int pre2 = nit;
+        pre2 = wave_scan_incl(pre2);
         if (lane < VB_SIDES) { s_cpre[lane] = (uint16_t)(pre - cnt); s_jpre[lane] = (uint16_t)(pre2 - nit); }
         if (lane == VB_SIDES - 1) { s_cpre[VB_SIDES] = (uint16_t)pre; s_jpre[VB_SIDES] = (uint16_t)pre2; }
     }

@@ -22,6 +22,15 @@ __global__ __launch_bounds__(64) void k_rate(unsigned long long *cyc, uint32_t *
         if (KIND == 3) OP16("v_pk_max_u16");
         if (KIND == 4) OP16("v_lshlrev_b32");
         if (KIND == 5) OP16("v_pk_add_u16");
+        if (KIND == 6) OP16("v_max_u32");
+#define OPS16(ins, tail) asm volatile(ins " %0, %0, %16 " tail "\n" ins " %1, %1, %16 " tail "\n" ins " %2, %2, %16 " tail "\n" ins " %3, %3, %16 " tail "\n" ins " %4, %4, %16 " tail "\n" ins " %5, %5, %16 " tail "\n" ins " %6, %6, %16 " tail "\n" ins " %7, %7, %16 " tail "\n" \
+                               ins " %8, %8, %16 " tail "\n" ins " %9, %9, %16 " tail "\n" ins " %10, %10, %16 " tail "\n" ins " %11, %11, %16 " tail "\n" ins " %12, %12, %16 " tail "\n" ins " %13, %13, %16 " tail "\n" ins " %14, %14, %16 " tail "\n" ins " %15, %15, %16 " tail "\n" \
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(c))
+        if (KIND == 7) OPS16("v_max_u16_sdwa", "dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1");      // bytewise max in place (k_vote pass A candidate)
+        if (KIND == 8) OPS16("v_perm_b32", ", %16");
+        if (KIND == 9) OPS16("v_bfi_b32", ", %16");
+        if (KIND == 10) OPS16("v_and_or_b32", ", %16");
+        if (KIND == 11) OPS16("v_max_u16_sdwa", "dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_2");
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -54,5 +63,11 @@ int main() {
     run<3>("v_pk_max_u16", cyc, sink, pr.multiProcessorCount);
     run<4>("v_lshlrev_b32", cyc, sink, pr.multiProcessorCount);
     run<5>("v_pk_add_u16", cyc, sink, pr.multiProcessorCount);
+    run<6>("v_max_u32", cyc, sink, pr.multiProcessorCount);
+    run<7>("v_max_u16_sdwa(byte)", cyc, sink, pr.multiProcessorCount);
+    run<8>("v_perm_b32", cyc, sink, pr.multiProcessorCount);
+    run<9>("v_bfi_b32", cyc, sink, pr.multiProcessorCount);
+    run<10>("v_and_or_b32", cyc, sink, pr.multiProcessorCount);
+    run<11>("v_max_u16_sdwa(w<-b)", cyc, sink, pr.multiProcessorCount);
     return 0;
 }
