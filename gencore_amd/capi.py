@@ -35,7 +35,7 @@ class GceParams(C.Structure):
         ("disable_duplex", C.c_int32), ("flush_period", C.c_int32),
         ("score_percent_req", C.c_double), ("umi_prefix", C.c_char * 32),
         ("n_targets", C.c_int32), ("target_len", C.c_void_p),
-        ("tick_offset", C.c_int64), ("trailing_flush", C.c_int32), ("reserved", C.c_int32),
+        ("tick_offset", C.c_int64), ("trailing_flush", C.c_int32), ("max_contig", C.c_int32),
     ]
 
 

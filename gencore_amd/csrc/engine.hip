@@ -84,7 +84,7 @@ struct gce_engine {
     DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     gce_timing timing{};
-    int64_t n = 0;
+    int64_t n = 0, n_pre = 0;            // reads processed; reads counted by the pre-Stats (one more when --quit_after_contig cut the stream)
     // depth statistics (gce_depth_stats)
     DevBuf dp_binoff, dp_regoff, dp_rs, dp_re, dp_pmax, dp_sorted, dp_depth, dp_bed;
     std::vector<int64_t> h_binoff, h_depth_pre, h_depth_post, h_bed_pre, h_bed_post;
@@ -253,13 +253,21 @@ int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid,
 
 // the six addRead counters of either Stats block are spread over GCE_PRE_SLOTS words each (k_describe, k_out_meta): summed into the
 // blocks themselves, the slots cleared, so that the device copy is complete (the host adds the slots of ITS copy: zeros after this)
-__global__ void k_fold_stats(StreamInfo *si) {
+struct PreExtra { long long v[6]; };      // addRead of the read on which --quit_after_contig ended the loop (counted, then ignored)
+__global__ void k_fold_stats(StreamInfo *si, PreExtra x) {
     const int k = threadIdx.x;
     if (k < 6) {
         long long a = 0, c = 0;
         for (int q = 0; q < GCE_PRE_SLOTS; q++) { a += si->pre_slot[q][k]; c += si->post_slot[q][k]; si->pre_slot[q][k] = 0; si->post_slot[q][k] = 0; }
-        si->pre[k] += a; si->post[k] += c;
+        si->pre[k] += a + x.v[k]; si->post[k] += c;
     }
+}
+// --quit_after_contig: the first read whose tid >= max_contig (the stream is sorted, unmapped reads -- tid -1 -- never match)
+__global__ void k_first_contig_ge(const gce_core *core, int64_t n, int32_t maxc, unsigned int *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = i < n && core[i].tid >= maxc;
+    const unsigned long long m = __ballot(hit);
+    if (m && (threadIdx.x & 63) == 0) { const unsigned int v = (unsigned int)(i + __ffsll((long long)m) - 1); if (v < *(volatile unsigned int *)out) atomicMin(out, v); }
 }
 
 __global__ void k_add_u64(uint64_t *a, uint64_t n, uint64_t base) {
@@ -457,7 +465,25 @@ int gce_process(gce_engine *e) {
     int rc;
     if (e->host_mode && (rc = upload(e)) != GCE_OK) return rc;
     const gce_batch &hb = e->dev_batch;
-    const int64_t N = hb.n_reads;
+    int64_t N = hb.n_reads;
+    PreExtra pre_extra{};
+    e->n_pre = N;
+    if (e->prm.max_contig > 0 && N > 0) {                                          // src/gencore.cpp:243-246: the loop ends on the first read of contig >= maxContig
+        HIPCHK(e->si.ensure(sizeof(StreamInfo)));
+        unsigned int first = NONE32;
+        HIPCHK(hipMemcpyAsync(e->si.p, &first, 4, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_first_contig_ge, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, e->stream, hb.core, N, e->prm.max_contig, (unsigned int *)e->si.p);
+        HIPCHK(hipMemcpyAsync(&first, e->si.p, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (first != NONE32) {
+            gce_core c2; int32_t nm = 0; uint8_t nmt = 0;                            // (the sorted check of :233-241 cannot fail on this read: every read in front has a smaller tid)
+            HIPCHK(hipMemcpy(&c2, hb.core + first, sizeof(gce_core), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&nm, hb.nm + first, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&nmt, hb.nm_type + first, 1, hipMemcpyDeviceToHost));
+            const int mism = nmt != 0 ? nm : 0;                                     // Stats::addRead (stats.cpp:101-121): the read is mapped (tid >= maxContig > 0)
+            pre_extra.v[0] = 1; pre_extra.v[1] = c2.l_qseq; pre_extra.v[4] = mism; pre_extra.v[5] = mism > 0;
+            N = (int64_t)first; e->n_pre = N + 1;
+        }
+    }
     e->n = N; e->n_out = 0; e->out_seq_bytes = e->out_qual_bytes = 0; e->dev_error = 0; e->dev_error_read = 0;
     e->processed = true;
     memset(&e->timing, 0, sizeof e->timing);
@@ -802,7 +828,7 @@ int gce_process(gce_engine *e) {
     }
     HIPCHK(hipEventRecord(e->ev[EV_OUTPUT], s));
     CANARY("EV_OUTPUT");
-    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, s, w.si);          // (outside the timed step: a convenience of gce_stats_device)
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, s, w.si, pre_extra);          // (outside the timed step: a convenience of gce_stats_device)
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
 #ifdef GCE_SI_CHECK       // debugging build: the post block's histogram only ever has entry 1 (outputPair: addMolecule(1, PE)) -- anything else is a stray write
@@ -923,7 +949,7 @@ int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_
     DepthCtx c; c.bin_off = e->dp_binoff.as<int64_t>(); c.n_targets = nt; c.step = step; c.reg_off = e->dp_regoff.as<int32_t>();
     c.r_start = e->dp_rs.as<int32_t>(); c.r_end = e->dp_re.as<int32_t>(); c.r_pmax = e->dp_pmax.as<int32_t>(); c.contig_sorted = e->dp_sorted.as<uint8_t>();
     unsigned long long *dpre = e->dp_depth.as<unsigned long long>(), *dpost = dpre + nbins, *bpre = e->dp_bed.as<unsigned long long>(), *bpost = bpre + nreg;
-    const uint64_t n = (uint64_t)e->n, no = (uint64_t)e->n_out;
+    const uint64_t n = (uint64_t)e->n_pre, no = (uint64_t)e->n_out;
     if (n) hipLaunchKernelGGL(k_depth, dim3(cdiv(n, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)nullptr, n, c, dpre, bpre);
     if (no) hipLaunchKernelGGL(k_depth, dim3(cdiv(no, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)e->o_src.p, no, c, dpost, bpost);
     e->h_depth_pre.resize(nbins); e->h_depth_post.resize(nbins);

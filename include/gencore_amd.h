@@ -101,7 +101,11 @@ typedef struct gce_params {
      * cluster key use gce_batch.tick + gce_set_flush_events instead. */
     int64_t tick_offset;
     int32_t trailing_flush;
-    int32_t reserved;
+    /* --quit_after_contig (Options::maxContig, src/options.cpp:10, src/gencore.cpp:243-246): > 0: the read loop ends at the first read whose
+     * tid >= max_contig -- that read is still counted by the pre-Stats (addRead comes first, :222) and sorted-checked (:233-241), then it and
+     * everything behind it are ignored; what is pending is finished as at the end of the file.  0: off.  (The field was `reserved`, always 0,
+     * up to ABI 3: additive.) */
+    int32_t max_contig;
 } gce_params;
 
 /* A batch of reads in INPUT ORDER (coordinate-sorted), struct-of-arrays.  Offsets are start offsets, lengths

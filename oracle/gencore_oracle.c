@@ -971,6 +971,7 @@ int orc_run_shard(const gce_params *prm, const orc_reference *ref, gce_batch *ba
         if (k->tid < last_tid || (k->tid == last_tid && k->pos < last_pos)) {   /* :233-241 */
             if (k->tid >= 0 && k->pos >= 0) { fail(&ctx, GCE_ERR_UNSORTED, "ERROR: the input is unsorted"); break; }
         }
+        if (prm->max_contig > 0 && k->tid >= prm->max_contig) break;   /* :243-246 --quit_after_contig: counted and checked above, then the loop ends */
         last_tid = k->tid; last_pos = k->pos;
         if (k->tid < 0 || k->pos < 0) {                     /* :255-266: unmapped reads are dropped */
             if (!out_set_cleared) {

@@ -202,3 +202,45 @@ def test_quirk_cases_on_the_engine(built, case):
                      "q7a": lambda: case_q7(5), "q7b": lambda: case_q7(6), "q13": case_q13_mateless_scores_six}[case]()
     got, want = run_both(batch, p, ref)
     assert want.status == 0 and got is not None
+
+
+# ------------------------------------------------------------------------------------------------------------------ --quit_after_contig
+TL3 = np.asarray([100000, 100000, 100000], np.uint32)
+
+
+def case_quit_after_contig(maxc):
+    """Options::maxContig (src/gencore.cpp:243-246): the read loop ends on the first read whose tid >= maxContig.  That read has been
+    counted by the pre-Stats (:222) before (the sorted check of :233-241 cannot fail on it: every read in front has a smaller tid); it and everything behind it are ignored; pending clusters
+    are finished as at the end of the file (threshold 0).  Three contigs, one pair on each; x and y on contig 0 have UMIs one base apart."""
+    recs = pair("x:UMI_AAAA") + pair("y:UMI_AAAT")
+    for t in (1, 2):
+        for r in pair("c%d:UMI_CCCC" % t, left=500, right=530):
+            r["tid"] = t; r["mtid"] = t
+            recs.append(r)
+    recs = by_pos(recs)
+    p = default_params(n_targets=3, target_len=TL3.ctypes.data, umi_prefix="UMI", max_contig=maxc)
+    p._keep = TL3
+    return ReadBatch.from_records(recs), p, []
+
+
+@pytest.mark.parametrize("maxc,reads_counted,names", [(0, 8, {"x:UMI_AAAA", "y:UMI_AAAT", "c1:UMI_CCCC", "c2:UMI_CCCC"}), (1, 5, {"x:UMI_AAAA", "y:UMI_AAAT"}),
+                                                      (2, 7, {"x:UMI_AAAA", "y:UMI_AAAT", "c1:UMI_CCCC"}), (3, 8, {"x:UMI_AAAA", "y:UMI_AAAT", "c1:UMI_CCCC", "c2:UMI_CCCC"})])
+def test_quit_after_contig(oracle, maxc, reads_counted, names):
+    """By hand: with maxContig = 1 the loop sees the four reads of contig 0 and the FIRST read of contig 1 (counted: 5 reads, 100 bases),
+    then breaks; x and y are finished with the end-of-file threshold 0 (two pairs, FR 1 each); nothing of contigs 1 and 2 is written."""
+    batch, p, ref = case_quit_after_contig(maxc)
+    rt = oracle.run(batch, p, ref)
+    assert rt.status == 0
+    assert rt.pre.as_dict()["reads"] == reads_counted and rt.pre.as_dict()["bases"] == 20 * reads_counted
+    recs = out_records(rt, batch)
+    assert {r["qname"].rstrip("\0") for r in recs} == names and len(recs) == 2 * len(names)
+    assert all(r["fr"] == 1 for r in recs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxc", [0, 1, 2, 3, 7])
+def test_quit_after_contig_on_the_engine(built, maxc):
+    from test_gpu_parity import run_both
+    batch, p, ref = case_quit_after_contig(maxc)
+    got, want = run_both(batch, p, ref)
+    assert got.pre.as_dict()["reads"] == want.pre.as_dict()["reads"]
