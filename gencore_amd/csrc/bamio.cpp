@@ -1287,6 +1287,9 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
 int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
 int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
 int gce_host_alloc(size_t bytes, void **out);
+int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror);
+int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode);
+int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total);
 void gce_host_free(void *p);
 }  // extern "C" (declarations)
 extern "C++" {
@@ -1307,12 +1310,14 @@ extern "C" {
 // gce_process -- re-assembled as BAM records (gce_raw_build_output) on the GPU; the output stream comes back in pieces that are deflated by
 // all host threads and written in order while the next piece is on its way.  Host memory: two compressed pieces, three inflated windows,
 // three output pieces -- independent of the file's size (round 2 held the whole inflated file and every record table on the host).
-int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
-                int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {
+// gce_run_bam (n_shards == 1) and gce_run_bam_sharded over the same pipeline: with several shards every piece of the file goes to one engine per
+// entry of `devices` (the mirrors of the first), each inflates and indexes the stream on its own GPU, plans it there and keeps its share
+// (gce_raw_select_shard); the record streams are merged on the first engine's device (gce_raw_merge_outputs) and written as one.
+static int run_bam_impl(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                        int64_t chunk_reads, int level, gce_bam_run *out, char err[256], int32_t n_shards, const int32_t *devices, int32_t plan_mode) {
     auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
     seterr("");
     if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
-    if (getenv("GCE_BAM_HOSTCODEC")) return gce_run_bam_hostcodec(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err);
     memset(out, 0, sizeof *out);
     out->rss_start_kb = status_kb("VmRSS:");
     const double t_start = now_s();
@@ -1323,7 +1328,8 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); seterr("cannot stat the input BAM"); return GCE_ERR_INVALID; }
     const uint64_t fsz = (uint64_t)st.st_size;
     gce_engine *e = nullptr; gce_fasta *fa = nullptr; FILE *fo = nullptr;
-    auto done = [&](int code, const char *m) { seterr(m); if (e) gce_destroy(e); if (fa) gce_fasta_free(fa); if (fo) fclose(fo); close(fd); return code; };
+    std::vector<gce_engine *> mir;                      // the engines of shards 1 .. n_shards - 1 (they receive every push made to e)
+    auto done = [&](int code, const char *m) { seterr(m); for (auto *x : mir) if (x) gce_destroy(x); if (e) gce_destroy(e); if (fa) gce_fasta_free(fa); if (fo) fclose(fo); close(fd); return code; };
     const size_t PIECE = (size_t)(chunk_reads > 0 && chunk_reads < (1 << 16) ? (1 << 20) : (8 << 20));       // compressed bytes per window (tests shrink it through chunk_reads)
     // GCE_BAM_HOST_INFLATE=1: the BGZF members are inflated by the host threads (the path of the first half of round 3); default: they go to
     // HBM compressed and the GPU inflates them (gce_raw_push_bgzf) -- the host inflates only the window(s) that hold the BAM header
@@ -1371,19 +1377,30 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS before gce_create %ld MB (entry %ld MB)\n", status_kb("VmRSS:") >> 10, (long)(out->rss_start_kb >> 10));
         lap("up to the header");
         int r2;
+        if (devices) prm.device = devices[0];
         if ((r2 = gce_create(&prm, &e)) != GCE_OK) { emsg = gce_status_message(r2); return r2; }
+        for (int32_t r = 1; r < n_shards; r++) {                                          // one engine per further shard, on its own device
+            gce_params pr = prm; pr.device = devices[r];
+            gce_engine *x = nullptr;
+            if ((r2 = gce_create(&pr, &x)) != GCE_OK) { emsg = gce_status_message(r2); return r2; }
+            mir.push_back(x);
+        }
         if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
         if (fasta_path && *fasta_path) {
             if ((r2 = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) { emsg = "cannot read the FASTA file"; return r2; }
             int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *flen;
             gce_fasta_get(fa, &nc, &ids, &seqs, &flen);
-            for (size_t t = 0; t < lens.size(); t++)                                     // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
-                for (int32_t c = 0; c < nc; c++)
-                    if (names[t] == ids[c] && (r2 = gce_set_reference_ascii(e, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { emsg = gce_last_error(e); return r2; }
+            for (int32_t r = 0; r < n_shards; r++) {
+                gce_engine *x = r ? mir[(size_t)r - 1] : e;
+                for (size_t t = 0; t < lens.size(); t++)                                 // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+                    for (int32_t c = 0; c < nc; c++)
+                        if (names[t] == ids[c] && (r2 = gce_set_reference_ascii(x, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { emsg = gce_last_error(x); return r2; }
+            }
             gce_fasta_free(fa); fa = nullptr;                                            // (packed in HBM: the host copy goes)
         }
         lap("gce_create + reference");
         if ((r2 = gce_raw_begin(e, capacity)) != GCE_OK) { emsg = gce_last_error(e); return r2; }
+        for (gce_engine *x : mir) if ((r2 = gce_raw_begin(x, capacity)) != GCE_OK || (r2 = gce_raw_attach_mirror(e, x)) != GCE_OK) { emsg = gce_last_error(x); return r2; }
         return GCE_OK;
     };
     auto bam_header_bytes = [&]() {                                                       // BAM magic, text, contig table (SAMv1 4.2)
@@ -1593,9 +1610,38 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after the input pipeline %ld MB\n", status_kb("VmRSS:") >> 10);
     double t0 = now_s();
     int64_t n_rec = 0;
+    uint64_t body = 0; int64_t n_out = 0;
+    if (n_shards > 1) {
+        // ---- several engines: each indexes the stream it received, keeps its shard, runs it and assembles its records -- side by side, one host
+        //      thread per engine, nothing exchanged; then the streams are merged on the first engine's device
+        std::vector<gce_engine *> all; all.push_back(e); for (auto *x : mir) all.push_back(x);
+        std::vector<int> rcs((size_t)n_shards, GCE_OK); std::vector<std::string> msgs((size_t)n_shards); std::vector<int64_t> nrec((size_t)n_shards, 0); std::vector<double> kms((size_t)n_shards, 0.0), t_idx((size_t)n_shards, 0.0);
+        std::vector<std::thread> th;
+        for (int32_t r = 0; r < n_shards; r++) th.emplace_back([&, r] {
+            gce_engine *x = all[(size_t)r]; int c2; int64_t n0 = 0; uint64_t b2 = 0; int64_t o2 = 0;
+            auto failr = [&](int code) { rcs[(size_t)r] = code; const char *m = gce_last_error(x); msgs[(size_t)r] = m && m[0] ? m : gce_status_message(code); };
+            const double a0 = now_s();
+            if ((c2 = gce_raw_finish(x, hdr_end, prm.n_targets, &n0)) != GCE_OK) return failr(c2);
+            if (n0 > 0 && (c2 = gce_raw_select_shard(x, n_shards, r, plan_mode)) != GCE_OK) return failr(c2);
+            t_idx[(size_t)r] = now_s() - a0;
+            gce_result rs;
+            if (n0 > 0 && ((c2 = gce_process(x)) != GCE_OK || (c2 = gce_result_device(x, &rs)) != GCE_OK || (c2 = gce_raw_build_output(x, &b2, &o2)) != GCE_OK)) return failr(c2);
+            gce_timing tm; if (n0 > 0 && gce_get_timing(x, &tm) == GCE_OK) kms[(size_t)r] = tm.total_ms;
+            nrec[(size_t)r] = n0;
+        });
+        for (auto &t : th) t.join();
+        for (int32_t r = 0; r < n_shards; r++) if (rcs[(size_t)r] != GCE_OK) return done(rcs[(size_t)r], msgs[(size_t)r].c_str());
+        for (int32_t r = 0; r < n_shards; r++) { out->kernel_ms = std::max(out->kernel_ms, kms[(size_t)r]); out->index_s = std::max(out->index_s, t_idx[(size_t)r]); }
+        out->process_s = now_s() - t0 - out->index_s; t0 = now_s();
+        n_rec = nrec[0];
+        if (n_rec > 0) {
+            if ((rc = gce_raw_merge_outputs(all.data(), n_shards, &body, &n_out, &out->pre, &out->post, &out->n_reads)) != GCE_OK) return done(rc, gce_last_error(e));
+            out->n_out = n_out;
+        }
+        out->drain_s = now_s() - t0; t0 = now_s();
+    } else {
     if ((rc = gce_raw_finish(e, hdr_end, prm.n_targets, &n_rec)) != GCE_OK) return done(rc, gce_last_error(e));
     out->index_s = now_s() - t0; t0 = now_s();
-    uint64_t body = 0; int64_t n_out = 0;
     if (n_rec > 0) {
         if ((rc = gce_process(e)) != GCE_OK) return done(rc, gce_last_error(e)[0] ? gce_last_error(e) : gce_status_message(rc));
         out->process_s = now_s() - t0; t0 = now_s();
@@ -1607,6 +1653,7 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
         out->drain_s = now_s() - t0; t0 = now_s();
         if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after process + output records %ld MB\n", status_kb("VmRSS:") >> 10);
     }
+    }   // (one engine)
     // ---- the output file: header bytes + the record stream from HBM, in pieces; deflate by all threads, written in order
     const size_t opl = strlen(out_path);
     if (opl >= 3 && strcmp(out_path + opl - 3, "sam") == 0) {
@@ -1690,8 +1737,8 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
 // exchange: the output tables (each in bamComp order) are merged k-way by (tid, pos, mtid, mpos, isize, input index), mate rows are
 // re-pointed, the two Stats blocks are SUMMED ON THE HOST (one process owns all engines here; one process per GPU merges them with one
 // RCCL all-reduce instead, bench.py).  The result equals gce_run_bam's: same records, same order, same Stats.
-int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards, const int32_t *devices,
-                        int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]) {
+int gce_run_bam_sharded_hostcodec(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards, const int32_t *devices,
+                                  int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]) {
     auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
     seterr("");
     if (!in_path || !out_path || !params || !out || n_shards < 1 || n_shards > 64 || !devices) return GCE_ERR_INVALID;
@@ -1828,6 +1875,24 @@ int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *f
     out->write_s = now_s() - t0;
     out->total_s = now_s() - t_start;
     return done(GCE_OK, "");
+}
+
+
+int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
+                int64_t chunk_reads, int level, gce_bam_run *out, char err[256]) {
+    if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
+    if (getenv("GCE_BAM_HOSTCODEC")) return gce_run_bam_hostcodec(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err);
+    return run_bam_impl(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err, 1, nullptr, 0);
+}
+
+// Gencore::consensus() for one file over SEVERAL engines on the GPU codec (src/gencore.cpp:164-205): see run_bam_impl.  The host
+// reads the file once; every engine gets the compressed pieces over its own PCIe link, inflates, indexes and plans on its own GPU and keeps its
+// key range; outputs are merged device to device.  GCE_BAM_HOSTCODEC=1: round 2's runner (host inflate and index, host-side cut, host merge).
+int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards, const int32_t *devices,
+                        int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]) {
+    if (!in_path || !out_path || !params || !out || n_shards < 1 || n_shards > 64 || !devices || (plan_mode != 0 && plan_mode != 1)) return GCE_ERR_INVALID;
+    if (getenv("GCE_BAM_HOSTCODEC")) return gce_run_bam_sharded_hostcodec(in_path, out_path, fasta_path, params, n_shards, devices, plan_mode, threads, level, out, err);
+    return run_bam_impl(in_path, out_path, fasta_path, params, threads, 0, level, out, err, n_shards, devices, plan_mode);
 }
 
 }  // extern "C"

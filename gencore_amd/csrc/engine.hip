@@ -78,6 +78,10 @@ struct gce_engine {
     DevBuf raw, rw_bad, rw_guess, rw_leave, rw_cnt, rw_base, rw_misc, rw_tmp, rw_off, rw_ncig, rw_nmpos, rw_rsize, rw_roff, rw_body;
     size_t raw_n = 0; bool raw_mode = false; int64_t raw_records = 0; uint64_t raw_body_bytes = 0;
     DevBuf z_comp, z_dir, z_err; size_t z_n = 0; std::vector<InfDir> z_members;      // BGZF members waiting for the GPU inflate (gce_raw_push_bgzf)
+    // the sharded file runner (gce_raw_attach_mirror / gce_raw_select_shard): engines that receive every push to this one's raw stream; this engine's
+    // share of the stream (reads gathered from the full batch; sh_sel = their places in the whole stream)
+    std::vector<gce_engine *> mirrors;
+    DevBuf sh_tickall, sh_shard, sh_flag, sh_sel, sh_core, sh_qoff, sh_coff, sh_soff, sh_loff, sh_nm, sh_nmt, sh_mioff, sh_tick, sh_roff, sh_nmpos, sh_keys, sh_stage; int64_t shard_n = -1;
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
@@ -164,6 +168,7 @@ void gce_destroy(gce_engine *e) {
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
+    for (DevBuf *b : {&e->sh_tickall, &e->sh_shard, &e->sh_flag, &e->sh_sel, &e->sh_core, &e->sh_qoff, &e->sh_coff, &e->sh_soff, &e->sh_loff, &e->sh_nm, &e->sh_nmt, &e->sh_mioff, &e->sh_tick, &e->sh_roff, &e->sh_nmpos, &e->sh_keys, &e->sh_stage}) b->release();
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }
@@ -334,6 +339,8 @@ int gce_submit_async(gce_engine *e, const gce_batch *b, int32_t *ticket) {
 int gce_submit_wait(gce_engine *e, int32_t ticket) {
     if (!e || ticket < 0 || (size_t)ticket >= e->up_events.size()) return GCE_ERR_INVALID;
     HIPCHK(hipEventSynchronize(e->up_events[ticket]));
+    for (gce_engine *m : e->mirrors)                                                // (the same pushes in the same order: the same ticket numbers)
+        if ((size_t)ticket < m->up_events.size() && hipEventSynchronize(m->up_events[ticket]) != hipSuccess) return fail(e, GCE_ERR_HIP, "mirror engine: copy failed");
     return GCE_OK;
 }
 

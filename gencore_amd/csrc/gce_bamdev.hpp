@@ -231,6 +231,46 @@ __global__ __launch_bounds__(256) void k_rec_nm(const uint8_t *u, const uint64_t
     body[roff[k] + np - lq_old + lq_new] = (uint8_t)r.nm_new[k];                   // dataNM[1] = newValNM (group.cpp:570)
 }
 
+// ---- the sharded file runner: one engine per shard, every engine holds the whole stream and takes its share of it
+struct ShardSrc { const gce_core *core; const uint64_t *qoff, *coff, *soff, *loff, *mioff, *tick, *roff; const int32_t *nm; const uint8_t *nmt; const uint32_t *nmpos; };
+struct ShardDst { gce_core *core; uint64_t *qoff, *coff, *soff, *loff, *mioff, *tick, *roff; int32_t *nm; uint8_t *nmt; uint32_t *nmpos; };
+__global__ __launch_bounds__(256) void k_shard_flag(const int32_t *shard, int64_t n, int32_t rank, uint8_t *flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = shard[i] == rank;
+}
+// thread per selected read: its key record and the per-read words of the batch, gathered (names, CIGAR words, bases and qualities stay where they are)
+__global__ __launch_bounds__(256) void k_shard_gather(const uint32_t *sel, int64_t m, ShardSrc a, ShardDst d) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t k = sel[j];
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.core + k); uint4 *dst = reinterpret_cast<uint4 *>(d.core + j);
+    dst[0] = src[0]; dst[1] = src[1];
+    d.qoff[j] = a.qoff[k]; d.coff[j] = a.coff[k]; d.soff[j] = a.soff[k]; d.loff[j] = a.loff[k]; d.nm[j] = a.nm[k]; d.nmt[j] = a.nmt[k];
+    if (a.mioff) d.mioff[j] = a.mioff[k];
+    d.tick[j] = a.tick[k]; d.roff[j] = a.roff[k]; d.nmpos[j] = a.nmpos[k];
+}
+// what the merge of the shards' output tables compares: bamComp's fields (gencore.h:19-47) + the read's place in the WHOLE stream (quirk Q3) + the record's bytes
+struct __attribute__((aligned(16))) MergeKey { int32_t tid, pos, mtid, mpos, isize; uint32_t gidx; uint32_t size, pad; };
+__global__ __launch_bounds__(256) void k_merge_keys(const gce_core *core, const uint32_t *src, const uint32_t *sel, const uint64_t *rsize, uint64_t n_out, MergeKey *out) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const uint32_t r = src[k]; const gce_core c = core[r];
+    MergeKey m; m.tid = c.tid; m.pos = c.pos; m.mtid = c.mtid; m.mpos = c.mpos; m.isize = c.isize; m.gidx = sel ? sel[r] : r; m.size = (uint32_t)rsize[k]; m.pad = 0;
+    out[k] = m;
+}
+// 16 lanes per record: record k of the merged stream = bytes [from[k], from[k] + size[k]) of the staged shard streams
+__global__ __launch_bounds__(256) void k_merge_copy(const uint8_t *stage, const uint64_t *from, const uint64_t *to, const uint32_t *size, uint64_t n, uint8_t *body) {
+    const int sub = threadIdx.x & 15;
+    for (uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; k < n; k += ((uint64_t)gridDim.x * blockDim.x) >> 4) {
+        const uint8_t *s = stage + from[k]; uint8_t *d = body + to[k]; const uint32_t sz = size[k];
+        for (uint32_t j = 4 * sub; j < sz; j += 64) {
+            if (j + 4 <= sz) *(rb_u32u *)(d + j) = rb32(s + j);
+            else for (uint32_t q = j; q < sz; q++) d[q] = s[q];
+        }
+    }
+}
+__global__ void k_add_i64(long long *acc, const long long *x, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) acc[i] += x[i]; }
+
 }  // namespace
 
 extern "C" {
@@ -273,6 +313,7 @@ int gce_raw_push(gce_engine *e, const void *host, size_t bytes, int32_t *ticket)
     HIPCHK(hipEventRecord(ev, e->up_stream));
     e->up_events.push_back(ev);
     if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    for (gce_engine *m : e->mirrors) { const int rm = gce_raw_push(m, host, bytes, nullptr); if (rm != GCE_OK) return fail(e, rm, gce_last_error(m)); }
     return GCE_OK;
 }
 
@@ -303,6 +344,7 @@ int gce_raw_push_bgzf(gce_engine *e, const void *comp, size_t comp_bytes, int32_
     HIPCHK(hipEventRecord(ev, e->up_stream));
     e->up_events.push_back(ev);
     if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
+    for (gce_engine *m : e->mirrors) { const int rm = gce_raw_push_bgzf(m, comp, comp_bytes, n_members, coff, csize, usize, nullptr); if (rm != GCE_OK) return fail(e, rm, gce_last_error(m)); }
     return GCE_OK;
 }
 
@@ -526,8 +568,172 @@ int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t
     return GCE_OK;
 }
 
+
+// ---- several engines over ONE file (gce_run_bam_sharded): the mirrors of an engine receive every gce_raw_push / gce_raw_push_bgzf made to it
+int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror) {
+    if (!e || !mirror || e == mirror || !e->raw_mode || !mirror->raw_mode || e->raw_n != mirror->raw_n) return GCE_ERR_INVALID;
+    e->mirrors.push_back(mirror);
+    return GCE_OK;
+}
+// After gce_raw_finish: this engine keeps shard `rank` of `world` of the stream it holds -- the planner runs on its own device over the key
+// records in HBM (gce_stream_context: every read's global tick, the flush events of the whole stream; gce_plan_shards: key ranges or clusters
+// dealt by weight), the reads of the shard are gathered (key records and per-read words; names, CIGARs, bases and qualities stay in the raw
+// stream), the engine gets their ticks and the events.  Every engine of a sharded run computes the same plan from the same stream: nothing is
+// exchanged.  Replaces the host-side cut of round 2's runner (gencore.cpp:164-205 over several GPUs).
+int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode) {
+    if (!e || !e->raw_mode || !e->device_mode || e->processed || world < 1 || rank < 0 || rank >= world) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    const int64_t n = e->raw_records;
+    hipStream_t s = e->stream;
+    e->shard_n = 0;
+    if (n == 0) { e->have_tick = false; return GCE_OK; }
+    HIPCHK(e->sh_tickall.ensure((size_t)n * 8)); HIPCHK(e->sh_shard.ensure((size_t)n * 4)); HIPCHK(e->sh_flag.ensure((size_t)n + 64)); HIPCHK(e->sh_sel.ensure((size_t)n * 4 + 64));
+    int32_t n_ev = 0, *ev_tid = nullptr, *ev_pos = nullptr;
+    const int period = e->prm.flush_period > 0 ? e->prm.flush_period : 10000;
+    int rc = gce_stream_context(e->prm.device, e->b_core.as<gce_core>(), n, period, e->sh_tickall.as<uint64_t>(), &n_ev, &ev_tid, &ev_pos);
+    if (rc != GCE_OK) return fail(e, rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
+    rc = gce_set_flush_events(e, n_ev, ev_tid, ev_pos);
+    gce_free(ev_tid); gce_free(ev_pos);
+    if (rc != GCE_OK) return rc;
+    if ((rc = gce_plan_shards(e->prm.device, e->b_core.as<gce_core>(), n, world, plan_mode, e->sh_shard.as<int32_t>())) != GCE_OK) return fail(e, rc, gce_status_message(rc));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_shard_flag, dim3(nb), dim3(256), 0, s, (const int32_t *)e->sh_shard.p, n, rank, e->sh_flag.as<uint8_t>());
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, hipcub::CountingInputIterator<uint32_t>(0), e->sh_flag.as<uint8_t>(), e->sh_sel.as<uint32_t>(), (int64_t *)e->rw_misc.p, (int)n, s));
+    HIPCHK(e->rw_tmp.ensure(tb));
+    HIPCHK(hipcub::DeviceSelect::Flagged(e->rw_tmp.p, tb, hipcub::CountingInputIterator<uint32_t>(0), e->sh_flag.as<uint8_t>(), e->sh_sel.as<uint32_t>(), (int64_t *)e->rw_misc.p, (int)n, s));
+    int64_t m = 0;
+    HIPCHK(hipMemcpyAsync(&m, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    const size_t m1 = (size_t)(m > 0 ? m : 1);
+    HIPCHK(e->sh_core.ensure(m1 * sizeof(gce_core) + 64)); HIPCHK(e->sh_qoff.ensure(m1 * 8 + 64)); HIPCHK(e->sh_coff.ensure(m1 * 8 + 64)); HIPCHK(e->sh_soff.ensure(m1 * 8 + 64)); HIPCHK(e->sh_loff.ensure(m1 * 8 + 64));
+    HIPCHK(e->sh_nm.ensure(m1 * 4 + 64)); HIPCHK(e->sh_nmt.ensure(m1 + 64)); HIPCHK(e->sh_mioff.ensure(m1 * 8 + 64)); HIPCHK(e->sh_tick.ensure(m1 * 8 + 64)); HIPCHK(e->sh_roff.ensure(m1 * 8 + 64)); HIPCHK(e->sh_nmpos.ensure(m1 * 4 + 64));
+    gce_batch &d = e->dev_batch;
+    if (m > 0) {
+        ShardSrc a{d.core, d.qname_off, d.cigar_off, d.seq_off, d.qual_off, d.mi_off, (const uint64_t *)e->sh_tickall.p, (const uint64_t *)e->rw_off.p, d.nm, d.nm_type, (const uint32_t *)e->rw_nmpos.p};
+        ShardDst o{e->sh_core.as<gce_core>(), e->sh_qoff.as<uint64_t>(), e->sh_coff.as<uint64_t>(), e->sh_soff.as<uint64_t>(), e->sh_loff.as<uint64_t>(), e->sh_mioff.as<uint64_t>(), e->sh_tick.as<uint64_t>(),
+                   e->sh_roff.as<uint64_t>(), e->sh_nm.as<int32_t>(), e->sh_nmt.as<uint8_t>(), e->sh_nmpos.as<uint32_t>()};
+        hipLaunchKernelGGL(k_shard_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const uint32_t *)e->sh_sel.p, m, a, o);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    d.n_reads = m; d.core = e->sh_core.as<gce_core>(); d.qname_off = e->sh_qoff.as<uint64_t>(); d.cigar_off = e->sh_coff.as<uint64_t>(); d.seq_off = e->sh_soff.as<uint64_t>(); d.qual_off = e->sh_loff.as<uint64_t>();
+    d.nm = e->sh_nm.as<int32_t>(); d.nm_type = e->sh_nmt.as<uint8_t>(); if (d.mi_off) d.mi_off = e->sh_mioff.as<uint64_t>();
+    d.tick = e->sh_tick.as<uint64_t>();
+    std::swap(e->rw_off, e->sh_roff); std::swap(e->rw_nmpos, e->sh_nmpos);          // gce_raw_build_output looks records up by the batch's (now: the shard's) read index
+    e->have_tick = true; e->raw_records = m; e->shard_n = m;
+    e->sh_tickall.release(); e->sh_shard.release(); e->sh_flag.release();
+    return GCE_OK;
+}
+// After every engine's gce_raw_build_output: the shards' record streams (each in bamComp order) merged into ONE stream in bamComp order over the
+// whole file -- (tid, pos, mtid, mpos, isize, place in the input stream), gencore.h:19-47 -- in engs[0]'s output buffer, so that the writer
+// streams it like a single engine's; the Stats blocks summed device to device into engs[0]'s (no host bounce of the blocks, no collective).
+// The order is worked out on the host from 32 bytes per emitted record (runs of one shard are found by bisection: key ranges overlap only at
+// their borders), the bytes are moved by the GPU.
+int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total) {
+    if (!engs || n_engs < 1 || !body_bytes) return GCE_ERR_INVALID;
+    gce_engine *e = engs[0];
+    for (int r = 0; r < n_engs; r++) if (!engs[r] || !engs[r]->raw_mode || !engs[r]->processed || engs[r]->dev_error) return GCE_ERR_INVALID;
+    std::vector<std::vector<MergeKey>> keys((size_t)n_engs);
+    std::vector<uint64_t> base((size_t)n_engs + 1, 0);                              // where shard r's stream lies in the staging buffer
+    int64_t total_out = 0, total_reads = 0;
+    for (int r = 0; r < n_engs; r++) {
+        gce_engine *x = engs[r];
+        (void)hipSetDevice(x->prm.device);
+        const uint64_t no = (uint64_t)x->n_out;
+        base[r + 1] = base[r] + x->raw_body_bytes; total_out += x->n_out; total_reads += x->n;
+        keys[r].resize((size_t)no);
+        if (!no) continue;
+        if (x->sh_keys.ensure(no * sizeof(MergeKey)) != hipSuccess) return fail(e, GCE_ERR_OOM, "out of device memory");
+        hipLaunchKernelGGL(k_merge_keys, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, x->stream, x->dev_batch.core, (const uint32_t *)x->o_src.p, x->shard_n >= 0 ? (const uint32_t *)x->sh_sel.p : (const uint32_t *)nullptr,
+                           (const uint64_t *)x->rw_rsize.p, no, x->sh_keys.as<MergeKey>());
+        if (hipMemcpyAsync(keys[r].data(), x->sh_keys.p, no * sizeof(MergeKey), hipMemcpyDeviceToHost, x->stream) != hipSuccess || hipStreamSynchronize(x->stream) != hipSuccess) return fail(e, GCE_ERR_HIP, "merge keys");
+    }
+    const uint64_t total = base[n_engs];
+    // ---- the order: smallest head first, then as many records of that shard as stay in front of every other head
+    std::vector<uint64_t> from((size_t)std::max<int64_t>(total_out, 1)), to((size_t)std::max<int64_t>(total_out, 1)); std::vector<uint32_t> size((size_t)std::max<int64_t>(total_out, 1));
+    auto less = [](const MergeKey &a, const MergeKey &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.mtid != b.mtid) return a.mtid < b.mtid;
+        if (a.mpos != b.mpos) return a.mpos < b.mpos;
+        if (a.isize != b.isize) return a.isize < b.isize;
+        return a.gidx < b.gidx;
+    };
+    {
+        std::vector<size_t> head((size_t)n_engs, 0); std::vector<uint64_t> soff((size_t)n_engs, 0);
+        int64_t row = 0; uint64_t at = 0;
+        while (row < total_out) {
+            int best = -1, second = -1;
+            for (int r = 0; r < n_engs; r++) if (head[r] < keys[r].size()) {
+                if (best < 0 || less(keys[r][head[r]], keys[best][head[best]])) { second = best; best = r; }
+                else if (second < 0 || less(keys[r][head[r]], keys[second][head[second]])) second = r;
+            }
+            size_t stop = keys[best].size();
+            if (second >= 0) {                                                      // the first record of `best` that is not in front of `second`'s head (the shard's table is sorted)
+                const MergeKey &lim = keys[second][head[second]];
+                size_t a = head[best] + 1, z = keys[best].size();
+                while (a < z) { const size_t mid = (a + z) >> 1; if (less(keys[best][mid], lim)) a = mid + 1; else z = mid; }
+                stop = a;
+            }
+            for (size_t k = head[best]; k < stop; k++, row++) { const uint32_t sz = keys[best][k].size; from[row] = base[best] + soff[best]; to[row] = at; size[row] = sz; soff[best] += sz; at += sz; }
+            head[best] = stop;
+        }
+        if (at != total) return fail(e, GCE_ERR_INVALID, "merge: record sizes do not add up");
+    }
+    // ---- the bytes: every shard's stream staged on engs[0]'s device, one gather into the merged stream
+    (void)hipSetDevice(e->prm.device);
+    hipStream_t s = e->stream;
+    if (e->sh_stage.ensure(total + 64) != hipSuccess) return fail(e, GCE_ERR_OOM, "out of device memory");
+    for (int r = 0; r < n_engs; r++) {
+        gce_engine *x = engs[r];
+        if (!x->raw_body_bytes) continue;
+        const hipError_t ce = x->prm.device == e->prm.device ? hipMemcpyAsync((char *)e->sh_stage.p + base[r], x->rw_body.p, x->raw_body_bytes, hipMemcpyDeviceToDevice, s)
+                                                              : hipMemcpyPeerAsync((char *)e->sh_stage.p + base[r], e->prm.device, x->rw_body.p, x->prm.device, x->raw_body_bytes, s);
+        if (ce != hipSuccess) return fail(e, GCE_ERR_HIP, "merge: device-to-device copy");
+    }
+    HIPCHK(hipStreamSynchronize(s));                                                 // (engs[0]'s own stream was the source of one of the copies: it may be overwritten from here on)
+    if (total_out > 0) {
+        DevBuf d_from, d_to, d_size;
+        HIPCHK(d_from.ensure((size_t)total_out * 8)); HIPCHK(d_to.ensure((size_t)total_out * 8)); HIPCHK(d_size.ensure((size_t)total_out * 4));
+        HIPCHK(hipMemcpyAsync(d_from.p, from.data(), (size_t)total_out * 8, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(d_to.p, to.data(), (size_t)total_out * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_size.p, size.data(), (size_t)total_out * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(e->rw_body.ensure(total + 64));
+        hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)std::min<uint64_t>(((uint64_t)total_out + 15) / 16, 65535u)), dim3(256), 0, s, (const uint8_t *)e->sh_stage.p, (const uint64_t *)d_from.p, (const uint64_t *)d_to.p,
+                           (const uint32_t *)d_size.p, (uint64_t)total_out, e->rw_body.as<uint8_t>());
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        d_from.release(); d_to.release(); d_size.release();
+    }
+    e->sh_stage.release();
+    e->raw_body_bytes = total;
+    // ---- Stats: the shards' blocks added into engs[0]'s, device to device
+    const int W2 = 2 * GCE_STATS_WORDS;
+    if (n_engs > 1) {
+        DevBuf tmp; HIPCHK(tmp.ensure((size_t)W2 * 8));
+        long long *acc = (long long *)e->si.as<StreamInfo>()->pre;
+        for (int r = 1; r < n_engs; r++) {
+            gce_engine *x = engs[r];
+            const void *src = (const void *)x->si.as<StreamInfo>()->pre;
+            const hipError_t ce = x->prm.device == e->prm.device ? hipMemcpyAsync(tmp.p, src, (size_t)W2 * 8, hipMemcpyDeviceToDevice, s) : hipMemcpyPeerAsync(tmp.p, e->prm.device, src, x->prm.device, (size_t)W2 * 8, s);
+            if (ce != hipSuccess) return fail(e, GCE_ERR_HIP, "merge: Stats copy");
+            hipLaunchKernelGGL(k_add_i64, dim3((W2 + 255) / 256), dim3(256), 0, s, acc, (const long long *)tmp.p, W2);
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        tmp.release();
+    }
+    static_assert(offsetof(StreamInfo, post) == offsetof(StreamInfo, pre) + GCE_STATS_WORDS * 8, "pre and post lie back to back");
+    long long both[2 * GCE_STATS_WORDS];
+    HIPCHK(hipMemcpy(both, e->si.as<StreamInfo>()->pre, sizeof both, hipMemcpyDeviceToHost));
+    if (pre) memcpy(pre, both, GCE_STATS_WORDS * 8);
+    if (post) memcpy(post, both + GCE_STATS_WORDS, GCE_STATS_WORDS * 8);
+    *body_bytes = total;
+    if (n_out_total) *n_out_total = total_out;
+    if (n_reads_total) *n_reads_total = total_reads;
+    return GCE_OK;
+}
+
 // pinned host memory for the windows of the file path (the DMA engines copy from / to it without a staging copy)
-int gce_host_alloc(size_t bytes, void **out) { if (!out) return GCE_ERR_INVALID; return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? GCE_OK : GCE_ERR_OOM; }
+int gce_host_alloc(size_t bytes, void **out) { if (!out) return GCE_ERR_INVALID; return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? GCE_OK : GCE_ERR_OOM; }      // (portable: the sharded runner's devices all copy from the same windows)
 void gce_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 }  // extern "C"

@@ -423,13 +423,30 @@ int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t
 int gce_host_alloc(size_t bytes, void **out);
 void gce_host_free(void *p);
 
-/* The same over SEVERAL engines, one per entry of `devices` (HIP ordinals; they may repeat): the stream is cut into n_shards ranges of the
- * cluster key by gce_stream_context + gce_plan_shards (plan_mode as there), every shard gets its reads, their global ticks, the flush
- * events and the reference window its reads touch; the engines run side by side, their tables are merged in bamComp order, the Stats
- * blocks summed on the host.  Same records, same order, same Stats as gce_run_bam.  Needs every mapped read in front of the first
- * unmapped one (a coordinate-sorted BAM).  params->tick_offset / trailing_flush are ignored. */
+/* Replaces: Gencore::consensus() (src/gencore.cpp:162-293) for one file over SEVERAL engines, one per entry of `devices` (HIP ordinals; they
+ * may repeat), ON THE GPU CODEC: the host reads the file once (BAM or SAM text, as gce_run_bam); every engine receives the compressed pieces
+ * (its own PCIe link), inflates and indexes the stream on its own GPU, plans it there (gce_stream_context + gce_plan_shards, plan_mode as
+ * there: the same plan on every device, nothing exchanged) and keeps its range of the cluster key with the reads' global ticks and the
+ * stream's flush events (gce_raw_select_shard); the engines run side by side; their record streams -- each in bamComp order -- are merged
+ * device to device on devices[0] (gce_raw_merge_outputs: order from 32 bytes per record on the host, bytes moved by the GPU), the Stats blocks
+ * summed in device memory; one writer.  Same records, same order, same Stats as gce_run_bam.  Needs every mapped read in front of the first
+ * unmapped one (a coordinate-sorted file).  params->device / tick_offset / trailing_flush are ignored.  An output name that ends in "sam" is
+ * written as text.  GCE_BAM_HOSTCODEC=1 (or gce_run_bam_sharded_hostcodec): round 2's runner -- host inflate / index / cut, per-shard
+ * reference windows, host merge; BAM in and out only. */
 int gce_run_bam_sharded(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards,
                         const int32_t *devices, int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]);
+int gce_run_bam_sharded_hostcodec(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int32_t n_shards,
+                                  const int32_t *devices, int32_t plan_mode, int threads, int level, gce_bam_run *out, char err[256]);
+/* The pieces of the sharded runner (additions under ABI v3; gencore_amd/csrc/gce_bamdev.hpp).
+ *   gce_raw_attach_mirror: from now on every gce_raw_push / gce_raw_push_bgzf to `e` goes to `mirror` as well (same bytes, same tickets);
+ *   gce_raw_select_shard (after gce_raw_finish, before gce_process): the engine keeps shard `rank` of `world` of the stream it holds (the
+ *     reference's read loop src/gencore.cpp:205-274 restricted to one range of the cluster key, with the tick and the flush walk of the
+ *     whole stream, :319-354);
+ *   gce_raw_merge_outputs (after every engine's gce_raw_build_output): one record stream in bamComp order (src/gencore.h:19-47 over the
+ *     whole file) in engs[0]'s output buffer -- read it with gce_raw_read_output_async(engs[0], ...) --, both Stats blocks summed. */
+int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror);
+int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode);
+int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total);
 
 #ifdef __cplusplus
 }

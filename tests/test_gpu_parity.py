@@ -477,10 +477,13 @@ def test_c_planner_equals_the_python_spec(built, name, n_pairs, world, mode, per
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hostcodec", [False, True])
 @pytest.mark.parametrize("workload,n_pairs,shards,mode,period", [("cfg3", 30000, 3, 0, 2000), ("cfg5", 3000, 2, 1, 10000), ("cfg2", 20000, 4, 0, 700)])
-def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, workload, n_pairs, shards, mode, period):
-    """gce_run_bam_sharded (C planner, one engine per shard -- all on device 0 here --, ticks + flush events + per-shard reference windows,
-    k-way merge, host Stats sum) writes the same records in the same order with the same Stats as gce_run_bam."""
+def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, monkeypatch, workload, n_pairs, shards, mode, period, hostcodec):
+    """gce_run_bam_sharded writes the same records in the same order with the same Stats as gce_run_bam.  Default: the GPU codec -- every
+    engine (all on device 0 here) receives the compressed pieces, inflates, indexes and plans the stream itself and keeps its shard
+    (gce_raw_select_shard), the record streams are merged device to device (gce_raw_merge_outputs), Stats summed in device memory.
+    hostcodec: round 2's runner (host inflate / index / cut, per-shard reference windows, host merge)."""
     import pybam
     from gencore_amd import synth
     from gencore_amd.bamio import run_bam, run_bam_sharded
@@ -499,7 +502,10 @@ def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, workload, n_p
                 f.write(b">" + nm.encode() + b"\n" + bases + b"\n")
     prm = default_params(umi_prefix="auto", cluster_size_req=d.info["supporting_reads"], flush_period=period)
     r1 = run_bam(src, one, prm, fasta=fa, threads=4)
+    if hostcodec:
+        monkeypatch.setenv("GCE_BAM_HOSTCODEC", "1")
     r2 = run_bam_sharded(src, many, prm, [0] * shards, fasta=fa, plan_mode=mode, threads=4)
+    monkeypatch.delenv("GCE_BAM_HOSTCODEC", raising=False)
     assert (r1.n_reads, r1.n_out) == (r2.n_reads, r2.n_out) and r1.n_out > 0
     assert bytes(r1.pre) == bytes(r2.pre) and bytes(r1.post) == bytes(r2.post)
     _, t1, g1 = pybam.read_bam(one)
