@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 from gencore_amd import capi  # noqa: E402  (synth -- and torch with it -- only in the generating parent)
-from gencore_amd.bamio import run_bam, write_batch_as_bam  # noqa: E402
+from gencore_amd.bamio import run_bam, run_bam_sharded, write_batch_as_bam  # noqa: E402
 from gencore_amd.shard import effective_cpus  # noqa: E402
 
 
@@ -44,6 +44,25 @@ def child(args):
                kernel_ms=round(r.kernel_ms, 3),
                pairs_per_s=dict(end_to_end=round(n_pairs / r.total_s), kernels_only=round(n_pairs / (r.kernel_ms * 1e-3))),
                first_run_total_s=round(runs[0][1].total_s, 3), make_input_s=round(t_make, 2), output_level=args.level)
+    if args.shards and int(args.shards) > 1:                   # the same file through gce_run_bam_sharded: K engines on device 0 (one GPU here: the paths, not a scaling claim)
+        K = int(args.shards)
+        res["sharded"] = {"engines": K, "devices": [0] * K, "note": "all engines on one GPU: every engine inflates and indexes the whole stream itself (on K GPUs that happens side by side)"}
+        for tag, env in (("gpu_codec", None), ("hostcodec_round2", "1")):
+            if env:
+                os.environ["GCE_BAM_HOSTCODEC"] = env
+            try:
+                best = None
+                for rep in range(2):
+                    o2 = os.path.join(tmp, "out_sh_%s.bam" % tag)
+                    t0 = time.time()
+                    rs = run_bam_sharded(src, o2, prm, [0] * K, fasta=(fa if not os.environ.get("GCE_BENCH_NO_FASTA") else None), threads=args.threads, level=args.level)
+                    best = (time.time() - t0, rs)
+                rs = best[1]
+                res["sharded"][tag] = dict(total_s=round(rs.total_s, 4), input_pipeline=round(rs.open_s, 4), index_plan_select=round(rs.index_s, 4), process=round(rs.process_s, 4), merge=round(rs.drain_s, 4), write=round(rs.write_s, 4),
+                                           kernel_ms_slowest_engine=round(rs.kernel_ms, 3), records_out=int(rs.n_out), output_identical_to_single_engine=open(o2, "rb").read() == open(out, "rb").read(),
+                                           stats_equal=bool(bytes(rs.pre) == bytes(r.pre) and bytes(rs.post) == bytes(r.post)))
+            finally:
+                os.environ.pop("GCE_BAM_HOSTCODEC", None)
     print(json.dumps(res))
 
 
@@ -57,6 +76,7 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--sam", action="store_true", help="with --c-caller: also time SAM text in / out")
     ap.add_argument("--c-caller", action="store_true", help="also run the files through tools/run_bam.c (a plain C process) and report its times and peak RSS")
+    ap.add_argument("--shards", default=None, help="also run the file through gce_run_bam_sharded with this many engines on device 0 (GPU codec and round 2's host codec)")
     for k_ in ("--child", "--make-s", "--npairs", "--nreads", "--sreq", "--unc"):
         ap.add_argument(k_, default=None)
     args = ap.parse_args()
@@ -91,7 +111,7 @@ def main():
     if args.child is None:                                      # the runs happen in a fresh process: its peak RSS is the file path's, not the generator's
         import subprocess
         outp = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", tmp, "--workload", args.workload, "--pairs", str(args.pairs), "--threads", str(args.threads),
-                               "--level", str(args.level), "--chunk", str(args.chunk), "--make-s", "%.2f" % t_make, "--npairs", str(d.info["n_pairs"]), "--nreads", str(batch.n),
+                               "--level", str(args.level), "--chunk", str(args.chunk)] + (["--shards", str(args.shards)] if args.shards else []) + ["--make-s", "%.2f" % t_make, "--npairs", str(d.info["n_pairs"]), "--nreads", str(batch.n),
                                "--sreq", str(d.info["supporting_reads"]), "--unc", str(int(batch.seq.size + batch.qual.size + batch.qname.size + 4 * batch.cigar.size + 40 * batch.n))], stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in outp.stdout.splitlines() if ln.startswith("{")]
         if lines and args.c_caller:                             # the same files through a plain C process: the path's own resident memory
