@@ -93,15 +93,19 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
     const size_t lq = (size_t)(fe(0) - fb(0));
     if (lq < 1 || lq > 254) { msg = "SAM line with a bad QNAME"; return false; }
     auto lookup = [&](const char *a, const char *z) -> int32_t { if (z - a == 1 && *a == '*') return -1; auto it = nm.m.find(std::string(a, z)); return it == nm.m.end() ? -1 : it->second; };   // (an unknown name: unmapped, as htslib treats it)
-    const int32_t tid = lookup(fb(2), fe(2));
+    int32_t tid = lookup(fb(2), fe(2));
     const int32_t mtid = (fe(6) - fb(6) == 1 && *fb(6) == '=') ? tid : lookup(fb(6), fe(6));
+    // htslib's sam_parse1: "mapped query cannot have zero coordinate; treated as unmapped" (tid = -1), and a read without a contig carries BAM_FUNMAP
+    if (pos == 0 && tid >= 0) tid = -1;
+    if (tid < 0) flag |= 4;
     // CIGAR
     const size_t base = out.size();
     uint32_t zero = 0; put_le(out, zero);                                              // block_size, patched at the end
     uint8_t core[32]; memset(core, 0, sizeof core); put(out, core, 32);
     put(out, fb(0), lq); out.push_back(0);
-    uint32_t n_cigar = 0; int64_t rlen = 0;
-    if (!(fe(5) - fb(5) == 1 && *fb(5) == '*')) {
+    uint32_t n_cigar = 0; int64_t rlen = 0, qlen = 0;
+    if (fe(5) - fb(5) == 1 && *fb(5) == '*') flag |= 4;                                  // sam_parse1: "mapped query must have a CIGAR; treated as unmapped" (the flag only: contig and position stay)
+    else {
         const char *p = fb(5), *z = fe(5);
         while (p < z) {
             uint64_t len = 0; const char *d = p;
@@ -112,6 +116,7 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
             const uint32_t op = (uint32_t)(o - ops);
             put_le(out, (uint32_t)(len << 4 | op));
             if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int64_t)len;
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += (int64_t)len;
             n_cigar++; p++;
             if (n_cigar > 65535) { msg = "more than 65535 CIGAR operations"; return false; }
         }
@@ -125,6 +130,7 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
         uint8_t *wp = &out[o0];
         for (size_t k = 0; k + 1 < lseq; k += 2) *wp++ = (uint8_t)(t16[(uint8_t)q[k]] << 4 | t16[(uint8_t)q[k + 1]]);
         if (lseq & 1) *wp = (uint8_t)(t16[(uint8_t)q[lseq - 1]] << 4);
+        if (n_cigar > 0 && qlen != (int64_t)lseq) { msg = "CIGAR and query sequence are of different length"; return false; }      // (sam_parse1's error: such a record would reach the vote, which walks bases by CIGAR)
     }
     {
         const char *q = fb(10), *z = fe(10);
@@ -166,6 +172,8 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
                 if (sub == 'f') { const float x = strtof(std::string(q, n).c_str(), nullptr); put_le(out, x); }
                 else {
                     long long x; if (!parse_int(q, n, x)) { msg = "malformed B value"; return false; }
+                    const long long lo_ = sub == 'c' ? -128 : sub == 's' ? -32768 : sub == 'i' ? -(1ll << 31) : 0, hi_ = sub == 'c' ? 127 : sub == 'C' ? 255 : sub == 's' ? 32767 : sub == 'S' ? 65535 : sub == 'i' ? 0x7FFFFFFFll : 0xFFFFFFFFll;
+                    if (x < lo_ || x > hi_) { msg = "B value out of its type's range"; return false; }
                     switch (sub) { case 'c': put_le(out, (int8_t)x); break; case 'C': put_le(out, (uint8_t)x); break; case 's': put_le(out, (int16_t)x); break;
                                    case 'S': put_le(out, (uint16_t)x); break; case 'i': put_le(out, (int32_t)x); break; default: put_le(out, (uint32_t)x); break; }
                 }
@@ -184,7 +192,7 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
     uint8_t *c = &out[base + 4];
     auto w32 = [&](int o, uint32_t x) { memcpy(c + o, &x, 4); };
     auto w16 = [&](int o, uint16_t x) { memcpy(c + o, &x, 2); };
-    w32(0, (uint32_t)tid); w32(4, (uint32_t)(int32_t)p0); c[8] = (uint8_t)(lq + 1); c[9] = (uint8_t)mapq; w16(10, bin); w16(12, (uint16_t)n_cigar); w16(14, (uint16_t)flag);
+    w32(0, (uint32_t)tid); w32(4, (uint32_t)(int32_t)p0); c[8] = (uint8_t)(lq + 1); c[9] = (uint8_t)mapq; w16(10, bin); w16(12, (uint16_t)n_cigar); w16(14, (uint16_t)flag);      // (flag: with BAM_FUNMAP added where sam_parse1 adds it)
     w32(16, (uint32_t)lseq); w32(20, (uint32_t)mtid); w32(24, (uint32_t)(int32_t)(pnext - 1)); w32(28, (uint32_t)(int32_t)tlen);
     const uint32_t bs = (uint32_t)(out.size() - base - 4);
     memcpy(&out[base], &bs, 4);

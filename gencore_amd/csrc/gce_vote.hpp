@@ -141,14 +141,17 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
 // item is placed by one ballot over the <= 32 prefix entries, every lane then walks on from there FOUR entries per LDS round trip (the
 // entries ascend: those <= the item are a prefix of the four) -- a wave's items span two to ten sides, and one entry per trip made
 // the last lanes wait for as many dependent trips.
+// No bounds tests (each one was an exec-mask branch of its own around one LDS read, four per trip): pre[n] is the total -- larger than every item, as
+// is whatever follows it in the array (the next sides' prefixes, then the 0xFFFF the arrays are padded with: VB_PRE entries) -- so reading up to four
+// entries past n is harmless and never counted.
+#define VB_PRE (VB_SIDES + 8)
 __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base, int lane, int last) {
     last = max(last, 0);
     const int b0 = min(base, last), it = min(base + lane, last);
-    const int pl = lane < n ? (int)pre[lane] : 0x7FFFFFFF;
+    const int pl = (int)pre[min(lane, n)];
     int s = __popcll(__ballot(pl <= b0)) - 1;
     for (;;) {
-        const int a1 = s + 1 < n ? (int)pre[s + 1] : 0x7FFFFFFF, a2 = s + 2 < n ? (int)pre[s + 2] : 0x7FFFFFFF;
-        const int a3 = s + 3 < n ? (int)pre[s + 3] : 0x7FFFFFFF, a4 = s + 4 < n ? (int)pre[s + 4] : 0x7FFFFFFF;
+        const int a1 = (int)pre[s + 1], a2 = (int)pre[s + 2], a3 = (int)pre[s + 3], a4 = (int)pre[s + 4];
         const int c = (a1 <= it) + (a2 <= it) + (a3 <= it) + (a4 <= it);
         s += c;
         if (c < 4) break;
@@ -173,9 +176,9 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ __attribute__((aligned(8))) uint32_t s_tal[VB_CCAP][5][2];          // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
                                                                                    // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
     __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
-    __shared__ uint16_t s_jpre[VB_SIDES + 1];                                      // pass B: first (voter, column) item of every side
+    __shared__ uint16_t s_jpre[VB_PRE];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
-    __shared__ uint16_t s_ipre[VB_SIDES + 1], s_cpre[VB_SIDES + 1];
+    __shared__ uint16_t s_ipre[VB_PRE], s_cpre[VB_PRE];                            // (entries behind VB_SIDES: 0xFFFF, see vb_find_wave)
     __shared__ uint16_t s_wbase[VB_SIDES][VB_COLS / 32];                           // place in the contested-column list of the first column of every 32-column word (P5b -> P7)
     __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         }
     }
     for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
+    if (tid >= 64 && tid < 64 + VB_PRE - VB_SIDES - 1) { const int k = VB_SIDES + 1 + tid - 64; s_ipre[k] = 0xFFFF; s_cpre[k] = 0xFFFF; s_jpre[k] = 0xFFFF; }
     if (tid >= VB_T - 4 * VB_SIDES) {                                                  // (the last waves: the first one is busy with the groups)
         const int k = tid - (VB_T - 4 * VB_SIDES);
         s_hm[k] = 0u;                                                                   // s_hm, s_single, s_vm, s_unf are adjacent

@@ -39,6 +39,8 @@ def records(seed=0, n=400):
         r = dict(qname="r%d:%s" % (k, "x" * rng.randrange(0, 40)), flag=flag, tid=tid, pos=pos, mapq=rng.randrange(0, 256), cigar=cigar,
                  mtid=mtid, mpos=-1 if mtid < 0 else rng.randrange(0, 99000), isize=rng.choice([0, 150, -150, 2 ** 31 - 1, -(2 ** 31 - 1), rng.randrange(-1000, 1000)]),
                  seq="".join(rng.choice("ACGTNRYKM=") for _ in range(ls)), qual=[rng.randrange(0, 94) for _ in range(ls)])
+        if tid < 0 or cigar == "*":
+            r["flag"] |= 4                       # what htslib's sam_parse1 makes of such a line (a read without contig or CIGAR carries BAM_FUNMAP): the text round trip keeps it
         if ls and rng.random() < 0.1:
             r["qual"] = [0xFF] * ls
         if ls == 1 and r["qual"] == [9]:
@@ -131,11 +133,29 @@ def test_sam_quirks(built, tmp_path):
     assert [g["qname"] for g in got] == ["a", "b", "c"]
     assert got[0]["seq"] == "ACGT" and got[0]["qual"] == [40] * 4 and got[0]["mtid"] == 0 and got[0]["aux"]["NM"] == ("C", 0) and got[0]["bin"] == 4681
     assert got[1]["tid"] == -1 and got[1]["mtid"] == 1 and got[1]["seq"] == "" and got[1]["cigar"] == []
+    assert got[1]["flag"] == 4                                # an unknown RNAME: treated as unmapped, BAM_FUNMAP set (sam_parse1)
     assert got[2]["tid"] == -1 and got[2]["pos"] == -1 and got[2]["qual"] == [255, 255] and got[2]["bin"] == 4680
 
 
+def test_sam_lines_htslib_treats_as_unmapped(built, tmp_path):
+    """sam_parse1: "mapped query cannot have zero coordinate; treated as unmapped" (contig dropped, BAM_FUNMAP), "mapped query must have a CIGAR;
+    treated as unmapped" (BAM_FUNMAP only: contig and position stay -- the consensus path goes by contig and position, src/gencore.cpp:255)."""
+    sam, bam = tmp_path / "u.sam", tmp_path / "u.bam"
+    open(sam, "w").write("@SQ\tSN:c1\tLN:1000\n"
+                         "z\t99\tc1\t0\t60\t4M\t=\t21\t14\tACGT\tIIII\n"
+                         "n\t99\tc1\t11\t60\t*\t=\t21\t14\tACGT\tIIII\n"
+                         "m\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\n")
+    bamio.sam_to_bam(sam, bam, threads=1)
+    _, _, got = pybam.read_bam(bam)
+    assert (got[0]["tid"], got[0]["pos"], got[0]["flag"]) == (-1, -1, 103)
+    assert (got[1]["tid"], got[1]["pos"], got[1]["flag"], got[1]["cigar"]) == (0, 10, 103, [])
+    assert (got[2]["tid"], got[2]["pos"], got[2]["flag"]) == (0, 10, 99)
+
+
 @pytest.mark.parametrize("line", ["a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT", "a\tx\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII", "a\t99\tc1\t11\t60\t4Q\t=\t21\t14\tACGT\tIIII",
-                                  "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIII", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tNM:i", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tNM:q:1"])
+                                  "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIII", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tNM:i", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tNM:q:1",
+                                  "a\t99\tc1\t11\t60\t5M\t=\t21\t14\tACGT\tIIII",             # "CIGAR and query sequence are of different length" (sam_parse1)
+                                  "a\t99\tc1\t11\t60\t2S1M\t=\t21\t14\tACGT\tIIII", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tXB:B:c,1,200", "a\t99\tc1\t11\t60\t4M\t=\t21\t14\tACGT\tIIII\tXB:B:S,-1"])
 def test_malformed_sam_lines_are_refused(built, tmp_path, line):
     sam = tmp_path / "bad.sam"
     open(sam, "w").write("@SQ\tSN:c1\tLN:1000\n" + line + "\n")
