@@ -1354,7 +1354,8 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
         reader_on = true;
         reader = std::thread([&, slot, keep, at, want] {                                    // the piece in up to four parts, read side by side (one pread stream copies ~7 GB/s out of the page cache)
             const double r0 = now_s();
-            const int R = (int)std::max<size_t>(1, std::min<size_t>({(size_t)4, (size_t)T, want >> 20}));
+            static const size_t RP = getenv("GCE_READ_PARTS") ? (size_t)atoi(getenv("GCE_READ_PARTS")) : 4;
+            const int R = (int)std::max<size_t>(1, std::min<size_t>({RP, (size_t)T, want >> 20}));
             std::vector<size_t> done_(R, 0); std::vector<std::thread> sub;
             auto part = [&](int r) { const size_t a = want * (size_t)r / R, z2 = want * (size_t)(r + 1) / R; size_t o = a; while (o < z2) { const ssize_t g = pread(fd, comp[slot].p + keep + o, z2 - o, (off_t)(at + o)); if (g <= 0) break; o += (size_t)g; } done_[r] = o - a; };
             for (int r = 1; r < R; r++) sub.emplace_back(part, r);
