@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
     "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch", "gce_sam_to_bam", "gce_bam_to_sam",
-    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_run_bam_sharded_hostcodec", "gce_raw_attach_mirror", "gce_raw_select_shard", "gce_raw_merge_outputs", "gce_raw_begin", "gce_raw_push", "gce_raw_push_bgzf", "gce_bgzf_inflate", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_run_bam_sharded_hostcodec", "gce_raw_deflate_output", "gce_raw_read_deflated_async", "gce_bgzf_deflate", "gce_raw_attach_mirror", "gce_raw_select_shard", "gce_raw_merge_outputs", "gce_raw_begin", "gce_raw_push", "gce_raw_push_bgzf", "gce_bgzf_inflate", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
 
 
 class GceBamInfo(C.Structure):

@@ -1287,6 +1287,8 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
 int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
 int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
 int gce_host_alloc(size_t bytes, void **out);
+int gce_raw_deflate_output(gce_engine *e, uint64_t *comp_bytes);
+int gce_raw_read_deflated_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
 int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror);
 int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode);
 int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total);
@@ -1700,6 +1702,33 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
     Pinned obuf[3]; int32_t otk[3] = {-1, -1, -1};
     Raw<uint8_t> zbuf; zbuf.resize((size_t)256 * 0x10000 + 64);
     if (!zbuf.ok()) return done(GCE_ERR_OOM, "out of host memory");
+    if (level == -2) {
+        // level -2: the record stream is deflated BY THE GPU (gce_deflate.hpp: fixed Huffman codes, one lane per BGZF block) -- the host compresses
+        // the header's few blocks, then only copies the file image out of HBM piece by piece and writes it
+        for (uint64_t o = 0; o < hdr.size(); o += BS) {
+            const uint32_t zs = (uint32_t)deflate_block(hdr.data() + o, (uint32_t)std::min<uint64_t>(BS, hdr.size() - o), 1, zbuf.data());
+            if (zs == 0 || fwrite(zbuf.data(), 1, zs, fo) != zs) return done(GCE_ERR_INVALID, "cannot write the output BAM");
+        }
+        uint64_t cb = 0;
+        if (body && (rc = gce_raw_deflate_output(e, &cb)) != GCE_OK) return done(rc, gce_last_error(e));
+        const uint64_t PC = (uint64_t)16 << 20; const int64_t np2 = (int64_t)((cb + PC - 1) / PC);
+        auto fetch2 = [&](int64_t pc) -> int { const uint64_t a2 = (uint64_t)pc * PC, z2 = std::min<uint64_t>(cb, a2 + PC); if (!obuf[pc & 1].ensure((size_t)(z2 - a2) + 64)) return GCE_ERR_OOM; return gce_raw_read_deflated_async(e, a2, obuf[pc & 1].p, (size_t)(z2 - a2), &otk[pc & 1]); };
+        if (np2 > 0 && (rc = fetch2(0)) != GCE_OK) return done(rc, "output piece");
+        for (int64_t pc = 0; pc < np2; pc++) {
+            if ((rc = gce_submit_wait(e, otk[pc & 1])) != GCE_OK) return done(rc, gce_last_error(e));
+            if (pc + 1 < np2 && (rc = fetch2(pc + 1)) != GCE_OK) return done(rc, "output piece");
+            const uint64_t a2 = (uint64_t)pc * PC, z2 = std::min<uint64_t>(cb, a2 + PC);
+            if (fwrite(obuf[pc & 1].p, 1, (size_t)(z2 - a2), fo) != (size_t)(z2 - a2)) return done(GCE_ERR_INVALID, "cannot write the output BAM");
+        }
+        static const uint8_t eof2[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool eof_ok2 = fwrite(eof2, 1, 28, fo) == 28;
+        const bool closed2 = fclose(fo) == 0; fo = nullptr;
+        if (!eof_ok2 || !closed2) return done(GCE_ERR_INVALID, "cannot write the output BAM");
+        out->write_s = now_s() - t0;
+        out->total_s = now_s() - t_start;
+        out->peak_rss_kb = status_kb("VmHWM:"); out->rss_end_kb = status_kb("VmRSS:");
+        return done(GCE_OK, "");
+    }
     auto fetch = [&](int64_t pc) -> int {                                                 // piece pc of (header ++ body) into obuf[pc % 3]
         const uint64_t a = (uint64_t)pc * OC, z2 = std::min<uint64_t>(total, a + OC);
         Pinned &b = obuf[pc % 3];

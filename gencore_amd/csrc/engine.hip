@@ -16,6 +16,7 @@
 #include "gce_output.hpp"
 #include "gce_depth.hpp"
 #include "gce_inflate.hpp"
+#include "gce_deflate.hpp"
 
 namespace {
 
@@ -80,6 +81,7 @@ struct gce_engine {
     DevBuf z_comp, z_dir, z_err; size_t z_n = 0; std::vector<InfDir> z_members;      // BGZF members waiting for the GPU inflate (gce_raw_push_bgzf)
     // the sharded file runner (gce_raw_attach_mirror / gce_raw_select_shard): engines that receive every push to this one's raw stream; this engine's
     // share of the stream (reads gathered from the full batch; sh_sel = their places in the whole stream)
+    DevBuf zo_slots, zo_sizes, zo_off, zo_out; uint64_t zo_bytes = 0;            // the output stream as BGZF blocks (gce_raw_deflate_output)
     std::vector<gce_engine *> mirrors;
     DevBuf sh_tickall, sh_shard, sh_flag, sh_sel, sh_core, sh_qoff, sh_coff, sh_soff, sh_loff, sh_nm, sh_nmt, sh_mioff, sh_tick, sh_roff, sh_nmpos, sh_keys, sh_stage; int64_t shard_n = -1;
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
@@ -168,6 +170,7 @@ void gce_destroy(gce_engine *e) {
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
+    for (DevBuf *b : {&e->zo_slots, &e->zo_sizes, &e->zo_off, &e->zo_out}) b->release();
     for (DevBuf *b : {&e->sh_tickall, &e->sh_shard, &e->sh_flag, &e->sh_sel, &e->sh_core, &e->sh_qoff, &e->sh_coff, &e->sh_soff, &e->sh_loff, &e->sh_nm, &e->sh_nmt, &e->sh_mioff, &e->sh_tick, &e->sh_roff, &e->sh_nmpos, &e->sh_keys, &e->sh_stage}) b->release();
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);

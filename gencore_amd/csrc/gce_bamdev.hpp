@@ -422,6 +422,44 @@ int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_
     return rc;
 }
 
+// The encoder of gce_raw_deflate_output on the caller's buffer (tests, tools): `n` bytes -> BGZF blocks of `block_bytes` input bytes each (<= 65 280),
+// back to back in out[0 .. *out_bytes); out_cap >= n + n / 8 + 64 x blocks is always enough.  Mirror of gce_bgzf_inflate.
+int gce_bgzf_deflate(int32_t device, const void *in, size_t n, uint32_t block_bytes, void *out, size_t out_cap, size_t *out_bytes) {
+    if ((n && !in) || !out_bytes || block_bytes < 1 || block_bytes > 0xff00u || (n && !out)) return GCE_ERR_INVALID;
+    *out_bytes = 0;
+    if (hipSetDevice(device) != hipSuccess) return GCE_ERR_NO_DEVICE;
+    if (!n) return GCE_OK;
+    const uint64_t nb64 = (n + block_bytes - 1) / block_bytes;
+    if (nb64 >= 0x7FFFFFF0ull) return GCE_ERR_INVALID;
+    const uint32_t nb = (uint32_t)nb64, slot = block_bytes + block_bytes / 8 + 64;
+    DevBuf zi, zs, zz, zo, zf, zt;
+    int rc = GCE_OK;
+    auto chk = [&](hipError_t x) { if (x != hipSuccess && rc == GCE_OK) rc = GCE_ERR_HIP; };
+    if (zi.ensure(n + 64) != hipSuccess || zs.ensure((size_t)nb * slot + 64) != hipSuccess || zz.ensure(((size_t)nb + 1) * 4) != hipSuccess || zf.ensure(((size_t)nb + 1) * 8) != hipSuccess) rc = GCE_ERR_OOM;
+    if (rc == GCE_OK) {
+        chk(hipMemcpy(zi.p, in, n, hipMemcpyHostToDevice)); chk(hipMemset((char *)zi.p + n, 0, 64));
+        hipLaunchKernelGGL(k_bgzf_deflate, dim3((nb + DEF_T - 1) / DEF_T), dim3(DEF_T), 0, 0, (const uint8_t *)zi.p, (uint64_t)n, block_bytes, nb, zs.as<uint8_t>(), slot, zz.as<uint32_t>());
+        chk(hipMemset((char *)zz.p + (size_t)nb * 4, 0, 4));
+        size_t tb = 0;
+        auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(zz.as<uint32_t>(), hipcub::CastOp<uint64_t>());
+        chk(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, zf.as<uint64_t>(), (int)(nb + 1), 0));
+        if (zt.ensure(tb) != hipSuccess) rc = GCE_ERR_OOM;
+        if (rc == GCE_OK) chk(hipcub::DeviceScan::ExclusiveSum(zt.p, tb, it, zf.as<uint64_t>(), (int)(nb + 1), 0));
+        uint64_t csz = 0;
+        if (rc == GCE_OK) chk(hipMemcpy(&csz, zf.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost));
+        if (rc == GCE_OK && csz > out_cap) rc = GCE_ERR_INVALID;
+        if (rc == GCE_OK && zo.ensure(csz + 64) != hipSuccess) rc = GCE_ERR_OOM;
+        if (rc == GCE_OK) {
+            hipLaunchKernelGGL(k_deflate_pack, dim3(std::min<uint32_t>((nb + 3) / 4, 16384u)), dim3(256), 0, 0, (const uint8_t *)zs.p, slot, (const uint32_t *)zz.p, (const uint64_t *)zf.p, nb, zo.as<uint8_t>());
+            chk(hipDeviceSynchronize()); chk(hipGetLastError());
+            chk(hipMemcpy(out, zo.p, csz, hipMemcpyDeviceToHost));
+            if (rc == GCE_OK) *out_bytes = (size_t)csz;
+        }
+    }
+    zi.release(); zs.release(); zz.release(); zo.release(); zf.release(); zt.release();
+    return rc;
+}
+
 // The whole stream is in HBM: index the records behind `records_begin` (the end of the BAM header), build the batch.  Afterwards the engine is
 // in the state gce_submit_device leaves it in: gce_process, then gce_drain / gce_result_device or gce_raw_build_output.
 int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records) {
@@ -729,6 +767,54 @@ int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_byte
     *body_bytes = total;
     if (n_out_total) *n_out_total = total_out;
     if (n_reads_total) *n_reads_total = total_reads;
+    return GCE_OK;
+}
+
+
+// After gce_raw_build_output (or gce_raw_merge_outputs): the record stream compressed into BGZF blocks by the GPU (gce_deflate.hpp: greedy LZ77,
+// fixed Huffman codes, one lane per block) -- replaces bgzf_write's deflate under sam_write1 (src/gencore.cpp:104).  *comp_bytes = size of the
+// file image of the records (BGZF blocks back to back; the caller writes the BAM header's blocks in front and the EOF marker behind);
+// gce_raw_read_deflated_async copies a piece of it to the host.
+int gce_raw_deflate_output(gce_engine *e, uint64_t *comp_bytes) {
+    if (!e || !e->raw_mode || !comp_bytes) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    hipStream_t s = e->stream;
+    const uint64_t total = e->raw_body_bytes;
+    *comp_bytes = 0; e->zo_bytes = 0;
+    if (!total) return GCE_OK;
+    // input bytes per block: enough blocks for every CU's 32 lanes (one workgroup per CU: the hash tables fill its LDS), never more than BGZF's 65 280
+    uint64_t blk = (total + 8191) / 8192; blk = (blk + 255) & ~(uint64_t)255;
+    if (blk < 4096) blk = 4096; if (blk > 0xff00) blk = 0xff00;
+    const uint64_t nb64 = (total + blk - 1) / blk;
+    if (nb64 >= 0x7FFFFFF0ull) return fail(e, GCE_ERR_INVALID, "output stream too large for one deflate pass");
+    const uint32_t nb = (uint32_t)nb64, slot = (uint32_t)(blk + blk / 8 + 64);
+    HIPCHK(e->zo_slots.ensure((size_t)nb * slot + 64)); HIPCHK(e->zo_sizes.ensure(((size_t)nb + 1) * 4)); HIPCHK(e->zo_off.ensure(((size_t)nb + 1) * 8));
+    hipLaunchKernelGGL(k_bgzf_deflate, dim3((nb + DEF_T - 1) / DEF_T), dim3(DEF_T), 0, s, (const uint8_t *)e->rw_body.p, total, (uint32_t)blk, nb, e->zo_slots.as<uint8_t>(), slot, e->zo_sizes.as<uint32_t>());
+    HIPCHK(hipMemsetAsync((char *)e->zo_sizes.p + (size_t)nb * 4, 0, 4, s));
+    size_t tb = 0;
+    auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->zo_sizes.as<uint32_t>(), hipcub::CastOp<uint64_t>());
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, e->zo_off.as<uint64_t>(), (int)(nb + 1), s));
+    HIPCHK(e->rw_tmp.ensure(tb));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, it, e->zo_off.as<uint64_t>(), (int)(nb + 1), s));
+    uint64_t csz = 0;
+    HIPCHK(hipMemcpyAsync(&csz, e->zo_off.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(e->zo_out.ensure(csz + 64));
+    hipLaunchKernelGGL(k_deflate_pack, dim3(std::min<uint32_t>((nb + 3) / 4, 16384u)), dim3(256), 0, s, (const uint8_t *)e->zo_slots.p, slot, (const uint32_t *)e->zo_sizes.p, (const uint64_t *)e->zo_off.p, nb, e->zo_out.as<uint8_t>());
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    e->zo_slots.release();
+    e->zo_bytes = csz; *comp_bytes = csz;
+    return GCE_OK;
+}
+int gce_raw_read_deflated_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket) {
+    if (!e || !e->raw_mode || offset + bytes > e->zo_bytes || (!host && bytes)) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (bytes) HIPCHK(hipMemcpyAsync(host, (const char *)e->zo_out.p + offset, bytes, hipMemcpyDeviceToHost, e->up_stream));
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, e->up_stream));
+    e->up_events.push_back(ev);
+    if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
     return GCE_OK;
 }
 

@@ -420,6 +420,15 @@ int gce_bgzf_inflate(int32_t device, const void *comp, size_t comp_bytes, int32_
 int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t *n_records);
 int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out);
 int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
+/* The output record stream (gce_raw_build_output / gce_raw_merge_outputs) compressed into BGZF blocks BY THE GPU -- replaces bgzf_write's deflate
+ * under sam_write1 (src/gencore.cpp:104 via htslib): greedy LZ77 + the fixed Huffman codes of RFC 1951, one lane per block, CRC-32 and ISIZE
+ * per block (gencore_amd/csrc/gce_deflate.hpp).  *comp_bytes = size of the records' file image; gce_raw_read_deflated_async copies a piece of
+ * it out (ticket -> gce_submit_wait).  The caller writes the BAM header's blocks in front and the 28-byte EOF marker behind: what gce_run_bam
+ * does for `level == -2` (level -1 = the same scheme on the host's threads; 0..9 = zlib).  gce_bgzf_deflate: the same encoder on the caller's
+ * buffer (tests, tools; mirror of gce_bgzf_inflate).  (Additions under ABI v3.) */
+int gce_raw_deflate_output(gce_engine *e, uint64_t *comp_bytes);
+int gce_raw_read_deflated_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
+int gce_bgzf_deflate(int32_t device, const void *in, size_t n, uint32_t block_bytes, void *out, size_t out_cap, size_t *out_bytes);
 int gce_host_alloc(size_t bytes, void **out);
 void gce_host_free(void *p);
 

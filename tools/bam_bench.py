@@ -44,6 +44,13 @@ def child(args):
                kernel_ms=round(r.kernel_ms, 3),
                pairs_per_s=dict(end_to_end=round(n_pairs / r.total_s), kernels_only=round(n_pairs / (r.kernel_ms * 1e-3))),
                first_run_total_s=round(runs[0][1].total_s, 3), make_input_s=round(t_make, 2), output_level=args.level)
+    if True:                                                    # the same run with the output deflated by the GPU (level -2) and by the host's fixed-Huffman encoder (level -1)
+        res["output_encoders"] = {}
+        for tag, lv in (("gpu_fixed_huffman_level_-2", -2), ("host_fixed_huffman_level_-1", -1)):
+            o2 = os.path.join(tmp, "out_lv%d.bam" % lv)
+            for rep in range(2):
+                rg = run_bam(src, o2, prm, fasta=None, threads=args.threads, chunk_reads=args.chunk, level=lv)
+            res["output_encoders"][tag] = dict(total_s=round(rg.total_s, 4), write_s=round(rg.write_s, 4), out_bam_bytes=os.path.getsize(o2), records_out=int(rg.n_out))
     if args.shards and int(args.shards) > 1:                   # the same file through gce_run_bam_sharded: K engines on device 0 (one GPU here: the paths, not a scaling claim)
         K = int(args.shards)
         res["sharded"] = {"engines": K, "devices": [0] * K, "note": "all engines on one GPU: every engine inflates and indexes the whole stream itself (on K GPUs that happens side by side)"}
