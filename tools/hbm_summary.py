@@ -37,10 +37,13 @@ def main():
         for k in rows:
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k, fe.get(k, (0, 0))[1] or wr.get(k, (0, 0))[1], fe.get(k, (0, 0))[0] / 1e3, 2 * fe.get(k, (0, 0))[0] / 1e3, wr.get(k, (0, 0))[0] / 1e3))
     js = {k: {"fetch_bytes": fe.get(k, (0, 0))[0] * 1e3, "fetch_bytes_x2": 2e3 * fe.get(k, (0, 0))[0], "write_bytes": wr.get(k, (0, 0))[0] * 1e3} for k in rows}
-    cons = [k for k in rows if k in ("k_vote", "k_score2", "k_consensus_fast", "k_consensus_slow")]
+    cons = [k for k in rows if k in ("k_vote", "k_score2", "k_consensus_fast", "k_consensus_slow", "k_deep_prepare", "k_vote_deep")]
     # (tools/mb/fetch_calib.hip, profiles/r03_fetch_calibration.json: the x2 of FETCH_SIZE holds for streaming reads of every lane width incl. the vote's
     #  unaligned 8-byte loads; WRITE_SIZE is exact; the counter unit is 1024 bytes)
-    json.dump({"note": note, "tag": dst.rsplit("/", 1)[-1], "workload": workload, "consensus_kernels": cons, "kernels": js}, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)
+    doc = {"note": note, "tag": dst.rsplit("/", 1)[-1], "workload": workload, "consensus_kernels": cons, "kernels": js}
+    json.dump(doc, open(dst.rsplit("/", 1)[0] + "/hbm_traffic_%s.json" % workload, "w"), indent=1)
+    if workload == "cfg3":
+        json.dump(doc, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)
     print(open(dst + "_hbm_traffic.csv").read())
 
 

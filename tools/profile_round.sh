@@ -15,5 +15,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_$c.log 2>&1
 done
+for wl in cfg2 cfg5; do for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${TAG}_${wl}_pmc_$c -o p -- python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_${wl}_pmc_$c.log 2>&1
+done; done
 timeout 600 python tools/bam_bench.py --pairs 4000000 --shards 4 --c-caller 2>&1 | tail -1 > gpurun_out/${TAG}_bam_e2e_cfg3.json
 cat gpurun_out/${TAG}_bench_cfg3.json
