@@ -684,6 +684,19 @@ int gce_process(gce_engine *e) {
             hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, count, (unsigned long long *)nullptr);
             hipLaunchKernelGGL(k_flag_apply, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, (const uint64_t *)w.scan_part, list);
         };
+#ifdef PS_STOP
+        {   // experiment builds (tools/pair_stop.sh): time the truncated k_pairing_sub<16> (all clusters) and <32> (all clusters as well: no list) alone and stop
+            hipEvent_t a_, b_, c_; (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventCreate(&c_);
+            (void)hipEventRecord(a_, s);
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
+            (void)hipEventRecord(b_, s);
+            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pf_flag);
+            (void)hipEventRecord(c_, s); (void)hipEventSynchronize(c_);
+            float m1 = 0, m2 = 0; (void)hipEventElapsedTime(&m1, a_, b_); (void)hipEventElapsedTime(&m2, b_, c_);
+            fprintf(stderr, "k_pairing_sub up to tick %d: <16> %.3f ms, <32> over ALL clusters %.3f ms\n", PS_STOP, m1, m2);
+            return fail(e, GCE_ERR_INVALID, "experiment build");
+        }
+#endif
         hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
         compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
         hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);

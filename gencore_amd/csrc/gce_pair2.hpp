@@ -27,6 +27,11 @@ template <int SUB> __device__ __forceinline__ uint32_t sub_ballot(bool pr, int h
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64_t)__shfl((long long)v, src); }
 
 // SUB = lanes per cluster (32: two clusters per wave, 16: four).  `list` != nullptr: the clusters a narrower instantiation flagged.
+#ifdef PS_STOP                        // cumulative cost of the phases (tools/pair_stop.sh): the kernel ends at tick PS_STOP
+#define PS_TICK(k, live_) do { if ((k) >= PS_STOP) { if ((uint32_t)(live_) == 0xDEADBEEFu) flag_out[0] = 1; return; } } while (0)      // (live_: what the phase computed -- keeps it from being optimised away)
+#else
+#define PS_TICK(k, live_) do { } while (0)
+#endif
 template <int SUB>
 __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Work w, uint32_t n_clusters, const uint32_t *list, const unsigned long long *list_n, uint8_t *flag_out) {
     constexpr int PER = 64 / SUB;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     const uint32_t toolong = sub_ballot<SUB>(nl > 64 || ul > 24, hb);
     if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
     if (!__any(live)) return;
+    PS_TICK(0, my ^ (uint32_t)nl ^ (uint32_t)ul ^ (uint32_t)(uintptr_t)nm ^ (uint32_t)(uintptr_t)up);
     const bool act = live && hl < (int)n;
     const int nwords = (wave_max_u(act ? nl : 0) + 7) >> 3;
     uint64_t nw[8];
@@ -78,6 +84,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         h32 = __builtin_rotateleft32(h32, 11) ^ (hi + 0x7F4A7C15u);
     }
     h32 ^= h32 >> 15;
+    PS_TICK(1, h32 ^ (uint32_t)(nw[0] ^ nw[1] ^ nw[2] ^ nw[3] ^ nw[4] ^ nw[5] ^ nw[6] ^ nw[7]) ^ (uint32_t)(ruw[0] ^ ruw[1] ^ ruw[2]));
     const int nmax = wave_max_u(live ? (int)n : 0);
     uint32_t EQ = 0, LOW = 0;
     {   // one ballot per DISTINCT hash of a half: a whole name class at a time (the halves run to the largest class count)
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         if (live && badm) { if (hl == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; live = false; }     // false hash match: generic kernel
     }
     if (!__any(live)) return;
+    PS_TICK(2, EQ ^ (LOW << 1));
     const bool act2 = act && live;
     // ---- pairs: first read of a name = mLeft, last one = mRight
     const bool first = act2 && !(EQ & LOW), last = act2 && !(EQ & ~LOW);
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         }
     }
     const uint32_t pidx = __popc(LT);                       // distinct names before mine
+    PS_TICK(3, LT ^ pidx ^ FIRST);
     {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty; the pair's current read is
         // the predecessor in arrival order = the largest read index among the same-name reads before mine
         uint32_t prev = act2 ? (EQ & LOW) : 0u;
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         R = (uint32_t)__builtin_amdgcn_ds_permute(to_right, (last && !first) ? (int)(my + 1u) : 0) - 1u;
         if (!pact) { L = NONE32; R = NONE32; }
     }
+    PS_TICK(4, L ^ (R << 1) ^ (uint32_t)any_umi);
     if (__any(any_umi)) {                                    // greedy UMI grouping (cluster.cpp:57-100), for the halves that carry UMIs
         uint64_t uw[3]; int ulen;
         {
@@ -253,6 +263,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             if (open) ngroups++;
         }
     }
+    PS_TICK(5, g_of ^ (ngroups << 8) ^ L ^ R);
     // ---- lay the pairs out group by group (qname order inside a group)
     {
         uint32_t gbase = 0;
