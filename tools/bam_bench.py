@@ -48,8 +48,14 @@ def child(args):
         res["output_encoders"] = {}
         for tag, lv in (("gpu_fixed_huffman_level_-2", -2), ("host_fixed_huffman_level_-1", -1)):
             o2 = os.path.join(tmp, "out_lv%d.bam" % lv)
-            for rep in range(2):
-                rg = run_bam(src, o2, prm, fasta=None, threads=args.threads, chunk_reads=args.chunk, level=lv)
+            rg = None
+            for rep in range(3):                               # best of three, the input re-read into the page cache in front of each (the FASTA and the outputs of the runs before push it out on a small box)
+                with open(src, "rb") as fh_:
+                    while fh_.read(1 << 26):
+                        pass
+                r_ = run_bam(src, o2, prm, fasta=None, threads=args.threads, chunk_reads=args.chunk, level=lv)
+                if rg is None or r_.total_s < rg.total_s:
+                    rg = r_
             res["output_encoders"][tag] = dict(total_s=round(rg.total_s, 4), write_s=round(rg.write_s, 4), out_bam_bytes=os.path.getsize(o2), records_out=int(rg.n_out))
     if args.shards and int(args.shards) > 1:                   # the same file through gce_run_bam_sharded: K engines on device 0 (one GPU here: the paths, not a scaling claim)
         K = int(args.shards)
@@ -58,13 +64,15 @@ def child(args):
             if env:
                 os.environ["GCE_BAM_HOSTCODEC"] = env
             try:
-                best = None
-                for rep in range(2):
+                rs = None
+                for rep in range(3):
                     o2 = os.path.join(tmp, "out_sh_%s.bam" % tag)
-                    t0 = time.time()
-                    rs = run_bam_sharded(src, o2, prm, [0] * K, fasta=None, threads=args.threads, level=args.level)      # (no FASTA, like the timed single-engine run it is compared with)
-                    best = (time.time() - t0, rs)
-                rs = best[1]
+                    with open(src, "rb") as fh_:
+                        while fh_.read(1 << 26):
+                            pass
+                    r_ = run_bam_sharded(src, o2, prm, [0] * K, fasta=None, threads=args.threads, level=args.level)      # (no FASTA, like the timed single-engine run it is compared with)
+                    if rs is None or r_.total_s < rs.total_s:
+                        rs = r_
                 res["sharded"][tag] = dict(total_s=round(rs.total_s, 4), input_pipeline=round(rs.open_s, 4), index_plan_select=round(rs.index_s, 4), process=round(rs.process_s, 4), merge=round(rs.drain_s, 4), write=round(rs.write_s, 4),
                                            kernel_ms_slowest_engine=round(rs.kernel_ms, 3), records_out=int(rs.n_out), output_identical_to_single_engine=open(o2, "rb").read() == open(out, "rb").read(),
                                            stats_equal=bool(bytes(rs.pre) == bytes(r.pre) and bytes(rs.post) == bytes(r.post)))
