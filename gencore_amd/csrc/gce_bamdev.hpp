@@ -273,6 +273,66 @@ __global__ void k_add_i64(long long *acc, const long long *x, int n) { const int
 
 }  // namespace
 
+
+// ---- prefix sums and compaction of the file layer on the engine's own scan kernels (gce_cluster.hpp: tiles of 2048, one block over the tile
+//      totals): exclusive sums out[0 .. n] (out[n] = the total) of n 32- or 64-bit values, three launches; flagged indices, three launches
+namespace {
+template <class T> __global__ __launch_bounds__(256) void k_xs_reduce(const T *in, uint64_t n, uint64_t *part) {
+    __shared__ uint64_t s4[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE; uint64_t v = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) { const uint64_t i = base + k * 256 + threadIdx.x; v += i < n ? (uint64_t)in[i] : 0ull; }
+    v = (uint64_t)wave_sum64((long long)v);
+    if (lane_id() == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s4[0] + s4[1] + s4[2] + s4[3];
+}
+template <class T> __global__ __launch_bounds__(256) void k_xs_apply(const T *in, uint64_t n, const uint64_t *part, uint64_t *out) {
+    __shared__ uint64_t s_w[4]; __shared__ uint64_t s_carry;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = part[blockIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        const uint64_t i = base + k * 256 + threadIdx.x;
+        const uint64_t v = i < n ? (uint64_t)in[i] : 0ull; uint64_t x = v;
+        for (int q = 1; q < 64; q <<= 1) { const uint64_t t = (uint64_t)__shfl_up((long long)x, q); if (lane >= q) x += t; }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        const uint64_t carry = s_carry, ex = carry + woff + x - v;
+        if (i < n) out[i] = ex;
+        if (i + 1 == n) out[n] = ex + v;                                              // the total behind the last element
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+}
+}  // namespace
+template <class T> static hipError_t dev_exclusive_sum(const T *in, uint64_t n, uint64_t *out, DevBuf &tmp, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(out, 0, 8, s);
+    const unsigned nb = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipError_t e = tmp.ensure((size_t)nb * 8 + 64);
+    if (e != hipSuccess) return e;
+    uint64_t *part = tmp.as<uint64_t>();
+    hipLaunchKernelGGL(k_xs_reduce<T>, dim3(nb), dim3(256), 0, s, in, n, part);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, part, (uint64_t)nb, (unsigned long long *)(part + nb), (unsigned long long *)(part + nb + 1));
+    hipLaunchKernelGGL(k_xs_apply<T>, dim3(nb), dim3(256), 0, s, in, n, (const uint64_t *)part, out);
+    return hipGetLastError();
+}
+// indices (ascending) of the set flags -> out, their number -> *count (device memory)
+static hipError_t dev_select_flagged(const uint8_t *flag, uint64_t n, uint32_t *out, unsigned long long *count, DevBuf &tmp, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(count, 0, 8, s);
+    const unsigned nb = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipError_t e = tmp.ensure((size_t)nb * 8 + 64);
+    if (e != hipSuccess) return e;
+    uint64_t *part = tmp.as<uint64_t>();
+    hipLaunchKernelGGL(k_flag_reduce, dim3(nb), dim3(256), 0, s, flag, n, part);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, part, (uint64_t)nb, count, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_flag_apply, dim3(nb), dim3(256), 0, s, flag, n, (const uint64_t *)part, out);
+    return hipGetLastError();
+}
+
 extern "C" {
 
 int gce_raw_begin(gce_engine *e, size_t capacity_hint) {
@@ -440,11 +500,7 @@ int gce_bgzf_deflate(int32_t device, const void *in, size_t n, uint32_t block_by
         chk(hipMemcpy(zi.p, in, n, hipMemcpyHostToDevice)); chk(hipMemset((char *)zi.p + n, 0, 64));
         hipLaunchKernelGGL(k_bgzf_deflate, dim3((nb + DEF_T - 1) / DEF_T), dim3(DEF_T), 0, 0, (const uint8_t *)zi.p, (uint64_t)n, block_bytes, nb, zs.as<uint8_t>(), slot, zz.as<uint32_t>());
         chk(hipMemset((char *)zz.p + (size_t)nb * 4, 0, 4));
-        size_t tb = 0;
-        auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(zz.as<uint32_t>(), hipcub::CastOp<uint64_t>());
-        chk(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, zf.as<uint64_t>(), (int)(nb + 1), 0));
-        if (zt.ensure(tb) != hipSuccess) rc = GCE_ERR_OOM;
-        if (rc == GCE_OK) chk(hipcub::DeviceScan::ExclusiveSum(zt.p, tb, it, zf.as<uint64_t>(), (int)(nb + 1), 0));
+        chk(dev_exclusive_sum(zz.as<uint32_t>(), (uint64_t)nb, zf.as<uint64_t>(), zt, 0));
         uint64_t csz = 0;
         if (rc == GCE_OK) chk(hipMemcpy(&csz, zf.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost));
         if (rc == GCE_OK && csz > out_cap) rc = GCE_ERR_INVALID;
@@ -510,11 +566,7 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
             if (flags[1]) return fail(e, GCE_ERR_INVALID, "truncated or damaged BAM record stream");
             lap("repair");
         }
-        size_t tb = 0;                                                             // exclusive scan of the segments' record counts (rocPRIM through hipCUB)
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_cnt.as<uint32_t>(), hipcub::CastOp<uint64_t>()), e->rw_base.as<uint64_t>(), (int)(nseg + 1), s));
-        HIPCHK(e->rw_tmp.ensure(tb));
-        HIPCHK(hipMemsetAsync((char *)e->rw_cnt.p + nseg * 4, 0, 4, s));           // (one element past the end: the total comes out as base[nseg])
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_cnt.as<uint32_t>(), hipcub::CastOp<uint64_t>()), e->rw_base.as<uint64_t>(), (int)(nseg + 1), s));
+        HIPCHK(dev_exclusive_sum(e->rw_cnt.as<uint32_t>(), nseg, e->rw_base.as<uint64_t>(), e->rw_tmp, s));      // exclusive scan of the segments' record counts: the total comes out as base[nseg]
         HIPCHK(hipMemcpyAsync(&n_rec, e->rw_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
         if (n_rec >= 0x7FFFFFF0ull) return fail(e, GCE_ERR_INVALID, "more than 2^31 records in one stream");
         lap("segments + scan");
@@ -533,13 +585,8 @@ int gce_raw_finish(gce_engine *e, uint64_t records_begin, int32_t n_ref, int64_t
         HIPCHK(hipMemsetAsync(e->rw_misc.as<unsigned int>() + 4, 0xFF, 4, s));
         const unsigned nbr = (unsigned)((n_rec + 255) / 256);
         hipLaunchKernelGGL(k_raw_fill, dim3(nbr), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, n_rec, o);
-        size_t tb = 0;
-        HIPCHK(hipMemsetAsync((char *)e->rw_ncig.p + n_rec * 4, 0, 4, s));
-        auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->rw_ncig.as<uint32_t>(), hipcub::CastOp<uint64_t>());
         HIPCHK(e->b_coff.ensure((n1 + 1) * 8 + 64));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, e->b_coff.as<uint64_t>(), (int)(n_rec + 1), s));
-        HIPCHK(e->rw_tmp.ensure(tb));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, it, e->b_coff.as<uint64_t>(), (int)(n_rec + 1), s));
+        HIPCHK(dev_exclusive_sum(e->rw_ncig.as<uint32_t>(), n_rec, e->b_coff.as<uint64_t>(), e->rw_tmp, s));
         HIPCHK(hipMemcpyAsync(&cig_words, e->b_coff.as<uint64_t>() + n_rec, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&have_mi, e->rw_misc.as<unsigned int>() + 2, 4, hipMemcpyDeviceToHost, s));
         unsigned int bad_rec = NONE32;
@@ -577,11 +624,7 @@ int gce_raw_build_output(gce_engine *e, uint64_t *body_bytes, int64_t *n_out) {
     RawOut r{e->o_src.as<uint32_t>(), e->o_qsrc.as<uint32_t>(), e->o_nm.as<int32_t>(), e->o_fr.as<int16_t>(), e->o_rr.as<int16_t>()};
     const unsigned nb = (unsigned)((no + 255) / 256);
     hipLaunchKernelGGL(k_rec_size, dim3(nb), dim3(256), 0, s, u, (const uint64_t *)e->rw_off.p, r, no, e->rw_rsize.as<uint64_t>());
-    HIPCHK(hipMemsetAsync((char *)e->rw_rsize.p + no * 8, 0, 8, s));
-    size_t tb = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, e->rw_rsize.as<uint64_t>(), e->rw_roff.as<uint64_t>(), (int)(no + 1), s));
-    HIPCHK(e->rw_tmp.ensure(tb));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, e->rw_rsize.as<uint64_t>(), e->rw_roff.as<uint64_t>(), (int)(no + 1), s));
+    HIPCHK(dev_exclusive_sum(e->rw_rsize.as<uint64_t>(), no, e->rw_roff.as<uint64_t>(), e->rw_tmp, s));
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, e->rw_roff.as<uint64_t>() + no, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
     HIPCHK(e->rw_body.ensure(total + 64));
@@ -636,10 +679,7 @@ int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t pla
     if ((rc = gce_plan_shards(e->prm.device, e->b_core.as<gce_core>(), n, world, plan_mode, e->sh_shard.as<int32_t>())) != GCE_OK) return fail(e, rc, gce_status_message(rc));
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_shard_flag, dim3(nb), dim3(256), 0, s, (const int32_t *)e->sh_shard.p, n, rank, e->sh_flag.as<uint8_t>());
-    size_t tb = 0;
-    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tb, hipcub::CountingInputIterator<uint32_t>(0), e->sh_flag.as<uint8_t>(), e->sh_sel.as<uint32_t>(), (int64_t *)e->rw_misc.p, (int)n, s));
-    HIPCHK(e->rw_tmp.ensure(tb));
-    HIPCHK(hipcub::DeviceSelect::Flagged(e->rw_tmp.p, tb, hipcub::CountingInputIterator<uint32_t>(0), e->sh_flag.as<uint8_t>(), e->sh_sel.as<uint32_t>(), (int64_t *)e->rw_misc.p, (int)n, s));
+    HIPCHK(dev_select_flagged(e->sh_flag.as<uint8_t>(), (uint64_t)n, e->sh_sel.as<uint32_t>(), (unsigned long long *)e->rw_misc.p, e->rw_tmp, s));
     int64_t m = 0;
     HIPCHK(hipMemcpyAsync(&m, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
     const size_t m1 = (size_t)(m > 0 ? m : 1);
@@ -791,11 +831,7 @@ int gce_raw_deflate_output(gce_engine *e, uint64_t *comp_bytes) {
     HIPCHK(e->zo_slots.ensure((size_t)nb * slot + 64)); HIPCHK(e->zo_sizes.ensure(((size_t)nb + 1) * 4)); HIPCHK(e->zo_off.ensure(((size_t)nb + 1) * 8));
     hipLaunchKernelGGL(k_bgzf_deflate, dim3((nb + DEF_T - 1) / DEF_T), dim3(DEF_T), 0, s, (const uint8_t *)e->rw_body.p, total, (uint32_t)blk, nb, e->zo_slots.as<uint8_t>(), slot, e->zo_sizes.as<uint32_t>());
     HIPCHK(hipMemsetAsync((char *)e->zo_sizes.p + (size_t)nb * 4, 0, 4, s));
-    size_t tb = 0;
-    auto it = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *>(e->zo_sizes.as<uint32_t>(), hipcub::CastOp<uint64_t>());
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, e->zo_off.as<uint64_t>(), (int)(nb + 1), s));
-    HIPCHK(e->rw_tmp.ensure(tb));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(e->rw_tmp.p, tb, it, e->zo_off.as<uint64_t>(), (int)(nb + 1), s));
+    HIPCHK(dev_exclusive_sum(e->zo_sizes.as<uint32_t>(), (uint64_t)nb, e->zo_off.as<uint64_t>(), e->rw_tmp, s));
     uint64_t csz = 0;
     HIPCHK(hipMemcpyAsync(&csz, e->zo_off.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
     HIPCHK(e->zo_out.ensure(csz + 64));
