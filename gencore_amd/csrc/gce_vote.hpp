@@ -45,17 +45,19 @@ static_assert(VB_W + 32 <= 128, "P1 finds a pair's group by a bytewise compare o
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
 #ifndef VB_CCAP
-#define VB_CCAP 184        // (with VB_RCAP: LDS stays within 22.5 KB = seven workgroups per CU; 168 / 640: 2.86 ms, 184 / 512: 2.82 ms)
+#define VB_CCAP 128        // (with VB_RCAP: LDS stays within 20 KB = EIGHT workgroups per CU, at 64 VGPRs (three dwords spilled): 2.79 -> 2.76 ms against
+                           //  184 / 512 at seven (22.5 KB, 66 VGPRs), although nearly half of the batches now vote in two rounds; batches of weight 80 / 64 at eight
+                           //  workgroups: 2.84 / 3.03 ms.  profiles/r04_q_ab_8waves.log)
 #endif
 //   VB_CCAP: contested columns voted per round (LDS tallies)
 #ifndef VB_WPE
-#define VB_WPE 7
+#define VB_WPE 8
 #endif
 #ifndef VB_SMAX
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #endif
 #ifndef VB_RCAP
-#define VB_RCAP 512        // contested columns of a whole batch (all rounds): a side that does not fit any more hands its group on (32 sides x VB_SMAX would be 1024)
+#define VB_RCAP 384        // contested columns of a whole batch (all rounds): a side that does not fit any more hands its group on (32 sides x VB_SMAX would be 1024)
 #endif
 
 struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
