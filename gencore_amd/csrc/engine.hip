@@ -447,6 +447,24 @@ static int read_si(gce_engine *e) {
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Several byte fills in ONE launch (hipMemsetAsync is a launch of its own per buffer: a step had eleven).  Buffers start on 16-byte boundaries (hipMalloc).
+struct FillSeg { void *p; uint64_t bytes; uint32_t val; uint32_t pad; };
+struct FillArgs { FillSeg s[6]; };
+__global__ __launch_bounds__(256) void k_fill_many(FillArgs a) {
+    const FillSeg g = a.s[blockIdx.y];
+    const uint64_t n16 = g.bytes >> 4;
+    const uint32_t v = g.val * 0x01010101u;
+    uint4 *q = reinterpret_cast<uint4 *>(g.p);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) q[i] = make_uint4(v, v, v, v);
+    if (blockIdx.x == 0 && threadIdx.x < (g.bytes & 15)) reinterpret_cast<uint8_t *>(g.p)[(n16 << 4) + threadIdx.x] = (uint8_t)g.val;
+}
+static void fill_many(hipStream_t s, std::initializer_list<FillSeg> segs) {
+    FillArgs a{}; int n = 0; uint64_t mx = 0;
+    for (const FillSeg &g : segs) { a.s[n++] = g; mx = std::max<uint64_t>(mx, g.bytes); }
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((mx >> 4) / (256 * 8), 1), 2048);      // ~8 stores per thread for the longest buffer
+    hipLaunchKernelGGL(k_fill_many, dim3(gx, (unsigned)n), dim3(256), 0, s, a);
+}
+
 // the second HIP stream of an engine (and its two events): made when a step first wants it
 static int aux_ready(gce_engine *e) {
     if (e->aux_stream) return GCE_OK;
@@ -672,12 +690,13 @@ int gce_process(gce_engine *e) {
     w.cl_nresult = e->cl_nresult.as<uint32_t>(); w.cl_hasumi = e->cl_hasumi.as<uint8_t>();
     uint32_t NG = 0;
     if (C > 0 && e->dev_error == 0) {
-        HIPCHK(hipMemsetAsync(e->gpl.p, 0xFF, n1 * 4, s));          // k_score2 recognises pair slots by gpl != NONE
+        // (gpl / gpr need no clearing: every reader -- k_vote, k_score2 behind the slot flags, the per-side kernels, k_group_tail -- looks at the pair slots
+        //  [g_begin, g_begin + g_np) of a group only, and the pairing kernels write both words of every one of those)
         // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
         // compacted by the scan kernels (never one shared append counter)
         ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4);
         w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>();
-        HIPCHK(hipMemsetAsync(e->pf_flag.p, 0, c1, s)); HIPCHK(hipMemsetAsync(e->pq_flag.p, 0, c1, s));
+        fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}, FillSeg{e->pq_flag.p, c1, 0u, 0u}});
         const unsigned nbc = cdiv(C, SCAN_TILE);
         auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
             hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
@@ -739,11 +758,11 @@ int gce_process(gce_engine *e) {
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     w.rp_nm = e->rp_nm.as<int32_t>(); w.rp_qsl = e->rp_qsl.as<uint32_t>(); w.rp_qsr = e->rp_qsr.as<uint32_t>();
     if (NG > 0 && e->dev_error == 0) {
-        HIPCHK(hipMemsetAsync(e->spatch.p, 0, n1 * 4, s));         // 0 = no overlap patch: every score is qual2score(qual)
-        HIPCHK(hipMemsetAsync(e->gen_flag.p, 0, g1 * 2, s));
-        HIPCHK(hipMemsetAsync(e->rp_nm.p, 0xFF, g1 * 8, s));       // -1: NM untouched
-        HIPCHK(hipMemsetAsync(e->rp_left.p, 0xFF, g1 * 4, s)); HIPCHK(hipMemsetAsync(e->rp_right.p, 0xFF, g1 * 4, s));   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
-        HIPCHK(hipMemsetAsync(e->slot_flag.p, 0, n1, s));
+        // one launch for the five clears (spatch needs none: k_score2 writes the patch word of both reads of every pair it scores, and only those are read)
+        fill_many(s, {FillSeg{e->gen_flag.p, g1 * 2, 0u, 0u},
+                      FillSeg{e->rp_nm.p, g1 * 8, 0xFFu, 0u},                                  // -1: NM untouched
+                      FillSeg{e->rp_left.p, g1 * 4, 0xFFu, 0u}, FillSeg{e->rp_right.p, g1 * 4, 0xFFu, 0u},   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
+                      FillSeg{e->slot_flag.p, n1, 0u, 0u}});
         const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
 #ifdef VB_STOP
         {   // experiment builds (tools/vote_stop.sh): time the truncated k_vote alone and stop -- it leaves garbage behind

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w,
                 if (cmp > 0) {
                     w.spatch[L] = (uint32_t)lstart | ((uint32_t)cmp << 16); w.spatch[R] = (uint32_t)rstart | ((uint32_t)cmp << 16);
                     lso = lk.so; rso = rk.so; lqo = lk.qo; rqo = rk.qo;
-                } else cmp = 0;                                                                  // no overlap: both reads are pure qual2score
+                } else { cmp = 0; w.spatch[L] = 0u; w.spatch[R] = 0u; }                          // no overlap: both reads are pure qual2score (written, not assumed: nobody clears spatch)
             }
         }
     }
