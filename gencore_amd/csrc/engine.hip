@@ -658,7 +658,7 @@ int gce_process(gce_engine *e) {
     w.slow_list = e->slow_list.as<uint32_t>();
     ENS(deep_list, (n1 / 64 + 64) * 16); w.deep_list = e->deep_list.p;
     const unsigned nblk_N = cdiv(n1, SCAN_TILE);
-    ENS(scan_part, std::max<size_t>(nsb1, (size_t)2 * nblk_N) * 8 + 16);        /* 2 x: the group-side flags (<= 2 per read) */ ENS(si, sizeof(StreamInfo));
+    ENS(scan_part, std::max<size_t>(2 * nsb1, (size_t)2 * nblk_N) * 8 + 16);    /* 2 x: the group-side flags (<= 2 per read); the scan blocks' totals behind those of k_num_reduce's blocks */ ENS(si, sizeof(StreamInfo));
     w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.nmx = e->nmx.as<uint32_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
@@ -710,7 +710,7 @@ int gce_process(gce_engine *e) {
         const unsigned nb4 = cdiv(n_sblk, 4);
         hipLaunchKernelGGL(k_leaders, dim3(nb4), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_num_reduce, dim3(nb4), dim3(256), 0, s, w, p.nw_cb);
-        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)n_sblk, &w.si->n_clusters, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb4, &w.si->n_clusters, (unsigned long long *)nullptr);      // (one partial per k_num_reduce block)
         hipLaunchKernelGGL(k_num_apply, dim3(nb4), dim3(256), 0, s, w);
         hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, N, w);
     }

@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
 __global__ __launch_bounds__(256) void k_num_reduce(Work w, int p_cb) {
     const int lane = lane_id();
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (blk >= w.n_sblk) return;
-    const uint32_t nl = w.bhdr[blk].n_lead;
+    const bool on = blk < w.n_sblk;                                                         // (no early return: the block meets at a barrier below)
+    const uint32_t nl = on ? w.bhdr[blk].n_lead : 0u;
     uint64_t v = 0;
     for (uint32_t kq = (uint32_t)lane; kq < nl; kq += 64) {
         const size_t LR = (size_t)blk * SB_READS + kq;
@@ -459,7 +459,12 @@ __global__ __launch_bounds__(256) void k_num_reduce(Work w, int p_cb) {
         }
     }
     v = (uint64_t)wave_sum64((long long)v);
-    if (lane == 0) w.scan_part[blk] = v;
+    // one partial per BLOCK of four scan blocks goes through k_scan_partials (a single workgroup: 33 us for 39 k partials, 10 us for a quarter of
+    // them); the waves' own totals stay unscanned behind them (scan_part[nb4 + blk]) and k_num_apply adds up those of the waves in front of it
+    __shared__ uint64_t s_v[4];
+    if (lane == 0) { s_v[threadIdx.x >> 6] = v; if (on) w.scan_part[gridDim.x + blk] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) w.scan_part[blockIdx.x] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
 }
 // element(h) = (count>0) << 32 | count ; used by the small per-cluster scans below
 __device__ __forceinline__ uint64_t tab_elem(const uint32_t *cnt, uint64_t h, uint64_t n) {
@@ -507,7 +512,8 @@ __global__ __launch_bounds__(256) void k_num_apply(Work w) {
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blk >= w.n_sblk) return;
     const uint32_t nl = w.bhdr[blk].n_lead;
-    uint64_t carry = w.scan_part[blk];
+    uint64_t carry = w.scan_part[blockIdx.x];                                   // (scanned: the blocks in front) + the waves in front of this one
+    for (int q = 0; q < (int)(threadIdx.x >> 6); q++) carry += w.scan_part[gridDim.x + blk - (threadIdx.x >> 6) + q];
     for (uint32_t k0 = 0; k0 < nl; k0 += 64) {                                  // (wave-uniform trips: the scan is a wave operation)
         const uint32_t kq = k0 + (uint32_t)lane;
         uint64_t v = 0, ic = 0; uint32_t h = 0;
