@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip -o libgencore_amd.so
 // No CPU fallback: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -493,6 +494,10 @@ static int read_si(gce_engine *e) {
 }
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+// A phase clock that is the STOP stamp of the phase's last kernel (an event attached to the dispatch itself) instead of a hipEventRecord behind it: the
+// record is a barrier packet of its own, 2.7 us between two kernels (tools/mb/event_gap.hip: 64 short kernels 456 us back to back, 632 us with a record
+// behind each, 459 us with attached stop events)
+#define LAUNCH_EV(kernel, grid, block, stream, ev, ...) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__)
 
 // Several byte fills in ONE launch (hipMemsetAsync is a launch of its own per buffer: a step had eleven).  Buffers start on 16-byte boundaries (hipMalloc).
 struct FillSeg { void *p; uint64_t bytes; uint32_t val; uint32_t pad; };
@@ -689,7 +694,7 @@ int gce_process(gce_engine *e) {
     HIPCHK(hipEventRecord(e->ev[EV_START], s));
     HIPCHK(hipMemsetAsync(e->out_flag.p, 0, n1, s));
     // ---- cluster formation (gce_cluster.hpp): the scan, then the leaders (ticks + flush events come with the batch for key-range shards)
-    if (N > 0) hipLaunchKernelGGL(k_cluster, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, b, p, w);
+    if (N > 0) LAUNCH_EV(k_cluster, dim3((unsigned)n_sblk), dim3(SB_T), s, e->ev[EV_CLUSTER], b, p, w);
 #ifdef CL_PROF
     if (N > 0) {
         StreamInfo hs; (void)hipStreamSynchronize(s); (void)hipMemcpy(&hs, e->si.p, sizeof hs, hipMemcpyDeviceToHost);
@@ -700,7 +705,7 @@ int gce_process(gce_engine *e) {
         fprintf(stderr, "\n");
     }
 #endif
-    HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
+    if (N <= 0) HIPCHK(hipEventRecord(e->ev[EV_CLUSTER], s));
     CANARY("EV_CLUSTER");
     if (N > 0) {
         if (!e->have_tick) {
@@ -712,9 +717,8 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_num_reduce, dim3(nb4), dim3(256), 0, s, w, p.nw_cb);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb4, &w.si->n_clusters, (unsigned long long *)nullptr);      // (one partial per k_num_reduce block)
         hipLaunchKernelGGL(k_num_apply, dim3(nb4), dim3(256), 0, s, w);
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), 0, s, N, w);
-    }
-    HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
+        LAUNCH_EV(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), s, e->ev[EV_CSR], N, w);
+    } else HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
     CANARY("EV_CSR");
     // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote
     if (N > 0) {
@@ -723,9 +727,8 @@ int gce_process(gce_engine *e) {
 #endif
         const int64_t n_tiles = (N + 255) / 256;
         int tpb = (int)((n_tiles + GCE_DESCRIBE_BLOCKS - 1) / GCE_DESCRIBE_BLOCKS); if (tpb < 1) tpb = 1;
-        hipLaunchKernelGGL(k_describe, dim3(cdiv(n_tiles, tpb)), dim3(256), 0, s, b, p, w, tpb);
-    }
-    HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
+        LAUNCH_EV(k_describe, dim3(cdiv(n_tiles, tpb)), dim3(256), s, e->ev[EV_DESCRIBE], b, p, w, tpb);
+    } else HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
     CANARY("EV_DESCRIBE");
     if ((rc = read_si(e)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
@@ -789,8 +792,7 @@ int gce_process(gce_engine *e) {
         hipLaunchKernelGGL(k_group_fill, dim3(cdiv(C, 256)), dim3(256), 0, s, w, C, p.skip_low_complexity_thr, (uint32_t)VB_W, (uint32_t)VB_MINW);
         hipLaunchKernelGGL(k_u64_reduce, dim3(nblk_N), dim3(256), 0, s, (const uint64_t *)w.gw, (const unsigned long long *)&w.si->n_groups, w.scan_part);
         hipLaunchKernelGGL(k_u64_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (const unsigned long long *)&w.si->n_groups, &w.si->vote_weight);
-        hipLaunchKernelGGL(k_vote_batches, dim3(nblk_N), dim3(256), 0, s, w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);
-        HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
+        LAUNCH_EV(k_vote_batches, dim3(nblk_N), dim3(256), s, e->ev[EV_PAIRING], w, (const unsigned long long *)&w.si->n_groups, (const uint64_t *)w.scan_part);
         CANARY("EV_PAIRING");
         if ((rc = read_si(e)) != GCE_OK) return rc;
         HIPCHK(hipGetLastError());
@@ -819,8 +821,7 @@ int gce_process(gce_engine *e) {
             return fail(e, GCE_ERR_INVALID, "experiment build");
         }
 #endif
-        hipLaunchKernelGGL(k_vote, dim3(nbatch), dim3(VB_T), 0, s, b, p, w, NG);
-        HIPCHK(hipEventRecord(e->ev[EV_SCORE], s));
+        LAUNCH_EV(k_vote, dim3(nbatch), dim3(VB_T), s, e->ev[EV_SCORE], b, p, w, NG);
         CANARY("EV_SCORE");
         // A stream of deep groups (mean depth beyond 24 pairs: the deep kernels carry the consensus phase, cfg5) runs Pair::computeScore for the
         // handed-on groups (k_score2: bandwidth) on a second HIP stream BESIDE the compaction, the hand-on of the deep sides and their template /
@@ -851,8 +852,7 @@ int gce_process(gce_engine *e) {
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
         }
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
-        hipLaunchKernelGGL(k_consensus_slow, dim3(512), dim3(256), 0, s, b, p, w);
-        HIPCHK(hipEventRecord(e->ev[EV_CONSENSUS], s));
+        LAUNCH_EV(k_consensus_slow, dim3(512), dim3(256), s, e->ev[EV_CONSENSUS], b, p, w);
         CANARY("EV_CONSENSUS");
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
         if (!p.disable_duplex) {                                                                  // duplex stage: flagged clusters, compacted, a wave each
