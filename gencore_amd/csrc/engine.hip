@@ -454,7 +454,10 @@ __global__ __launch_bounds__(256) void k_publish_si(const StreamInfo *si, Stream
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 static_assert(sizeof(StreamInfo) % 4 == 0, "k_publish_si copies words");
-static int read_si(gce_engine *e) {
+// In two halves: the first enqueues the publishing kernel, the second waits for its word -- work that does not need the answer can be enqueued in between
+// and keeps the GPU busy while the word travels (gce_process: k_describe behind the cluster count).
+static int read_si_begin(gce_engine *e, unsigned long long *seq_out) {
+    *seq_out = 0;
     static const bool sync_copy = getenv("GCE_SYNC_COPY") != nullptr;
     if (!sync_copy && !e->si_pin) {
         void *hp = nullptr;
@@ -465,14 +468,20 @@ static int read_si(gce_engine *e) {
         }
         (void)hipGetLastError();
     }
-    bool published = false;
     if (!sync_copy && e->si_pin) {
-        StreamInfo *hs = reinterpret_cast<StreamInfo *>(e->si_pin);
-        unsigned long long *hflag = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->si_pin) + ((sizeof(StreamInfo) + 7) & ~size_t(7)));
         unsigned long long *dflag = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->si_pin_dev) + ((sizeof(StreamInfo) + 7) & ~size_t(7)));
         const unsigned long long seq = ++e->si_seq;
         hipLaunchKernelGGL(k_publish_si, dim3(1), dim3(256), 0, e->stream, (const StreamInfo *)e->si.p, reinterpret_cast<StreamInfo *>(e->si_pin_dev), dflag, seq);
         HIPCHK(hipGetLastError());
+        *seq_out = seq;
+    }
+    return GCE_OK;
+}
+static int read_si_end(gce_engine *e, unsigned long long seq) {
+    bool published = false;
+    if (seq) {
+        StreamInfo *hs = reinterpret_cast<StreamInfo *>(e->si_pin);
+        unsigned long long *hflag = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(e->si_pin) + ((sizeof(StreamInfo) + 7) & ~size_t(7)));
         for (unsigned spins = 1;; spins++) {
             if (__atomic_load_n(hflag, __ATOMIC_ACQUIRE) == seq) { published = true; break; }
             if ((spins & 0x3FFF) == 0) {                                              // now and then: is the stream still alive?
@@ -491,6 +500,11 @@ static int read_si(gce_engine *e) {
     for (int k = 0; k < 6; k++) for (int q = 0; q < GCE_PRE_SLOTS; q++) { e->h_si.pre[k] += e->h_si.pre_slot[q][k]; e->h_si.post[k] += e->h_si.post_slot[q][k]; }    // k_describe's spread counters
     if (e->h_si.err_key != ~0ull) { e->dev_error = -(int)(e->h_si.err_key & 0xFF); e->dev_error_read = (uint32_t)(e->h_si.err_key >> 8); }
     return GCE_OK;
+}
+static int read_si(gce_engine *e) {
+    unsigned long long seq = 0;
+    const int rc = read_si_begin(e, &seq);
+    return rc != GCE_OK ? rc : read_si_end(e, seq);
 }
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -720,7 +734,11 @@ int gce_process(gce_engine *e) {
         LAUNCH_EV(k_scatter, dim3((unsigned)n_sblk), dim3(SB_T), s, e->ev[EV_CSR], N, w);
     } else HIPCHK(hipEventRecord(e->ev[EV_CSR], s));
     CANARY("EV_CSR");
-    // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote
+    // ---- per-read descriptors, UMI slices, pre-Stats: independent of the clusters, consumed by pairing and the vote.
+    // The host's look at the cluster count is asked for IN FRONT of it and awaited behind it: the word travels while k_describe runs (what k_describe adds to the
+    // block -- pre-Stats, read-length range, its errors -- is read by the later looks; the pairing kernels do not mind a read k_describe refused)
+    unsigned long long si_seq1 = 0;
+    if ((rc = read_si_begin(e, &si_seq1)) != GCE_OK) return rc;
     if (N > 0) {
 #ifndef GCE_DESCRIBE_BLOCKS
 #define GCE_DESCRIBE_BLOCKS 32768        // at most this many blocks: their Stats partial sums end in six global atomics each
@@ -730,7 +748,7 @@ int gce_process(gce_engine *e) {
         LAUNCH_EV(k_describe, dim3(cdiv(n_tiles, tpb)), dim3(256), s, e->ev[EV_DESCRIBE], b, p, w, tpb);
     } else HIPCHK(hipEventRecord(e->ev[EV_DESCRIBE], s));
     CANARY("EV_DESCRIBE");
-    if ((rc = read_si(e)) != GCE_OK) return rc;
+    if ((rc = read_si_end(e, si_seq1)) != GCE_OK) return rc;
     HIPCHK(hipGetLastError());
     e->tab_clean = true;                          // k_scatter ran to the end
     const uint32_t C = (uint32_t)e->h_si.n_clusters;
