@@ -854,20 +854,19 @@ int gce_process(gce_engine *e) {
         };
         if (deep_stream) {
             if ((rc = aux_ready(e)) != GCE_OK) return rc;
-            HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand
+            HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand, the deep sides are on slow_list
             HIPCHK(hipStreamWaitEvent(e->aux_stream, e->aux_ev[0], 0));
             hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, e->aux_stream, b, p, w, (uint32_t)N, 1);
             HIPCHK(hipEventRecord(e->aux_ev[1], e->aux_stream));
+            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (template + voter list of the deep sides: reads no score, no quality)
             compact_gen();
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 1);        // the deep sides -> slow_list
-            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
             HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));                                // the scores (and the rewritten qualities) stand
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 2);        // everything else on gen_list
         } else {
             hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
             compact_gen();
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 0);
-            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);
+            hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (before k_consensus_fast appends the sides IT cannot take: those are not deep)
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 2);
         }
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         LAUNCH_EV(k_consensus_slow, dim3(512), dim3(256), s, e->ev[EV_CONSENSUS], b, p, w);

@@ -1320,15 +1320,13 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane, int mode) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
+    // deep sides (> 64 pairs, or beyond the low-complexity threshold) are not this kernel's: k_vote put them on slow_list itself when it handed their
+    // group on (gce_vote.hpp, P0 -- the same test), so that k_deep_prepare can start behind k_vote instead of behind a pass of this kernel over gen_list
     const bool deep_side = !(np == 1 && w.gpr[begin] == NONE32) && (np > 64 || (int)np > p.skip_low_complexity_thr);
-    if (mode == 1 && !deep_side) return;
-    if (mode == 2 && deep_side) return;
+    (void)mode;
+    if (deep_side) return;
     if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
         if (lane == 0) rp_out[gi] = is_left ? w.gpl[begin] : NONE32;
-        return;
-    }
-    if (deep_side) {
-        if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow, 1u)] = gi * 2 + (is_left ? 0 : 1);
         return;
     }
     const uint32_t *side = is_left ? w.gpl : w.gpr;

@@ -224,6 +224,12 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
             const uint32_t gb = gb_;
             for (uint32_t k = 0; k < np; k++) w.slot_flag[gb + k] = 1;
+            // the DEEP sides (consensus_fast_side's test) go on slow_list here and now: k_deep_prepare starts right behind this kernel, beside k_score2
+            // (a pass of k_consensus_fast over gen_list just to find them was 0.38 ms of cfg5's critical path)
+            if ((np > 64u || (int)np > p.skip_low_complexity_thr) && !(np == 1u && w.gpr[gb] == NONE32)) {
+                const uint32_t at = atomicAdd(&w.si->n_slow, 2u);
+                w.slow_list[at] = 2u * gi; w.slow_list[at + 1] = 2u * gi + 1u;
+            }
         }
     }
     for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
