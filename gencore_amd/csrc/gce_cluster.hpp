@@ -111,6 +111,7 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
     __shared__ uint16_t s_num[SB_READS];
     __shared__ uint32_t s_wcnt[SB_U][SB_T / 64];
     __shared__ uint32_t s_nlead;
+    __shared__ uint32_t s_unm[SB_T / 64];                                                  // per wave: an unmapped read among its reads
     const int lane = lane_id(), wv = threadIdx.x >> 6;
 #ifdef CL_PROF
     unsigned long long t_prev_ = wall_clock64();
@@ -163,7 +164,15 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
     // an unmapped read in the block: the reads behind it belong to the stream's second segment (gencore.cpp:255-262 ran
     // finishConsensus in between) and must not merge with the ones in front -- such a block (the tail of a file, as a rule: no
     // clustered reads at all) does not aggregate, every read is its own leader and the bucket table sorts it out
-    const int any_unm = __syncthreads_or(unm);
+    // (every wave leaves its own word and the barrier the block needs anyway follows: __syncthreads_or is a work-group reduction with barriers of its own)
+    {
+        const unsigned long long um = __ballot(unm);
+        if (lane == 0) s_unm[wv] = um != 0ull;
+    }
+    __syncthreads();
+    int any_unm = 0;
+#pragma unroll
+    for (int q = 0; q < SB_T / 64; q++) any_unm |= (int)s_unm[q];
     CL_TICK(0);
     int leader[SB_U]; uint32_t lrank[SB_U];
 #pragma unroll

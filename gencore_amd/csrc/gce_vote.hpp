@@ -715,7 +715,9 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             }
         }
     }
-    (void)__syncthreads_or(any_restore);            // (every read of the originals above precedes every write below)
+    (void)any_restore;
+    __syncthreads();                                // (every read of the originals above precedes every write below; __syncthreads_or kept the packed work-item ids
+                                                    //  alive through the whole kernel for a result nobody looked at: one VGPR and, at 64, a spilled pair)
 #pragma unroll
     for (int kk = 0; kk < VB_IPL; kk++) {
         const int it = tid + VB_T * kk;
