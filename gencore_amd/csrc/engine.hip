@@ -511,7 +511,10 @@ static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b -
 // A phase clock that is the STOP stamp of the phase's last kernel (an event attached to the dispatch itself) instead of a hipEventRecord behind it: the
 // record is a barrier packet of its own, 2.7 us between two kernels (tools/mb/event_gap.hip: 64 short kernels 456 us back to back, 632 us with a record
 // behind each, 459 us with attached stop events)
-#define LAUNCH_EV(kernel, grid, block, stream, ev, ...) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__)
+static const bool g_record_events = getenv("GCE_RECORD_EVENTS") != nullptr;       // GCE_RECORD_EVENTS=1: plain launches with hipEventRecord behind them
+#define LAUNCH_EV(kernel, grid, block, stream, ev, ...) do { \
+    if (g_record_events) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); (void)hipEventRecord(ev, stream); } \
+    else hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, ev, 0, __VA_ARGS__); } while (0)
 
 // Several byte fills in ONE launch (hipMemsetAsync is a launch of its own per buffer: a step had eleven).  Buffers start on 16-byte boundaries (hipMalloc).
 struct FillSeg { void *p; uint64_t bytes; uint32_t val; uint32_t pad; };
