@@ -88,7 +88,7 @@ struct gce_engine {
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     void *si_pin = nullptr, *si_pin_dev = nullptr; unsigned long long si_seq = 0;      // read_si: the block in mapped host memory + its sequence word
     gce_timing timing{};
@@ -172,7 +172,7 @@ void gce_destroy(gce_engine *e) {
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
-    for (DevBuf *b : {&e->zo_slots, &e->zo_sizes, &e->zo_off, &e->zo_out}) b->release();
+    for (DevBuf *b : {&e->zo_slots, &e->zo_sizes, &e->zo_off, &e->zo_out, &e->p16_flag, &e->p16_list}) b->release();
     for (DevBuf *b : {&e->sh_tickall, &e->sh_shard, &e->sh_flag, &e->sh_sel, &e->sh_core, &e->sh_qoff, &e->sh_coff, &e->sh_soff, &e->sh_loff, &e->sh_nm, &e->sh_nmt, &e->sh_mioff, &e->sh_tick, &e->sh_roff, &e->sh_nmpos, &e->sh_keys, &e->sh_stage}) b->release();
     for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
@@ -765,9 +765,13 @@ int gce_process(gce_engine *e) {
         //  [g_begin, g_begin + g_np) of a group only, and the pairing kernels write both words of every one of those)
         // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
         // compacted by the scan kernels (never one shared append counter)
-        ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4);
-        w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>();
-        fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}, FillSeg{e->pq_flag.p, c1, 0u, 0u}});
+        ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4); ENS(p16_flag, c1 + 64); ENS(p16_list, c1 * 4);
+        w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>(); w.p16_flag = e->p16_flag.as<uint8_t>(); w.p16_list = e->p16_list.as<uint32_t>();
+        // size classes in front of the quarter-wave kernel (k_pair_classes) when a good share of the clusters is beyond it: mean cluster beyond 10 reads
+        // (cfg3: 16 reads, 45 % of the clusters beyond 16 -- pairing 1.41 -> 1.26 ms; cfg2: 7 reads, nearly none -- the class pass would be 16 us for nothing)
+        const bool pair_classes = (double)N > 10.0 * (double)C;
+        if (pair_classes) fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}});          // (pq_flag / p16_flag: every entry written by k_pair_classes)
+        else fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}, FillSeg{e->pq_flag.p, c1, 0u, 0u}});
         const unsigned nbc = cdiv(C, SCAN_TILE);
         auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
             hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
@@ -787,7 +791,11 @@ int gce_process(gce_engine *e) {
             return fail(e, GCE_ERR_INVALID, "experiment build");
         }
 #endif
-        hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
+        if (pair_classes) {
+            hipLaunchKernelGGL(k_pair_classes, dim3(cdiv(C, 256)), dim3(256), 0, s, (const uint32_t *)w.cl_n, C, w.p16_flag, w.pq_flag);
+            compact(w.p16_flag, w.p16_list, &w.si->n_p16_items);
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.p16_list, (const unsigned long long *)&w.si->n_p16_items, w.pq_flag);
+        } else hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
         compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
         hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
         compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);

@@ -77,6 +77,7 @@ struct StreamInfo {
     unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one
     unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
+    unsigned long long n_p16_items;      // clusters of <= 16 reads: the quarter-wave pairing kernel's list
     long long pre[GCE_STATS_WORDS];
     long long post[GCE_STATS_WORDS];
     long long post_slot[GCE_PRE_SLOTS][8];  // k_out_meta's six addRead counters of the emitted records, spread the same way

@@ -55,6 +55,7 @@ struct Work {
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint8_t *pf_flag; uint32_t *pf_list;      // clusters the half-wave pairing kernel hands to the full-wave one (same scheme)
     uint8_t *pq_flag; uint32_t *pq_list;      // ... and the quarter-wave kernel to the half-wave one
+    uint8_t *p16_flag; uint32_t *p16_list;    // clusters of <= 16 reads, compacted: the quarter-wave kernel runs on full waves (k_pair_classes)
     void *deep_list;                       // DeepRec[] (gce_deep.hpp)
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
                                           // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)

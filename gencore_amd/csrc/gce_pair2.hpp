@@ -26,6 +26,15 @@ template <int SUB> __device__ __forceinline__ uint32_t sub_ballot(bool pr, int h
 }
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64_t)__shfl((long long)v, src); }
 
+// Size classes in front of the pairing kernels: the quarter-wave kernel used to run over ALL clusters and flag the ones of more than 16 reads for the
+// next one -- 45 % of cfg3's clusters, a dead quarter of a wave each, in a kernel that executes the same instruction stream whatever share of its lanes
+// is alive.  Now it gets the compacted list of the clusters it can take; the others are flagged for the half-wave kernel here.
+__global__ __launch_bounds__(256) void k_pair_classes(const uint32_t *cl_n, uint32_t n_clusters, uint8_t *f16, uint8_t *fq) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_clusters) return;
+    const bool small = cl_n[c] <= 16u;
+    f16[c] = small ? 1 : 0; fq[c] = small ? 0 : 1;
+}
 // SUB = lanes per cluster (32: two clusters per wave, 16: four).  `list` != nullptr: the clusters a narrower instantiation flagged.
 #ifdef PS_STOP                        // cumulative cost of the phases (tools/pair_stop.sh): the kernel ends at tick PS_STOP
 #define PS_TICK(k, live_) do { if ((k) >= PS_STOP) { if ((uint32_t)(live_) == 0xDEADBEEFu) flag_out[0] = 1; return; } } while (0)      // (live_: what the phase computed -- keeps it from being optimised away)
