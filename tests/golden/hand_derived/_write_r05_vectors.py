@@ -1,0 +1,134 @@
+#!/usr/bin/env python
+"""Writes the round-5 hand-derived vectors (the three rules VERDICT r4 named as most likely to be "fixed" by accident).  A WRITING AID, not
+an oracle: every `expected` block, every `expected_stats` block and every derivation was worked out by hand from the cited reference
+lines; no oracle or engine run is involved."""
+import json, os
+HERE = os.path.dirname(os.path.abspath(__file__))
+Q = lambda q, n: [q] * n
+
+
+def rec(qname, flag, pos, cigar, mpos, isize, seq, qual, tid=0, mtid=0, nm=0, **kw):
+    return dict(qname=qname, flag=flag, tid=tid, pos=pos, cigar=cigar, mtid=mtid, mpos=mpos, isize=isize, seq=seq, qual=qual, nm=nm, **kw)
+
+
+def out(qname, flag, pos, cigar, seq, qual, nm, fr, rr=-1, tid=0):
+    return dict(qname=qname, flag=flag, tid=tid, pos=pos, cigar=cigar, seq=seq, qual=qual, nm=nm, fr=fr, rr=rr)
+
+
+def write(v):
+    with open(os.path.join(HERE, v["name"] + ".json"), "w") as f:
+        json.dump(v, f, indent=1)
+        f.write("\n")
+
+
+C0 = [dict(name="c0", length=100000)]
+L20 = "ACGTACGTACGTACGTACGT"          # = the contig below at 100..119
+R10 = "GTACGTACGTTTGCAAGCTT"          # a right read at 110: its first ten bases are L20[10:20]
+
+# ------------------------------------------------------------------------------------------------ 1: the absent bin is "second"
+la = L20[:12] + "C" + L20[13:]         # pair a's left read: C instead of A in column 12
+write(dict(
+    name="absent_bin_fast_accept_keeps_the_templates_minority_base",
+    cites=["src/pair.cpp:108-120", "src/pair.cpp:151-168", "src/pair.cpp:77-86", "src/group.cpp:381-392", "src/group.cpp:395-417", "src/group.cpp:421-428",
+           "src/group.cpp:196-261", "src/group.cpp:528"],
+    derivation=(
+        "One cluster (0, 100, 129), three pairs a, b, c, no UMI, no reference; every read 20M, left reads at 100, right reads at 110: "
+        "posDis = 10, left columns 10..19 lie on right columns 0..9 (pair.cpp:108-120).  Pairs b and c: the mates agree everywhere, qualities 37: "
+        "overlap positions score qual2score((37+37)/2) + 4 = 12 on both reads, the rest 8.  Pair a: the LEFT read shows C in column 12 (quality "
+        "37) where its mate shows A in column 2 (quality 30): a mismatch with lq >= rq, so lqual[12] = 37 - 30 = 7, rqual[2] = max(0, 30 - 37) = 0, "
+        "mLeftScore[12] = qual2score(7) - 3 = 2 - 3 = -1, mRightScore[2] = 0 (pair.cpp:151-168; 7 < lowQuality 15: 'bad' = 2).  LEFT side: the "
+        "three reads are identical in CIGAR and length, containedBy 3 each, the first in qname order (a) is the template and all vote.  Column "
+        "12: counts A 2 / C 1, baseScores A = 24, C = -1, every other bin 0 with quals 0.  Top (group.cpp:395-403): bin 0 first (0 > -inf), then A "
+        "(24): topBase A, topNum 2, topQual 37.  Second (:406-417, A skipped): bin 0 takes it with score 0; C's -1 is NOT greater than 0; every "
+        "later empty bin ties at 0 with quals 0 >= 0 and takes over: secBase ends at bin 15, secNum = counts[15] = 0 -- the real minority base "
+        "C lost 'second' to an ABSENT bin.  secNum == 0 and topScore 24 >= 6 and topQual 37 >= 20: outqual[12] = 37 and `continue` "
+        "(:421-428) -- the loop never reaches the code that writes topBase into the template: a keeps its C, now with the majority's "
+        "quality 37 instead of the rewritten 7.  Every other left column is unanimous with top quality 37.  mismatchInc 0: NM stays 1.  "
+        "RIGHT side: all at 110 -> left-read mode, template a.  Column 2: A three times, scores 0 + 12 + 12, qualities 0 / 37 / 37: secNum 0, "
+        "24 >= 6, topQual 37: quality 37 replaces the rewritten 0.  Both records leave with a's name and FR = 3."),
+    params={}, contigs=C0,
+    records=[rec("a", 99, 100, "20M", 110, 30, la, Q(37, 20), nm=1), rec("b", 99, 100, "20M", 110, 30, L20, Q(37, 20)), rec("c", 99, 100, "20M", 110, 30, L20, Q(37, 20)),
+             rec("a", 147, 110, "20M", 100, -30, R10, Q(37, 2) + [30] + Q(37, 17)), rec("b", 147, 110, "20M", 100, -30, R10, Q(37, 20)), rec("c", 147, 110, "20M", 100, -30, R10, Q(37, 20))],
+    expected_status=0,
+    expected=[out("a", 99, 100, "20M", la, Q(37, 20), 1, 3), out("a", 147, 110, "20M", R10, Q(37, 20), 0, 3)]))
+
+# ------------------------------------------------------------------------------------------------ 2: an unmapped read in mid-stream
+LA, RA = "ACGTTGCAAGCTTCGATGCA", "TTGCAAGCTTCGATGCAAGC"
+U = lambda n, u: "%s:UMI_%s" % (n, u)
+
+
+def pair_recs(n1, u1, n2, u2, lp, rp):
+    return [rec(U(n1, u1), 99, lp, "20M", rp, rp + 20 - lp, LA, Q(37, 20)), rec(U(n2, u2), 99, lp, "20M", rp, rp + 20 - lp, LA, Q(37, 20)),
+            rec(U(n1, u1), 147, rp, "20M", lp, -(rp + 20 - lp), RA, Q(37, 20)), rec(U(n2, u2), 147, rp, "20M", lp, -(rp + 20 - lp), RA, Q(37, 20))]
+
+
+recs2 = (pair_recs("a", "AAAAAAAA", "b", "AAAAAAAT", 100, 400)
+         + [dict(qname="u", flag=4, tid=-1, pos=-1, cigar="*", mtid=-1, mpos=-1, isize=0, seq=LA, qual=Q(37, 20), nm=None)]
+         + pair_recs("c", "CCCCCCCC", "d", "CCCCCCCG", 500, 800)
+         + pair_recs("e", "GGGGGGGG", "f", "GGGGGGGT", 900, 1200)
+         + [rec("m", 73, 1300, "20M", -1, 0, LA, Q(37, 20), mtid=-1)])
+write(dict(
+    name="unmapped_read_in_mid_stream_is_the_only_finish",
+    cites=["src/gencore.cpp:233-241", "src/gencore.cpp:255-266", "src/gencore.cpp:276-279", "src/gencore.cpp:295-322", "src/gencore.cpp:333-354", "src/gencore.cpp:409",
+           "src/gencore.cpp:21-22", "src/cluster.cpp:55-102", "src/cluster.cpp:172-186", "src/stats.cpp:101-139", "src/gencore.cpp:145-146"],
+    derivation=(
+        "UMI prefix 'UMI', flush period 5 (the literal 10000 of gencore.cpp:321).  Records 0-3: pairs a (UMI AAAAAAAA) and b (AAAAAAAT), left reads at 100, "
+        "right reads at 400: one cluster (0, 100, 419), ticks 1-4.  Record 4: an UNMAPPED read (tid -1, pos -1): the sortedness test skips it "
+        "(:233-241), mPreStats counts it (unmapped), and since the output set was never cleared, finishConsensus runs NOW (:255-262) -- the only "
+        "time in this run: mProperClustersFinished becomes true and the call at end of file (:276-279) is skipped.  finishConsensus uses "
+        "unproperReadsUmiDiffThreshold = 0 (:409): the two UMIs differ in one base and stay TWO groups of one pair (under the periodic flush's "
+        "threshold 1 they would merge into one consensus with FR 2): a and b leave untouched, FR 1 each; preStats addCluster(multi) + 2 x "
+        "addMolecule(1, PE), postStats 2 x SSCS + addCluster(multi) + 2 x addMolecule(1, PE) (outputPair).  The unmapped read itself is not written "
+        "(the writeBam at :264 is commented out).  Records 5-8: pairs c (CCCCCCCC) and d (CCCCCCCG) at 500 / 800: a NEW entry in mProperClusters, "
+        "ticks 5-8; tick 5 fires a walk with pos 500: the cluster's left 500 >= 500 stops it.  Records 9-12: pairs e, f at 900 / 1200, ticks 9-12; "
+        "tick 10 (f's left read) fires the walk with pos 900: cluster (500, 819) has left < 900 and right < 900 and is taken with "
+        "properReadsUmiDiffThreshold = 1 (:355): c and d merge into ONE group, template c (first qname), identical reads: unchanged, FR 2 -- the "
+        "periodic flush is alive behind the unmapped read.  Cluster (900, 1219) stays (left 900 >= 900); no further tick is a multiple of 5, and "
+        "at end of file nothing finishes it: e and f are counted by mPreStats->addRead and by nothing else -- never clustered in the Stats, never "
+        "emitted.  Record 13: a mate-unmapped read (mtid -1) goes straight to outputBam (:307-309), no tick, and leaves when ~Gencore drains the "
+        "output set (:21-22): emitted untouched, without FR tag.  Stats: pre reads 14 x 20 bases, 1 unmapped; clusters 2 (1 multi-molecule); "
+        "molecules 2 x (1 read) + 1 x (2 reads), all PE.  post: 7 records written; clusters 2 (1 multi); 3 SSCS; outputPair counts 3 molecules of 1."),
+    params=dict(umi_prefix="UMI", flush_period=5), contigs=C0, records=recs2,
+    expected_status=0,
+    expected=[out(U("a", "AAAAAAAA"), 99, 100, "20M", LA, Q(37, 20), 0, 1), out(U("a", "AAAAAAAA"), 147, 400, "20M", RA, Q(37, 20), 0, 1),
+              out(U("b", "AAAAAAAT"), 99, 100, "20M", LA, Q(37, 20), 0, 1), out(U("b", "AAAAAAAT"), 147, 400, "20M", RA, Q(37, 20), 0, 1),
+              out(U("c", "CCCCCCCC"), 99, 500, "20M", LA, Q(37, 20), 0, 2), out(U("c", "CCCCCCCC"), 147, 800, "20M", RA, Q(37, 20), 0, 2),
+              out("m", 73, 1300, "20M", LA, Q(37, 20), 0, -1)],
+    expected_stats=dict(
+        pre=dict(reads=14, bases=280, reads_unmapped=1, bases_unmapped=20, base_mismatches=0, reads_with_mismatches=0, clusters=2, multi_molecule_clusters=1,
+                 molecules=3, molecules_se=0, molecules_pe=3, sscs=0, dcs=0, supporting_hist={"1": 2, "2": 1}),
+        post=dict(reads=7, bases=140, reads_unmapped=0, bases_unmapped=0, clusters=2, multi_molecule_clusters=1, molecules=3, molecules_se=0, molecules_pe=3,
+                  sscs=3, dcs=0, supporting_hist={"1": 3}))))
+
+# ------------------------------------------------------------------------------------------------ 3: the restore keeps the rescored quality
+ALT = "CATGCA" + L20[6:]               # b, c, d: another base than the reference in columns 0..5
+RR = "GTACGTACGTACGTACGTAC"            # = the contig at 110..129
+ra = RR[:5] + "A" + RR[6:]             # pair a's right read: A instead of T in column 5 (position 115)
+write(dict(
+    name="q7_restore_keeps_the_overlap_rescored_quality",
+    cites=["src/group.cpp:327-333", "src/group.cpp:362-367", "src/group.cpp:442-467", "src/group.cpp:503-526", "src/group.cpp:528-573", "src/pair.cpp:108-120", "src/pair.cpp:140-168",
+           "src/pair.cpp:77-86", "src/reference.cpp:33-70"],
+    derivation=(
+        "Contig c0 = ACGT x 25000 is the reference.  One cluster (0, 100, 129), four pairs a-d, 20M everywhere, left reads at 100, right reads at "
+        "110 (left columns 10..19 on right columns 0..9).  a's left read equals the reference, qualities 30; b, c, d show CATGCA in columns 0..5 "
+        "where the reference has ACGTAC, qualities 37.  a's right read shows A (quality 12) in column 5 = position 115 where its mate's column 15 "
+        "shows T (quality 30): computeScore (which runs for every pair BEFORE consensusMergeBam) rewrites lqual[15] = 30 - 12 = 18 and rqual[5] = "
+        "max(0, 12 - 30) = 0, mLeftScore[15] = qual2score(18) - 3 = 4 - 3 = 1, mRightScore[5] = 0 (pair.cpp:151-168).  LEFT side: identical CIGARs "
+        "and lengths: template a (first qname), four voters; makeConsensus backs the template up AFTER the rewrite (group.cpp:327-333: qualBak[15] "
+        "= 18).  Columns 0..5: reference base 1 vote (score 8, quality 30), other base 3 votes (24, top quality 37): top = other base, topNum 3; "
+        "second = a's base, secNum 1, quals 30 > lowQuality: 'high quality secondary', but topNum 3 and topQual 37 >= 30: no reference check; 24 "
+        ">= 6: the template's base is overwritten, and since it WAS the reference base mismatchInc++ (:516-517): six columns, mismatchInc = 6.  "
+        "Columns 6..19 are unanimous (column 15: scores 1 + 12 + 12 + 12): quality 37 is written.  mismatchInc 6 > 5: seq and qual are copied "
+        "back from the backup (:546-547): the bases are the reference's again, the qualities are 30 -- except column 15, which keeps the "
+        "RESCORED 18, not the 30 the read came with (quirk Q7).  NM is not touched on this branch.  RIGHT side: all at 110: left-read mode, "
+        "template a.  Column 5: A once (score 0, quality 0 -- the rewritten one), T three times (12 each, 37): top T (36).  Second: bin 0 takes it "
+        "with score 0, A ties at 0 with quals 0 >= 0 and takes over -- and so does every later bin but T, all of them empty: secBase ends at 15, "
+        "secNum 0 (the absent-bin rule again, this time through a score of exactly 0): 36 >= 6 and topQual 37 >= 20: quality 37 and `continue`: "
+        "a's right read KEEPS its A, mismatchInc stays 0, NM stays 1.  The other columns are unanimous, quality 37.  FR = 4 on both."),
+    params={}, contigs=[dict(name="c0", length=100000, sequence=dict(repeat="ACGT", times=25000))],
+    records=[rec("a", 99, 100, "20M", 110, 30, L20, Q(30, 20)), rec("b", 99, 100, "20M", 110, 30, ALT, Q(37, 20), nm=6), rec("c", 99, 100, "20M", 110, 30, ALT, Q(37, 20), nm=6),
+             rec("d", 99, 100, "20M", 110, 30, ALT, Q(37, 20), nm=6),
+             rec("a", 147, 110, "20M", 100, -30, ra, Q(37, 5) + [12] + Q(37, 14), nm=1), rec("b", 147, 110, "20M", 100, -30, RR, Q(37, 20)), rec("c", 147, 110, "20M", 100, -30, RR, Q(37, 20)),
+             rec("d", 147, 110, "20M", 100, -30, RR, Q(37, 20))],
+    expected_status=0,
+    expected=[out("a", 99, 100, "20M", L20, Q(30, 15) + [18] + Q(30, 4), 0, 4), out("a", 147, 110, "20M", ra, Q(37, 20), 1, 4)]))

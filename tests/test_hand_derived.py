@@ -55,6 +55,12 @@ def check(v, rt, batch):
     assert len(got) == len(want), (len(got), len(want), got)
     for g, w in zip(got, want):
         assert g == w, "%s\n got  %s\n want %s" % (v["name"], g, w)
+    # optional: hand-derived words of the two Stats blocks (src/stats.h:47-65; gce_stats in include/gencore_amd.h)
+    for blk in ("pre", "post"):
+        got_s = getattr(rt, blk).as_dict()
+        for k, want_v in v.get("expected_stats", {}).get(blk, {}).items():
+            got_v = {str(i): x for i, x in enumerate(got_s[k]) if x} if k == "supporting_hist" else got_s[k]
+            assert got_v == want_v, "%s %s.%s: got %s want %s" % (v["name"], blk, k, got_v, want_v)
 
 
 def oracle_reference(contigs):
@@ -72,7 +78,7 @@ def test_oracle_matches_hand_derivation(oracle, name):
 
 
 def test_vectors_present():
-    assert len(CASES) >= 27
+    assert len(CASES) >= 30
 
 
 @pytest.mark.gpu
