@@ -1801,11 +1801,18 @@ int gce_run_bam_sharded_hostcodec(const char *in_path, const char *out_path, con
     parallel_for(T, n, [&](int, int64_t a, int64_t e) { for (int64_t k = a; k < e; k++) memcpy(&cores[k], u + f->rec[k] + 4, 32); });
     int32_t n_ev = 0;
     const int period = prm.flush_period > 0 ? prm.flush_period : 10000;
-    if ((rc = gce_stream_context(devices[0], cores.data(), n, period, tick.data(), &n_ev, &ev_tid, &ev_pos)) != GCE_OK)
-        return done(rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
-    if ((rc = gce_plan_shards(devices[0], cores.data(), n, n_shards, plan_mode, shard.data())) != GCE_OK) return done(rc, gce_status_message(rc));
+    // --quit_after_contig (gencore.cpp:243-246): ONE cut on the whole stream, in front of the plan; the cut read goes to shard 0 behind its own reads (that
+    // engine counts it and drops it), the other engines do not look for a cut (see gce_raw_select_shard)
+    int64_t n_plan = n, cut = -1;
+    if (prm.max_contig > 0) for (int64_t k = 0; k < n; k++) if (cores[k].tid >= prm.max_contig) { cut = k; n_plan = k; break; }
+    if (n_plan > 0) {
+        if ((rc = gce_stream_context(devices[0], cores.data(), n_plan, period, tick.data(), &n_ev, &ev_tid, &ev_pos)) != GCE_OK)
+            return done(rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
+        if ((rc = gce_plan_shards(devices[0], cores.data(), n_plan, n_shards, plan_mode, shard.data())) != GCE_OK) return done(rc, gce_status_message(rc));
+    }
     std::vector<std::vector<int64_t>> idx((size_t)n_shards);
-    { std::vector<int64_t> cnt((size_t)n_shards, 0); for (int64_t k = 0; k < n; k++) cnt[shard[k]]++; for (int r = 0; r < n_shards; r++) idx[r].reserve((size_t)cnt[r]); for (int64_t k = 0; k < n; k++) idx[shard[k]].push_back(k); }
+    { std::vector<int64_t> cnt((size_t)n_shards, 0); for (int64_t k = 0; k < n_plan; k++) cnt[shard[k]]++; for (int r = 0; r < n_shards; r++) idx[r].reserve((size_t)cnt[r] + 1); for (int64_t k = 0; k < n_plan; k++) idx[shard[k]].push_back(k); }
+    if (cut >= 0) { idx[0].push_back(cut); tick[cut] = 0; }
     if (fasta_path && *fasta_path && (rc = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) return done(rc, "cannot read the FASTA file");
     int32_t nc = 0; const char *const *ids = nullptr; const char *const *seqs = nullptr; const int64_t *lens = nullptr;
     if (fa) gce_fasta_get(fa, &nc, &ids, &seqs, &lens);
@@ -1825,6 +1832,7 @@ int gce_run_bam_sharded_hostcodec(const char *in_path, const char *out_path, con
         const int64_t cnt = (int64_t)idx[r].size();
         memset(&res[r], 0, sizeof res[r]);
         gce_params pr = prm; pr.device = devices[r];
+        if (r != 0 || cut < 0) pr.max_contig = 0;                                // (the cut is made above, once)
         int c2;
         if ((c2 = gce_create(&pr, &eng[r])) != GCE_OK) return failr(c2, gce_status_message(c2));
         if (cnt == 0) return;

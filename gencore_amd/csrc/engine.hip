@@ -85,6 +85,7 @@ struct gce_engine {
     DevBuf zo_slots, zo_sizes, zo_off, zo_out; uint64_t zo_bytes = 0;            // the output stream as BGZF blocks (gce_raw_deflate_output)
     std::vector<gce_engine *> mirrors;
     DevBuf sh_tickall, sh_shard, sh_flag, sh_sel, sh_core, sh_qoff, sh_coff, sh_soff, sh_loff, sh_nm, sh_nmt, sh_mioff, sh_tick, sh_roff, sh_nmpos, sh_keys, sh_stage; int64_t shard_n = -1;
+    bool shard_cut_done = false;          // gce_raw_select_shard applied --quit_after_contig to the WHOLE stream: this engine's gce_process does not look for the cut again
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
@@ -249,7 +250,7 @@ int gce_reset(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
     e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear(); e->h_tick.clear();
     e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
-    e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = e->raw_mode = false; e->n = 0; e->n_out = 0;
+    e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = e->raw_mode = false; e->n = 0; e->n_out = 0; e->shard_n = -1; e->shard_cut_done = false;
     e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = 0;                     // a reservation (gce_reserve) stays
     return GCE_OK;
 }
@@ -565,7 +566,7 @@ int gce_process(gce_engine *e) {
     int64_t N = hb.n_reads;
     PreExtra pre_extra{};
     e->n_pre = N;
-    if (e->prm.max_contig > 0 && N > 0) {                                          // src/gencore.cpp:243-246: the loop ends on the first read of contig >= maxContig
+    if (e->prm.max_contig > 0 && N > 0 && !e->shard_cut_done) {                    // src/gencore.cpp:243-246: the loop ends on the first read of contig >= maxContig
         HIPCHK(e->si.ensure(sizeof(StreamInfo)));
         unsigned int first = NONE32;
         HIPCHK(hipMemcpyAsync(e->si.p, &first, 4, hipMemcpyHostToDevice, e->stream));
@@ -872,12 +873,12 @@ int gce_process(gce_engine *e) {
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (template + voter list of the deep sides: reads no score, no quality)
             compact_gen();
             HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));                                // the scores (and the rewritten qualities) stand
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 2);        // everything else on gen_list
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);           // everything else on gen_list
         } else {
             hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
             compact_gen();
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (before k_consensus_fast appends the sides IT cannot take: those are not deep)
-            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w, 2);
+            hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);
         }
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
         LAUNCH_EV(k_consensus_slow, dim3(512), dim3(256), s, e->ev[EV_CONSENSUS], b, p, w);

@@ -653,6 +653,9 @@ int gce_raw_read_output_async(gce_engine *e, uint64_t offset, void *host, size_t
 // ---- several engines over ONE file (gce_run_bam_sharded): the mirrors of an engine receive every gce_raw_push / gce_raw_push_bgzf made to it
 int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror) {
     if (!e || !mirror || e == mirror || !e->raw_mode || !mirror->raw_mode || e->raw_n != mirror->raw_n) return GCE_ERR_INVALID;
+    // gce_submit_wait waits on the SAME ticket number of every mirror: the two engines must have handed out the same tickets so far, and neither
+    // may hold BGZF members the other never saw (an attach behind an earlier push made the wait land on the wrong event)
+    if (e->up_events.size() != mirror->up_events.size() || !e->z_members.empty() || !mirror->z_members.empty()) return fail(e, GCE_ERR_INVALID, "gce_raw_attach_mirror: attach before the first push to either engine");
     e->mirrors.push_back(mirror);
     return GCE_OK;
 }
@@ -664,22 +667,44 @@ int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror) {
 int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode) {
     if (!e || !e->raw_mode || !e->device_mode || e->processed || world < 1 || rank < 0 || rank >= world) return GCE_ERR_INVALID;
     (void)hipSetDevice(e->prm.device);
-    const int64_t n = e->raw_records;
+    int64_t n = e->raw_records;
     hipStream_t s = e->stream;
     e->shard_n = 0;
     if (n == 0) { e->have_tick = false; return GCE_OK; }
-    HIPCHK(e->sh_tickall.ensure((size_t)n * 8)); HIPCHK(e->sh_shard.ensure((size_t)n * 4)); HIPCHK(e->sh_flag.ensure((size_t)n + 64)); HIPCHK(e->sh_sel.ensure((size_t)n * 4 + 64));
-    int32_t n_ev = 0, *ev_tid = nullptr, *ev_pos = nullptr;
-    const int period = e->prm.flush_period > 0 ? e->prm.flush_period : 10000;
-    int rc = gce_stream_context(e->prm.device, e->b_core.as<gce_core>(), n, period, e->sh_tickall.as<uint64_t>(), &n_ev, &ev_tid, &ev_pos);
-    if (rc != GCE_OK) return fail(e, rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
-    rc = gce_set_flush_events(e, n_ev, ev_tid, ev_pos);
-    gce_free(ev_tid); gce_free(ev_pos);
-    if (rc != GCE_OK) return rc;
-    if ((rc = gce_plan_shards(e->prm.device, e->b_core.as<gce_core>(), n, world, plan_mode, e->sh_shard.as<int32_t>())) != GCE_OK) return fail(e, rc, gce_status_message(rc));
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_shard_flag, dim3(nb), dim3(256), 0, s, (const int32_t *)e->sh_shard.p, n, rank, e->sh_flag.as<uint8_t>());
-    HIPCHK(dev_select_flagged(e->sh_flag.as<uint8_t>(), (uint64_t)n, e->sh_sel.as<uint32_t>(), (unsigned long long *)e->rw_misc.p, e->rw_tmp, s));
+    const int64_t n_all = n;
+    // --quit_after_contig (gencore.cpp:243-246) ends the loop ONCE, on the first read of the whole stream with tid >= maxContig: that read is
+    // counted by the pre-Stats and nothing behind it exists.  The cut is made here, on the whole stream, in front of the plan: shard 0 receives
+    // the cut read behind its own reads and counts it (its gce_process finds the cut there), the other engines do not look for a cut at all --
+    // every shard cutting its own part counted one extra read per shard that held a read of the later contigs.
+    int64_t cut = -1;
+    e->shard_cut_done = false;
+    if (e->prm.max_contig > 0) {
+        unsigned int first = NONE32;
+        HIPCHK(hipMemcpyAsync(e->rw_misc.p, &first, 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_first_contig_ge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const gce_core *)e->b_core.as<gce_core>(), n, e->prm.max_contig, (unsigned int *)e->rw_misc.p);
+        HIPCHK(hipMemcpyAsync(&first, e->rw_misc.p, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+        if (first != NONE32) { cut = (int64_t)first; n = cut; }
+        e->shard_cut_done = rank != 0 || cut < 0;
+    }
+    HIPCHK(e->sh_tickall.ensure((size_t)n_all * 8)); HIPCHK(e->sh_shard.ensure((size_t)n_all * 4)); HIPCHK(e->sh_flag.ensure((size_t)n_all + 64)); HIPCHK(e->sh_sel.ensure((size_t)n_all * 4 + 64));
+    int rc;
+    if (n > 0) {
+        int32_t n_ev = 0, *ev_tid = nullptr, *ev_pos = nullptr;
+        const int period = e->prm.flush_period > 0 ? e->prm.flush_period : 10000;
+        rc = gce_stream_context(e->prm.device, e->b_core.as<gce_core>(), n, period, e->sh_tickall.as<uint64_t>(), &n_ev, &ev_tid, &ev_pos);
+        if (rc != GCE_OK) return fail(e, rc, rc == GCE_ERR_INVALID ? "not shardable by cluster key: a mapped read follows the first unmapped read" : gce_status_message(rc));
+        rc = gce_set_flush_events(e, n_ev, ev_tid, ev_pos);
+        gce_free(ev_tid); gce_free(ev_pos);
+        if (rc != GCE_OK) return rc;
+        if ((rc = gce_plan_shards(e->prm.device, e->b_core.as<gce_core>(), n, world, plan_mode, e->sh_shard.as<int32_t>())) != GCE_OK) return fail(e, rc, gce_status_message(rc));
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_shard_flag, dim3(nb), dim3(256), 0, s, (const int32_t *)e->sh_shard.p, n, rank, e->sh_flag.as<uint8_t>());
+    } else if ((rc = gce_set_flush_events(e, 0, nullptr, nullptr)) != GCE_OK) return rc;
+    if (cut >= 0) {                                                                  // the cut read: shard 0's last read (its tick is never looked at: gce_process drops it)
+        HIPCHK(hipMemsetAsync(e->sh_flag.as<uint8_t>() + cut, rank == 0 ? 1 : 0, 1, s));
+        HIPCHK(hipMemsetAsync(e->sh_tickall.as<uint64_t>() + cut, 0, 8, s));
+    }
+    HIPCHK(dev_select_flagged(e->sh_flag.as<uint8_t>(), (uint64_t)(n + (cut >= 0 ? 1 : 0)), e->sh_sel.as<uint32_t>(), (unsigned long long *)e->rw_misc.p, e->rw_tmp, s));
     int64_t m = 0;
     HIPCHK(hipMemcpyAsync(&m, e->rw_misc.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
     const size_t m1 = (size_t)(m > 0 ? m : 1);

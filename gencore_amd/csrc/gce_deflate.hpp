@@ -16,6 +16,8 @@
 
 #define DEF_T 32
 #define DEF_HBITS 11
+// the hash table is sized for gfx950's 160 KB of LDS per CU (one 32-lane workgroup per CU holds 136 KB of it): this library is built for gfx950 only
+static_assert((size_t)(1u << DEF_HBITS) * DEF_T * 2 + 8 * 256 * 4 <= 160u * 1024u, "k_bgzf_deflate: hash table + CRC tables must fit gfx950's 160 KB of LDS");
 namespace {
 typedef uint32_t def_u32u __attribute__((aligned(1)));
 typedef uint64_t def_u64u __attribute__((aligned(1)));

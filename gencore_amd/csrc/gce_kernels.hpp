@@ -521,7 +521,10 @@ __global__ void k_group_fill(Work w, uint32_t n_clusters, int skip_thr, uint32_t
         const uint32_t np = w.grp_n[cs + g];
         w.gl_cluster[g0 + g] = c; w.g_begin[g0 + g] = w.grp_begin[cs + g]; w.g_np[g0 + g] = np;
         // k_vote batches (gce_vote.hpp): a group weighs its pairs (at least VB_MINW: <= 16 groups per batch); a deep group is handed on by a batch of its own
-        w.gw[g0 + g] = (np > 32u || (int)np > skip_thr) ? (uint64_t)deep_weight : (uint64_t)(np < min_weight ? min_weight : np);
+        // (only a group of more than 32 pairs: P0's slot-flag loop is serial in its pairs.  A group that is "deep" by a small --skip_low_complexity
+        //  threshold alone is handed on from a shared batch: with a batch of its own for every 2-pair group the batch count left the bound vb_start is sized by)
+        (void)skip_thr;
+        w.gw[g0 + g] = np > 32u ? (uint64_t)deep_weight : (uint64_t)(np < min_weight ? min_weight : np);
     }
 }
 // scan of cl_ngroups -> cl_gbase : same 3-phase scheme on the plain counts
@@ -1316,15 +1319,12 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 // One wave per (group, side): Group::consensusMergeBam + makeConsensus for groups of <= 64 pairs with register-resident
 // pair metadata and register tallies.  Anything else is appended to slow_list for k_consensus_slow.
 // This is the kernel behind the group kernel (gce_vote.hpp): it takes the group sides that one flags (gen_flag -> gen_list).
-// mode 0: everything; mode 1: only the hand-on of the deep sides (needs no scores: it runs, with k_deep_prepare behind it, beside k_score2 on a
-// second stream when the stream is a deep one); mode 2: everything but the deep sides (they were handed on by a mode-1 launch)
-__device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane, int mode) {
+__device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const Work &w, uint32_t gi, bool is_left, uint8_t *s_res_wave, int lane) {
     const uint32_t begin = w.g_begin[gi], np = w.g_np[gi];
     uint32_t *rp_out = is_left ? w.rp_left : w.rp_right;
     // deep sides (> 64 pairs, or beyond the low-complexity threshold) are not this kernel's: k_vote put them on slow_list itself when it handed their
     // group on (gce_vote.hpp, P0 -- the same test), so that k_deep_prepare can start behind k_vote instead of behind a pass of this kernel over gen_list
     const bool deep_side = !(np == 1 && w.gpr[begin] == NONE32) && (np > 64 || (int)np > p.skip_low_complexity_thr);
-    (void)mode;
     if (deep_side) return;
     if (np == 1 && w.gpr[begin] == NONE32) {                                  // group.cpp:73-77: returned untouched
         if (lane == 0) rp_out[gi] = is_left ? w.gpl[begin] : NONE32;
@@ -1641,7 +1641,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
 }
 
 // global-memory consensus, one wave per (group, side): the sides on gen_list (grid-stride, count read on the device)
-__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w, int mode) {
+__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     // the count only exists on the device: a capped grid strides over the list (a wave takes one or two entries when the list is
@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams
     const uint32_t n = (uint32_t)w.si->n_gen_items;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t e = w.gen_list[idx];
-        consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane, mode);
+        consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);
         WAVE_SYNC();
     }
 }

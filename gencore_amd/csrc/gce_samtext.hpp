@@ -94,10 +94,10 @@ template <class V> inline bool line_to_bam(const char *s, const char *e, const N
     if (lq < 1 || lq > 254) { msg = "SAM line with a bad QNAME"; return false; }
     auto lookup = [&](const char *a, const char *z) -> int32_t { if (z - a == 1 && *a == '*') return -1; auto it = nm.m.find(std::string(a, z)); return it == nm.m.end() ? -1 : it->second; };   // (an unknown name: unmapped, as htslib treats it)
     int32_t tid = lookup(fb(2), fe(2));
-    const int32_t mtid = (fe(6) - fb(6) == 1 && *fb(6) == '=') ? tid : lookup(fb(6), fe(6));
     // htslib's sam_parse1: "mapped query cannot have zero coordinate; treated as unmapped" (tid = -1), and a read without a contig carries BAM_FUNMAP
     if (pos == 0 && tid >= 0) tid = -1;
     if (tid < 0) flag |= 4;
+    const int32_t mtid = (fe(6) - fb(6) == 1 && *fb(6) == '=') ? tid : lookup(fb(6), fe(6));      // (RNEXT is parsed behind POS there: '=' copies the tid as it stands AFTER that reset)
     // CIGAR
     const size_t base = out.size();
     uint32_t zero = 0; put_le(out, zero);                                              // block_size, patched at the end

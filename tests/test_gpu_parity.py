@@ -515,6 +515,42 @@ def test_sharded_bam_run_equals_the_single_engine(built, tmp_path, monkeypatch, 
         assert a == b
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hostcodec", [False, True])
+@pytest.mark.parametrize("max_contig,shards,mode", [(5, 3, 0), (4, 4, 1), (1, 2, 0)])
+def test_sharded_bam_run_with_quit_after_contig(built, tmp_path, monkeypatch, max_contig, shards, mode, hostcodec):
+    """--quit_after_contig (gce_params.max_contig, src/gencore.cpp:243-246) ends the loop ONCE: the first read of the whole stream with tid >= maxContig
+    is counted by the pre-Stats, nothing behind it exists.  The sharded runners make that cut on the whole stream in front of the plan (every
+    shard cutting its own part counted one extra read per shard that held a read of the later contigs): same records, same order, same Stats as
+    gce_run_bam.  max_contig 1: only reads of the first contig are left, the plan gives most shards nothing."""
+    import pybam
+    from gencore_amd import synth
+    from gencore_amd.bamio import run_bam, run_bam_sharded
+    from gencore_amd.capi import default_params
+    from test_bamio import records_of
+    d = synth.generate("cfg3", n_pairs=30000)
+    batch = d.to_batch()
+    tl = np.asarray(d.target_len, np.uint32)
+    targets = [("chr%d" % (i + 1), int(l)) for i, l in enumerate(tl)]
+    src, one, many = (str(tmp_path / x) for x in ("in.bam", "one.bam", "many.bam"))
+    pybam.write_bam(src, records_of(batch), targets)
+    prm = default_params(umi_prefix="auto", cluster_size_req=d.info["supporting_reads"], flush_period=1500, max_contig=max_contig)
+    r1 = run_bam(src, one, prm, threads=4)
+    n_front = int((batch.core["tid"][batch.core["tid"] >= 0] < max_contig).sum())
+    assert int(r1.pre.reads) == n_front + 1                                  # the cut read is counted, once
+    if hostcodec:
+        monkeypatch.setenv("GCE_BAM_HOSTCODEC", "1")
+    r2 = run_bam_sharded(src, many, prm, [0] * shards, plan_mode=mode, threads=4)
+    monkeypatch.delenv("GCE_BAM_HOSTCODEC", raising=False)
+    assert (r1.n_reads, r1.n_out) == (r2.n_reads, r2.n_out) and r1.n_out > 0
+    assert bytes(r1.pre) == bytes(r2.pre) and bytes(r1.post) == bytes(r2.post)
+    _, t1, g1 = pybam.read_bam(one)
+    _, t2, g2 = pybam.read_bam(many)
+    assert t1 == t2 and len(g1) == len(g2)
+    for a, b in zip(g1, g2):
+        assert a == b
+
+
 def test_stats_blocks_in_device_memory_equal_the_drained_ones(built):
     """gce_stats_device: the two Stats blocks as they lie in HBM (what a multi-GPU run all-reduces, bench.py) are the ones gce_drain returns."""
     import ctypes as C

@@ -148,6 +148,8 @@ def test_sam_lines_htslib_treats_as_unmapped(built, tmp_path):
     bamio.sam_to_bam(sam, bam, threads=1)
     _, _, got = pybam.read_bam(bam)
     assert (got[0]["tid"], got[0]["pos"], got[0]["flag"]) == (-1, -1, 103)
+    assert got[0]["mtid"] == -1                    # RNEXT "=" copies the tid as it stands after the reset (sam_parse1 parses RNEXT behind POS)
+    assert got[1]["mtid"] == 0 and got[2]["mtid"] == 0
     assert (got[1]["tid"], got[1]["pos"], got[1]["flag"], got[1]["cigar"]) == (0, 10, 103, [])
     assert (got[2]["tid"], got[2]["pos"], got[2]["flag"]) == (0, 10, 99)
 
