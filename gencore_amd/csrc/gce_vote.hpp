@@ -45,7 +45,7 @@ static_assert(VB_W + 32 <= 128, "P1 finds a pair's group by a bytewise compare o
 #define VB_SIDES (2 * VB_MAXG)
 #define VB_COLS 256
 #ifndef VB_CCAP
-#define VB_CCAP 128        // (with VB_RCAP: LDS stays within 20 KB = EIGHT workgroups per CU, at 64 VGPRs (three dwords spilled): 2.79 -> 2.76 ms against
+#define VB_CCAP 256        // (round 5: 160 -- 47 % of cfg3's batches held more than 128 contested columns and voted a second round, ~0.3 ms of the kernel; the LDS came from the voter lists, now 256 B, and the byte-wide s_wbase)  Round 4, at 128: (with VB_RCAP: LDS stays within 20 KB = EIGHT workgroups per CU, at 64 VGPRs (three dwords spilled): 2.79 -> 2.76 ms against
                            //  184 / 512 at seven (22.5 KB, 66 VGPRs), although nearly half of the batches now vote in two rounds; batches of weight 80 / 64 at eight
                            //  workgroups: 2.84 / 3.03 ms.  profiles/r04_q_ab_8waves.log)
 #endif
@@ -60,13 +60,16 @@ static_assert(VB_W + 32 <= 128, "P1 finds a pair's group by a bytewise compare o
 #define VB_RCAP 384        // contested columns of a whole batch (all rounds): a side that does not fit any more hands its group on (32 sides x VB_SMAX would be 1024)
 #endif
 
-struct __attribute__((aligned(16))) VRead { uint64_t so, qo; uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };   // fl bit 0: isize != 0
-static_assert(sizeof(VRead) == 32, "VRead must stay 32 bytes");
-// the second 16 bytes of a VRead (everything but the two blob offsets) with ONE LDS load
-struct VTail { uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };
-__device__ __forceinline__ VTail vr_tail(const VRead *r) {
+// A read of the batch in LDS, in two halves: the blob offsets live through the whole kernel; the rest (first CIGAR word, position, read index, length, CIGAR ops,
+// fl bit 0: isize != 0) is what P1 .. P2 choose templates and voters by -- from pass A on its 4 KB are TALLY space (round 5: with them the tallies take 256
+// contested columns in one round at the same 20 KB of LDS; at 128 nearly every batch of weight 96 voted two or three rounds, and a round costs every wave of
+// the block its whole instruction stream however few items it has: 188 M of the kernel's 1067 M VALU instructions)
+struct __attribute__((aligned(16))) VRead { uint64_t so, qo; };
+struct __attribute__((aligned(16))) VTail { uint32_t c0; int32_t pos; uint32_t rd; uint16_t lq; uint8_t nc, fl; };
+static_assert(sizeof(VRead) == 16 && sizeof(VTail) == 16, "VRead / VTail must stay 16 bytes");
+__device__ __forceinline__ VTail vr_tail(const VTail *r) {                  // ONE LDS load
     union { uint4 q; VTail t; } u;
-    u.q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(r) + 16);
+    u.q = *reinterpret_cast<const uint4 *>(r);
     return u.t;
 }
 struct VOv { uint16_t ls, rs, cmp, fl; };                   // fl: 1 = every score of the pair is the constant (pair.cpp:89-105), 2 = overlap [ls|rs, +cmp)
@@ -174,14 +177,14 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ VOv s_ov[VB_MAXP];
     __shared__ VSide s_side[VB_SIDES];
     __shared__ uint32_t s_cmask[VB_SIDES][VB_COLS / 32];
-    __shared__ uint8_t s_vlist[VB_SIDES][32];                                      // voters of a side (pair index in the batch), ascending
-    __shared__ __attribute__((aligned(8))) uint32_t s_tal[VB_CCAP][5][2];          // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
+    __shared__ uint8_t s_vlist[2][VB_MAXP];                                        // voters of a side (pair index in the batch), ascending: the k-th voter of side (group, parity) at [parity][lp0 + k] -- a side has no more voters than its group has pairs
+    __shared__ __attribute__((aligned(16))) uint32_t s_tal[VB_CCAP][5][2];         // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
                                                                                    // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
     __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
     __shared__ uint16_t s_jpre[VB_PRE];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
     __shared__ uint16_t s_ipre[VB_PRE], s_cpre[VB_PRE];                            // (entries behind VB_SIDES: 0xFFFF, see vb_find_wave)
-    __shared__ uint16_t s_wbase[VB_SIDES][VB_COLS / 32];                           // place in the contested-column list of the first column of every 32-column word (P5b -> P7)
+    __shared__ uint8_t s_wbase[VB_SIDES][VB_COLS / 32];                            // place in the SIDE's contested-column list (<= VB_SMAX) of the first column of every 32-column word (P5b -> P7)
     __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng, s_np;
@@ -194,7 +197,9 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     uint32_t *s_hm = &s_tal[0][0][0] + 3 * VB_MAXP, *s_single = s_hm + VB_SIDES, *s_vm = s_single + VB_SIDES, *s_unf = s_vm + VB_SIDES;
     int32_t *s_pmin = reinterpret_cast<int32_t *>(s_unf + VB_SIDES), *s_pmax = s_pmin + VB_SIDES;
     uint8_t *s_pg = reinterpret_cast<uint8_t *>(s_pmax + VB_SIDES);
-    static_assert(sizeof(s_tal) >= (3 * VB_MAXP + 6 * VB_SIDES) * 4 + VB_MAXP, "P1 scratch must fit the tally space");
+    // ... and, in its top 4 KB, the second half of every read (VTail) until P2 is through
+    VTail (*s_rt)[VB_MAXP] = reinterpret_cast<VTail (*)[VB_MAXP]>(reinterpret_cast<char *>(&s_tal[0][0][0]) + sizeof(s_tal) - 2 * VB_MAXP * sizeof(VTail));
+    static_assert(sizeof(s_tal) >= (3 * VB_MAXP + 6 * VB_SIDES) * 4 + VB_MAXP + 2 * VB_MAXP * sizeof(VTail), "P1 scratch and the reads' second halves must fit the tally space");
     // work index of a thread: rotated by the batch number, so that the single-wave phases (P0, P2, P5a, P6) and the half-empty ones
     // do not all land on the same SIMD of the CU (wave k of every workgroup runs on SIMD k)
     const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
@@ -257,10 +262,10 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         ReadDesc lk{}, rk{};
         if (L != NONE32) lk = load_desc(w.rdesc, L);
         if (R != NONE32) rk = load_desc(w.rdesc, R);
-        VRead vl, vr;
-        vl.so = lk.so; vl.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
-        vr.so = rk.so; vr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
-        s_rd[0][tid] = vl; s_rd[1][tid] = vr; s_ptid[0][tid] = lk.tid; s_ptid[1][tid] = rk.tid; s_lastm[0][tid] = lk.lastm; s_lastm[1][tid] = rk.lastm;
+        VRead ol, orr; VTail vl, vr;
+        ol.so = lk.so; ol.qo = lk.qo; vl.c0 = lk.c0; vl.pos = lk.pos; vl.rd = L; vl.lq = (uint16_t)lk.lq; vl.nc = (uint8_t)min((int)lk.nc, 255); vl.fl = lk.isize != 0;
+        orr.so = rk.so; orr.qo = rk.qo; vr.c0 = rk.c0; vr.pos = rk.pos; vr.rd = R; vr.lq = (uint16_t)rk.lq; vr.nc = (uint8_t)min((int)rk.nc, 255); vr.fl = rk.isize != 0;
+        s_rd[0][tid] = ol; s_rd[1][tid] = orr; s_rt[0][tid] = vl; s_rt[1][tid] = vr; s_ptid[0][tid] = lk.tid; s_ptid[1][tid] = rk.tid; s_lastm[0][tid] = lk.lastm; s_lastm[1][tid] = rk.lastm;
         s_pg[tid] = (uint8_t)j;
         {   // what the sides' template choice needs of their reads (group.cpp:177-194), gathered by the pairs
             const uint32_t kb = 1u << (tid - (int)s_glp0[j]);
@@ -340,12 +345,12 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     //     was a quarter of the batch's life time: 2 x 32 trips for the deepest group of the wave, at one wave's issue rate)
     for (int it = tid; it < 2 * npairs; it += VB_T) {
         const int pr = it >> 1, side = it & 1, jg = s_pg[pr], sl = 2 * jg + side, lp0 = s_glp0[jg];
-        const VTail r = vr_tail(&s_rd[side][pr]);
+        const VTail r = vr_tail(&s_rt[side][pr]);
         if (r.rd == NONE32 || s_gflag[jg] != 0) continue;
         const uint32_t hm = s_hm[sl], single = s_single[sl];
         const bool multi = single == 0;
         const int fl = multi ? __ffs((int)hm) - 1 : __ffs((int)single) - 1;
-        const VTail t = vr_tail(&s_rd[side][lp0 + fl]);
+        const VTail t = vr_tail(&s_rt[side][lp0 + fl]);
         const bool ralign = side == 1 && s_pmin[sl] != s_pmax[sl];                     // (some read off the template's position <=> not all positions equal)
         uint32_t o_cw1 = 0, o_cw2 = 0, cw1 = 0, cw2 = 0;
         if (multi && t.nc >= 2 && t.nc <= 3) { const uint32_t *cg = b.cigar + b.cigar_off[t.rd]; o_cw1 = cg[1]; if (t.nc == 3) o_cw2 = cg[2]; }
@@ -369,14 +374,14 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         bool to_gen = false;
         if (mine) {
             const int np = s_gnp[j], lp0 = s_glp0[j];
-            const VRead *rds = s_rd[side] + lp0;
+            const VTail *rds = s_rt[side] + lp0;
             // the reference of the side's contig (a side's reads share it, cross-contig clusters aside): asked for now, needed further down
             const int tid0 = s_ptid[side][lp0];
             const bool tid0_ok = tid0 >= 0 && tid0 < p.n_ref;
             const uint8_t *rdp0 = tid0_ok ? p.ref_data[tid0] : nullptr;
             const int64_t rl0 = tid0_ok ? p.ref_len[tid0] : 0;
-            if (np == 1 && s_rd[1][lp0].rd == NONE32) {                                 // group.cpp:73-77: returned untouched
-                sd.result = side == 0 ? s_rd[0][lp0].rd : NONE32;
+            if (np == 1 && s_rt[1][lp0].rd == NONE32) {                                 // group.cpp:73-77: returned untouched
+                sd.result = side == 0 ? s_rt[0][lp0].rd : NONE32;
             } else {
                 const uint32_t hm = s_hm[lane], single = s_single[lane];
                 if (hm != 0) {
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             const uint32_t vm = s_side[2 * j + side].vmask;                             // (0 unless the side is active)
-            if ((vm >> k) & 1u) s_vlist[2 * j + side][__popc(vm & ((1u << k) - 1u))] = (uint8_t)tid;     // (the pair's index in the batch)
+            if ((vm >> k) & 1u) s_vlist[side][(int)s_glp0[j] + __popc(vm & ((1u << k) - 1u))] = (uint8_t)tid;     // (the pair's index in the batch)
         }
     }
     VB_TICK(3);
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             if (s_cpre[s + 1] > s_cpre[s]) {
                 int base = s_cpre[s];
                 for (int x = 0; x < k; x++) base += __popc(word(x));
-                s_wbase[s][k] = (uint16_t)base;
+                s_wbase[s][k] = (uint8_t)(base - (int)s_cpre[s]);
                 for (uint32_t m = mk; m; m &= m - 1) s_ccol[base++] = (uint8_t)(32 * k + __ffs((int)m) - 1);
             }
         }
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             x.ci = (int)s_cpre[s] + c; x.col = s_ccol[x.ci];
             const VSide *sd = &s_side[s];
             x.grp = sd->grp;
-            const int lp = s_vlist[s][kv];
+            const int lp = s_vlist[x.side][(int)sd->lp0 + kv];
             const VRead *r = &s_rd[x.side][lp];
             const VOv ov = s_ov[lp];
             const int mystart = x.side ? ov.rs : ov.ls;
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             uint64_t x = 0, x0 = 0; int nbytes = 0;
             if (cm) {
                 // the voted columns of this chunk: their place in the side's list = contested columns in front of them
-                int ci = s_wbase[s][chunk >> 1];                                        // (P5b: columns of the side in front of this 32-column word)
+                int ci = (int)s_cpre[s] + (int)s_wbase[s][chunk >> 1];                  // (P5b: columns of the side in front of this 32-column word)
                 if (chunk & 1) ci += __popc(s_cmask[s][chunk >> 1] & 0xFFFFu);
                 nbytes = min(8, ((int)sd.len + 1) / 2 - 8 * chunk);
                 x = ld8_unaligned(os);                                                  // (blobs are readable past a read's last byte)
