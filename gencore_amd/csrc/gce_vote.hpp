@@ -188,6 +188,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng, s_np;
+    __shared__ uint8_t s_ord[VB_SIDES];                                            // pass A: the sides in the order of their depth (P2b)
     __shared__ uint32_t s_cnt[VB_SIDES];                                           // contested columns of a side, counted by pass A (NOT in the tally space: the tallies are cleared while other waves still read these)
     // P1 -> P3 only, in the (not yet used) tally space: contig of either read of a pair (the template's reference lookup); length of its
     // last CIGAR op if that is an M block (isPartOf from the right end); per side the masks of its reads / its single-M reads, the range of
@@ -424,12 +425,29 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             }
         }
         // pass-A items: 16-column chunks of the active sides, prefix over the sides
+        // The sides in the order of their DEPTH (steps of four voters, deepest first): a pass-A wave runs to the deepest side among its 64 chunks, so sides of one
+        // depth go to the same waves.  s_ord[k] = the side at place k; s_ipre runs over the places.  (Worth 2 % of the kernel's VALU instructions and 0.01 ms: a
+        // batch's sides are closer to one another in depth than the clusters of the stream are.)
         const int nchunk = (mine && sd.state == VS_ACTIVE) ? (sd.len + 15) >> 4 : 0;
-        int pre = nchunk;
+        const int cls = lane >= VB_SIDES ? -2 : nchunk ? min(7, ((int)sd.nvot + 3) / 4 - 1) : -1;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int place = 0, cbase = 0;
+#pragma unroll
+        for (int c = 7; c >= -1; c--) {
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) place = cbase + __popcll(m & lt);
+            cbase += __popcll(m);
+        }
+        if (lane < VB_SIDES) s_ord[place] = (uint8_t)lane;
+        WAVE_SYNC();
+        const int src = lane < VB_SIDES ? (int)s_ord[lane] : lane;                      // the side at my place
+        const int nch_k = __shfl(nchunk, src);
+        int pre = nch_k;
         pre = wave_scan_incl(pre);
-        sd.item0 = (uint16_t)(pre - nchunk);
-        if (lane < VB_SIDES) { s_side[lane] = sd; s_ipre[lane] = (uint16_t)(pre - nchunk); }
+        if (lane < VB_SIDES) { s_side[lane] = sd; s_ipre[lane] = (uint16_t)(pre - nch_k); }
         if (lane == VB_SIDES - 1) s_ipre[VB_SIDES] = (uint16_t)pre;
+        WAVE_SYNC();
+        if (lane < VB_SIDES) s_side[src].item0 = (uint16_t)(pre - nch_k);               // (behind the struct store of the side's own lane: LDS operations of one wave keep their order)
     }
     __syncthreads();
     VB_TICK(2);
@@ -455,7 +473,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         const int it = tid + VB_T * kk;
         item_side[kk] = 0;
         if (it - lane >= n_items) continue;                                        // (wave-uniform: the second round is empty for the usual batch of <= 256 items)
-        const int s = vb_find_wave(s_ipre, VB_SIDES, it - lane, lane, n_items - 1);
+        const int s = s_ord[vb_find_wave(s_ipre, VB_SIDES, it - lane, lane, n_items - 1)];
         item_side[kk] = s;
         if (it < n_items) {
             const VSide sd = s_side[s];
