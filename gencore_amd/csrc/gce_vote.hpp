@@ -6,12 +6,12 @@
 // batch of ~9 groups (<= 16 groups, <= 95 pairs, weight 64) through a few FLAT phases, every phase with one lane per independent item:
 //   P1  lane = pair            the two reads' descriptors into LDS; the pair's mate-overlap window (pair.cpp:108-120); what the sides'
 //                              template choice needs of their reads (masks, position range) by LDS atomics
-//   P3  (the same lanes, no barrier)  mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
 //   P2  lane = (pair, side), then lane = (group, side)   consensusMergeBam for the sides this kernel covers: one class of reads with the
 //                              same CIGAR and length -- and position, when the right reads start at different positions (right-aligned
 //                              mode) -- (+ a provably unrelated minority), template = first read of the class, voters = the class
 //   P4  lane = (side, 16 columns)  "pass A": OR / AND of the voters' packed bases (unanimity), packed max of their quals; a column
 //                              all voters agree on with top quality >= moderate takes group.cpp:421-428 (base kept, qual = max qual)
+//   P3  lane = pair (behind pass A, in its phase: the bytes come from the L2)  mismatching bases in the mate overlap -> those columns are forced into the full vote of both sides
 //   P5  lane = (side, voter, contested column)  "pass B": the voter's base, quality and exact score (pair.cpp:132-169 computed on the fly,
 //                              the qualities of mismatching overlap bases rewritten to max(0, own - mate)) go into the column's 5-bin tally
 //                              in LDS (count | biased score sum | quality sum packed into ONE atomic add, one atomic max for the top
@@ -287,44 +287,6 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         }
         s_ov[tid] = ov;
     }
-    // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
-    //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten).
-    //      The same lanes as P1, on what they wrote themselves: no barrier in between.
-    if (tid < npairs) {
-        const VOv ov = s_ov[tid];
-        const int j = s_pg[tid];
-        if ((ov.fl & 2) && s_gflag[j] == 0) {
-            const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
-            // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
-            auto cols8 = [](uint64_t x, int c0) {
-                const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
-                return (uint32_t)(y >> (4 * (c0 & 1)));
-            };
-            for (int i = 0; i < (int)ov.cmp; i += 32) {                                 // four 8-column words per step, loads first
-                uint64_t lw[4], rw[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ii = min(i + 8 * u, (int)ov.cmp - 1);                     // (clamped: a short last step re-reads a valid word)
-                    lw[u] = ld8_unaligned(ls + ((ov.ls + ii) >> 1)); rw[u] = ld8_unaligned(rs + ((ov.rs + ii) >> 1));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i0 = i + 8 * u, nv = min(8, (int)ov.cmp - i0);
-                    if (nv <= 0) continue;
-                    const int l0 = ov.ls + i0, r0 = ov.rs + i0;
-                    uint32_t d = (cols8(lw[u], l0) ^ cols8(rw[u], r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
-                    d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
-                    while (d) {
-                        const int k = (__ffs((int)d) - 1) >> 2;
-                        d &= d - 1;
-                        const int l = l0 + k, r = r0 + k;
-                        if (l < VB_COLS) atomicOr(&s_cmask[2 * j][l >> 5], 1u << (l & 31));
-                        if (r < VB_COLS) atomicOr(&s_cmask[2 * j + 1][r >> 5], 1u << (r & 31));
-                    }
-                }
-            }
-        }
-    }
     __syncthreads();
     VB_TICK(1);
     // ---------------------------------------------------------------- P2: Group::consensusMergeBam per (group, side)   group.cpp:136-318
@@ -522,10 +484,51 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             const uint32_t hib = (msb4(t0) | (msb4(t1) << 4) | (msb4(t2) << 8) | (msb4(t3) << 12)) & colmask;
             if (hib != 0 || p.moderate_q > 127) s_gflag[sd.grp] = 2;
             keep[kk] = make_uint4(t0, t1, t2, t3);
-            {   // into the side's column mask, next to the columns P3 forced (complete by now); the side's count goes along
-                const uint32_t sh = 16u * (chunk & 1), forced = (s_cmask[s][chunk >> 1] >> sh) & colmask, tot = forced | contested;
-                if (contested & ~forced) atomicOr(&s_cmask[s][chunk >> 1], contested << sh);
-                if (tot) atomicAdd(&s_cnt[s], (uint32_t)__popc(tot));
+            if (contested) {   // into the side's column mask, beside the columns P3 forces (in this phase, behind pass A); a bit is counted by whoever sets it first
+                const uint32_t sh = 16u * (chunk & 1), mine_ = contested << sh, fresh = mine_ & ~atomicOr(&s_cmask[s][chunk >> 1], mine_);
+                if (fresh) atomicAdd(&s_cnt[s], (uint32_t)__popc(fresh));
+            }
+        }
+    }
+    // ---------------------------------------------------------------- P3: mismatching bases in the mate overlap (pair.cpp:132-168)
+    //      -> the column is forced into pass B on both sides (its scores are not qual2score(qual), its quals are rewritten).
+    //      BEHIND pass A since round 5 (one lane per pair, the lanes that are through with their chunks): the two reads' bytes around the overlap were fetched by
+    //      pass A a few microseconds ago and come from the L2 -- in front of P2, behind the descriptors, they were a third dependent trip to HBM in P1 and
+    //      ~1 GB of sectors fetched twice (0.2 ms of the kernel in a build without the compare).  Pass A does not need the forced columns: a bit of s_cmask is
+    //      counted by whoever sets it first (atomicOr returns the word as it was).
+    if (tid < npairs) {
+        const VOv ov = s_ov[tid];
+        const int j = s_pg[tid];
+        if ((ov.fl & 2) && s_gflag[j] == 0) {
+            const uint8_t *ls = b.seq + s_rd[0][tid].so, *rs = b.seq + s_rd[1][tid].so;
+            const int lenl = s_side[2 * j].state == VS_ACTIVE ? (int)s_side[2 * j].len : 0, lenr = s_side[2 * j + 1].state == VS_ACTIVE ? (int)s_side[2 * j + 1].len : 0;
+            // 8 columns of either read as nibbles in column order: swap the nibbles of every byte, drop the odd leading column
+            auto cols8 = [](uint64_t x, int c0) {
+                const uint64_t y = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
+                return (uint32_t)(y >> (4 * (c0 & 1)));
+            };
+            for (int i = 0; i < (int)ov.cmp; i += 32) {                                 // four 8-column words per step, loads first
+                uint64_t lw[4], rw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = min(i + 8 * u, (int)ov.cmp - 1);                     // (clamped: a short last step re-reads a valid word)
+                    lw[u] = ld8_unaligned(ls + ((ov.ls + ii) >> 1)); rw[u] = ld8_unaligned(rs + ((ov.rs + ii) >> 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i0 = i + 8 * u, nv = min(8, (int)ov.cmp - i0);
+                    if (nv <= 0) continue;
+                    const int l0 = ov.ls + i0, r0 = ov.rs + i0;
+                    uint32_t d = (cols8(lw[u], l0) ^ cols8(rw[u], r0)) & (nv >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nv)) - 1u));
+                    d = (d | (d >> 1) | (d >> 2) | (d >> 3)) & 0x11111111u;
+                    while (d) {
+                        const int k = (__ffs((int)d) - 1) >> 2;
+                        d &= d - 1;
+                        const int l = l0 + k, r = r0 + k;
+                        if (l < VB_COLS) { const uint32_t bit = 1u << (l & 31); if (!(atomicOr(&s_cmask[2 * j][l >> 5], bit) & bit) && l < lenl) atomicAdd(&s_cnt[2 * j], 1u); }
+                        if (r < VB_COLS) { const uint32_t bit = 1u << (r & 31); if (!(atomicOr(&s_cmask[2 * j + 1][r >> 5], bit) & bit) && r < lenr) atomicAdd(&s_cnt[2 * j + 1], 1u); }
+                    }
+                }
             }
         }
     }
