@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--test-one-gpu", action="store_true", help="testing aid: every rank uses cuda:0 and torch.distributed runs over gloo, so the N > 1 code path (one stream cut into key ranges, ticks + flush events, Stats all-reduce) can be exercised on a 1-GPU box")
+    ap.add_argument("--coverage-step", type=int, default=10000, help="Options::coverageStep of the depth statistics in the Stats merge (src/options.cpp:36)")
+    ap.add_argument("--stats-merge", default="full", choices=["full", "counters"], help="what the ranks all-reduce after every step at N > 1: the whole Stats payload (counters + "
+                    "histogram + per-contig depth bins + BED region counts, SURVEY 8e; gce_stats_payload_device) or the two counter blocks alone (rounds 1-4)")
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
     args = ap.parse_args()
 
@@ -198,6 +201,24 @@ def main():
     t["qname"] = padded_clone(t["qname"])
 
     stats_dev = torch.zeros(2 * capi.GCE_STATS_WORDS, dtype=torch.int64, device=dev)
+    # the regions of the depth statistics: the workload's BED panel, or -- a whole-genome stream (configs[3]: "whole-genome BED") -- 200 bp every ~150 kb
+    bed = data.info.get("bed")
+    if bed is None:
+        regs = []
+        for tid_, ln_ in enumerate(tl):
+            stp = max(int(data.info["genome_bases"]) // 20000, 1000)
+            regs += [(tid_, a, a + 200) for a in range(stp // 2, max(int(ln_) - 200, 1), stp)]
+        bed = np.asarray(regs, np.int64).reshape(-1, 3)
+    r_tid, r_start, r_end = (np.ascontiguousarray(np.asarray(bed)[:, k], np.int32) for k in range(3))
+    payload_lay = capi.GcePayloadLayout()
+
+    def stats_payload():
+        """gce_stats_payload_device: Stats blocks + depth bins + BED counts of this rank's reads and records as one int64 buffer in HBM -> (pointer, words)"""
+        pp = C.c_void_p()
+        rc = lib.gce_stats_payload_device(eng, args.coverage_step, len(r_tid), r_tid.ctypes.data, r_start.ctypes.data, r_end.ctypes.data, C.byref(pp), C.byref(payload_lay))
+        if rc:
+            raise SystemExit("gce_stats_payload_device failed: %s" % lib.gce_last_error(eng).decode())
+        return pp, int(payload_lay.total_words)
     hip = _hip()
     timings, last_res = [], {}
 
@@ -209,9 +230,15 @@ def main():
             raise SystemExit("engine failed: %s" % lib.gce_last_error(eng).decode())
         r = capi.GceResult()
         lib.gce_result_device(eng, C.byref(r))
-        if dist:                                            # the final Stats merge: one RCCL all-reduce over xGMI, device to device
-            sp = C.c_void_p()                               # (gce_stats_device: both blocks as they lie in HBM, 2 x 114 int64)
-            assert lib.gce_stats_device(eng, C.byref(sp)) == 0
+        if dist:                                            # the final Stats merge: ONE RCCL all-reduce over xGMI, device to device
+            nonlocal stats_dev
+            if args.stats_merge == "full":                  # counters + histogram + depth bins + BED region counts in one buffer (~5 MB at hg19 / 10 kb)
+                sp, words = stats_payload()
+                if stats_dev.numel() != words:
+                    stats_dev = torch.zeros(words, dtype=torch.int64, device=dev)
+            else:                                           # (gce_stats_device: both blocks as they lie in HBM, 2 x 114 int64)
+                sp = C.c_void_p()
+                assert lib.gce_stats_device(eng, C.byref(sp)) == 0
             assert hip.hipMemcpyAsync(C.c_void_p(stats_dev.data_ptr()), sp, C.c_size_t(stats_dev.numel() * 8), 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
             dist.all_reduce(stats_dev)
         tm = GceTiming()
@@ -386,15 +413,28 @@ def main():
         # engine's own -- the same stream cut into 1 or N ranges must give the same numbers (tests/test_bench_ranks.py)
         names = ("reads", "bases", "reads_unmapped", "bases_unmapped", "base_mismatches", "reads_with_mismatches", "clusters", "multi_molecule_clusters",
                  "molecules", "molecules_se", "molecules_pe", "sscs", "dcs", "uncounted_supporting_reads")
+        def depth_digest(v, lay):              # sums and a position-weighted checksum of the four vectors behind the Stats blocks
+            nb, nr, o = int(lay.n_bins), int(lay.n_regions), 2 * capi.GCE_STATS_WORDS
+            parts = {"pre_depth": v[o:o + nb], "post_depth": v[o + nb:o + 2 * nb], "pre_bed": v[o + 2 * nb:o + 2 * nb + nr], "post_bed": v[o + 2 * nb + nr:o + 2 * nb + 2 * nr]}
+            dg = {k: {"sum": int(x.sum()), "checksum": int((x * (np.arange(len(x), dtype=np.int64) % 1000003 + 1)).sum() % (1 << 61))} for k, x in parts.items()}
+            dg.update(coverage_step=args.coverage_step, depth_bins=nb, bed_regions=nr, payload_bytes=int(lay.total_words) * 8)
+            return dg
         if dist:
-            sv = stats_dev.cpu().tolist()
+            sv = stats_dev.cpu().numpy()
             W = capi.GCE_STATS_WORDS
-            out["stats_whole_stream"] = {"pre": dict(zip(names, sv[:14])), "post": dict(zip(names, sv[W:W + 14])), "pre_hist_sum": int(sum(sv[14:W])), "post_hist_sum": int(sum(sv[W + 14:])),
-                                         "how": "one all-reduce(sum) of 2 x %d int64 straight from device memory (gce_stats_device)" % W}
+            out["stats_whole_stream"] = {"pre": dict(zip(names, sv[:14].tolist())), "post": dict(zip(names, sv[W:W + 14].tolist())), "pre_hist_sum": int(sv[14:W].sum()), "post_hist_sum": int(sv[W + 14:2 * W].sum()),
+                                         "how": ("one all-reduce(sum) of %d int64 = %.2f MB per rank straight from device memory (gce_stats_payload_device: counters + histogram + depth bins + BED region counts)" % (len(sv), len(sv) * 8 / 1e6))
+                                                if args.stats_merge == "full" else "one all-reduce(sum) of 2 x %d int64 straight from device memory (gce_stats_device)" % W}
+            if args.stats_merge == "full":
+                out["stats_whole_stream"]["depth"] = depth_digest(sv, payload_lay)
         else:
             po = last_res.get("post", {})
             out["stats_whole_stream"] = {"pre": {k: pre.get(k) for k in names}, "post": {k: po.get(k) for k in names}, "pre_hist_sum": int(sum(pre.get("supporting_hist", []))),
                                          "post_hist_sum": int(sum(po.get("supporting_hist", []))), "how": "single engine"}
+            sp, words = stats_payload()                # (outside the timed steps: one engine has nothing to merge)
+            host = np.zeros(words, np.int64)
+            assert lib.gce_stats_payload_read(eng, sp, words, host.ctypes.data) == 0
+            out["stats_whole_stream"]["depth"] = depth_digest(host, payload_lay)
         if cpu:
             out["speedup_vs_cpu_port"] = round(value / cpu["value"], 2)
         print(json.dumps(out))

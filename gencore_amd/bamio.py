@@ -107,6 +107,27 @@ def run_bam_sharded(in_path, out_path, params, devices, fasta=None, plan_mode=0,
     return run
 
 
+def run_bam_depth(in_path, out_path, params, devices, coverage_step, bed=None, fasta=None, plan_mode=0, threads=0, level=6):
+    """gce_run_bam_depth: gce_run_bam (one device) / gce_run_bam_sharded (several) with the depth statistics of the reference's report
+    (Options::coverageStep, Options::bedFile): returns (run, dict(bin_off, pre_depth, post_depth, regions, pre_bed, post_bed, pre, post, payload_bytes))."""
+    from .capi import GceDepthRun
+    lib = capi.load_library()
+    run, dr = GceBamRun(), GceDepthRun()
+    err = (C.c_char * 256)()
+    dv = (C.c_int32 * len(devices))(*devices)
+    rc = lib.gce_run_bam_depth(str(in_path).encode(), str(out_path).encode(), str(fasta).encode() if fasta else None, str(bed).encode() if bed else None, int(coverage_step),
+                               C.byref(params), len(devices), dv, plan_mode, threads, level, C.byref(run), C.byref(dr), err)
+    if rc != 0:
+        raise GceError(rc, err.value.decode(errors="replace"))
+    arr = lambda p, n: np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].copy()
+    nb, nr = int(dr.n_bins), int(dr.n_regions)
+    out = dict(bin_off=arr(dr.bin_off, dr.n_targets + 1), pre_depth=arr(dr.pre_depth, nb), post_depth=arr(dr.post_depth, nb),
+               regions=[(dr.region_tid[k], dr.region_start[k], dr.region_end[k]) for k in range(nr)], pre_bed=arr(dr.pre_bed, nr), post_bed=arr(dr.post_bed, nr),
+               pre=bytes(dr.pre), post=bytes(dr.post), payload_bytes=int(dr.payload_bytes))
+    lib.gce_depth_run_free(C.byref(dr))
+    return run, out
+
+
 def write_batch_as_bam(path, batch, target_len, target_name=None, text="@HD\tVN:1.6\tSO:coordinate\n", threads=0, level=1):
     """gce_bam_from_batch: a ReadBatch as a BAM file (synthetic inputs for the end-to-end runs)."""
     lib = capi.load_library()

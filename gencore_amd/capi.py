@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "gce_get_timing", "gce_reset", "gce_last_error", "gce_status_message", "gce_abi_version",
     "gce_reserve", "gce_submit_async", "gce_submit_wait",
     "gce_bam_open", "gce_bam_close", "gce_bam_error", "gce_bam_get_info", "gce_bam_chunk", "gce_bam_write", "gce_bam_from_batch", "gce_sam_to_bam", "gce_bam_to_sam",
-    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_run_bam_sharded_hostcodec", "gce_raw_deflate_output", "gce_raw_read_deflated_async", "gce_bgzf_deflate", "gce_raw_attach_mirror", "gce_raw_select_shard", "gce_raw_merge_outputs", "gce_raw_begin", "gce_raw_push", "gce_raw_push_bgzf", "gce_bgzf_inflate", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
+    "gce_fasta_load", "gce_fasta_get", "gce_fasta_free", "gce_run_bam", "gce_run_bam_hostcodec", "gce_run_bam_sharded", "gce_run_bam_sharded_hostcodec", "gce_raw_deflate_output", "gce_raw_read_deflated_async", "gce_bgzf_deflate", "gce_raw_attach_mirror", "gce_raw_select_shard", "gce_raw_merge_outputs", "gce_raw_begin", "gce_raw_push", "gce_raw_push_bgzf", "gce_bgzf_inflate", "gce_raw_finish", "gce_raw_build_output", "gce_raw_read_output_async", "gce_host_alloc", "gce_host_free", "gce_depth_stats", "gce_stats_payload_device", "gce_stats_payload_sum", "gce_stats_payload_read", "gce_run_bam_depth", "gce_depth_run_free", "gce_stats_device", "gce_stream_context", "gce_plan_shards", "gce_free", "gce_bed_load", "gce_bed_free"]
 
 
 class GceBamInfo(C.Structure):
@@ -116,6 +116,17 @@ class GceBamInfo(C.Structure):
 class GceDepth(C.Structure):
     _fields_ = [("n_targets", C.c_int32), ("bin_off", C.POINTER(C.c_int64)), ("pre_depth", C.POINTER(C.c_int64)), ("post_depth", C.POINTER(C.c_int64)),
                 ("n_regions", C.c_int32), ("pre_bed", C.POINTER(C.c_int64)), ("post_bed", C.POINTER(C.c_int64))]
+
+
+class GcePayloadLayout(C.Structure):
+    _fields_ = [("stats_words", C.c_int32), ("n_targets", C.c_int32), ("n_bins", C.c_int64), ("n_regions", C.c_int32), ("total_words", C.c_int64),
+                ("bin_off", C.POINTER(C.c_int64))]
+
+
+class GceDepthRun(C.Structure):
+    _fields_ = [("n_targets", C.c_int32), ("n_bins", C.c_int64), ("bin_off", C.POINTER(C.c_int64)), ("pre_depth", C.POINTER(C.c_int64)), ("post_depth", C.POINTER(C.c_int64)),
+                ("n_regions", C.c_int32), ("region_tid", C.POINTER(C.c_int32)), ("region_start", C.POINTER(C.c_int32)), ("region_end", C.POINTER(C.c_int32)),
+                ("pre_bed", C.POINTER(C.c_int64)), ("post_bed", C.POINTER(C.c_int64)), ("pre", GceStats), ("post", GceStats), ("payload_bytes", C.c_int64)]
 
 
 class GceBamRun(C.Structure):
@@ -192,6 +203,13 @@ def load_library(path=None, mode=C.RTLD_GLOBAL):
     lib.gce_fasta_free.argtypes = [C.c_void_p]
     lib.gce_fasta_free.restype = None
     lib.gce_depth_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GceDepth)]
+    lib.gce_stats_payload_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GcePayloadLayout)]
+    lib.gce_stats_payload_sum.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(GcePayloadLayout)]
+    lib.gce_stats_payload_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.gce_run_bam_depth.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(GceParams), C.c_int32, C.c_void_p, C.c_int32, C.c_int, C.c_int,
+                                      C.POINTER(GceBamRun), C.POINTER(GceDepthRun), C.c_char_p]
+    lib.gce_depth_run_free.argtypes = [C.POINTER(GceDepthRun)]
+    lib.gce_depth_run_free.restype = None
     lib.gce_bed_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
                                  C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_char_p))]
     lib.gce_bed_free.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1291,6 +1291,9 @@ int gce_raw_deflate_output(gce_engine *e, uint64_t *comp_bytes);
 int gce_raw_read_deflated_async(gce_engine *e, uint64_t offset, void *host, size_t bytes, int32_t *ticket);
 int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror);
 int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode);
+int gce_stats_payload_device(gce_engine *e, int32_t coverage_step, int32_t n_regions, const int32_t *region_tid, const int32_t *region_start, const int32_t *region_end, const int64_t **payload, gce_payload_layout *layout);
+int gce_stats_payload_sum(gce_engine **engs, int32_t n_engs, const int64_t **payload, gce_payload_layout *layout);
+int gce_stats_payload_read(gce_engine *e, const int64_t *payload, int64_t n_words, int64_t *host);
 int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total);
 void gce_host_free(void *p);
 }  // extern "C" (declarations)
@@ -1316,7 +1319,8 @@ extern "C" {
 // entry of `devices` (the mirrors of the first), each inflates and indexes the stream on its own GPU, plans it there and keeps its share
 // (gce_raw_select_shard); the record streams are merged on the first engine's device (gce_raw_merge_outputs) and written as one.
 static int run_bam_impl(const char *in_path, const char *out_path, const char *fasta_path, const gce_params *params, int threads,
-                        int64_t chunk_reads, int level, gce_bam_run *out, char err[256], int32_t n_shards, const int32_t *devices, int32_t plan_mode) {
+                        int64_t chunk_reads, int level, gce_bam_run *out, char err[256], int32_t n_shards, const int32_t *devices, int32_t plan_mode,
+                        const char *bed_path = nullptr, int32_t coverage_step = 0, gce_depth_run *depth = nullptr) {
     auto seterr = [&](const char *m) { if (err) { strncpy(err, m ? m : "", 255); err[255] = 0; } };
     seterr("");
     if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
@@ -1614,6 +1618,32 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
     double t0 = now_s();
     int64_t n_rec = 0;
     uint64_t body = 0; int64_t n_out = 0;
+    // ---- the depth statistics of the report (Options::coverageStep, Options::bedFile; stats.cpp:56-83, bed.cpp:64-79): every engine adds up its own reads and
+    //      records on its GPU right behind its run -- BEFORE the merge adds the other engines' Stats blocks into the first one's -- (gce_stats_payload_device)
+    if (depth) {
+        memset(depth, 0, sizeof *depth);
+        if (coverage_step <= 0) return done(GCE_ERR_INVALID, "coverage_step must be positive");
+        if (bed_path && *bed_path) {
+            std::vector<const char *> np; for (auto &x : names) np.push_back(x.c_str());
+            if ((rc = gce_bed_load(bed_path, (int32_t)np.size(), np.data(), &depth->n_regions, &depth->region_tid, &depth->region_start, &depth->region_end, nullptr)) != GCE_OK) return done(rc, "cannot read the BED file");
+        }
+        const int nt = (int)lens.size();
+        depth->n_targets = nt;
+        depth->bin_off = (int64_t *)calloc((size_t)nt + 1, 8);
+        if (!depth->bin_off) return done(GCE_ERR_OOM, "out of host memory");
+        for (int t = 0; t < nt; t++) depth->bin_off[t + 1] = depth->bin_off[t] + 1 + (int64_t)lens[(size_t)t] / coverage_step;
+        const int64_t nb = depth->bin_off[nt];
+        depth->n_bins = nb;
+        depth->pre_depth = (int64_t *)calloc((size_t)std::max<int64_t>(nb, 1), 8); depth->post_depth = (int64_t *)calloc((size_t)std::max<int64_t>(nb, 1), 8);
+        depth->pre_bed = (int64_t *)calloc((size_t)std::max(depth->n_regions, 1), 8); depth->post_bed = (int64_t *)calloc((size_t)std::max(depth->n_regions, 1), 8);
+        if (!depth->pre_depth || !depth->post_depth || !depth->pre_bed || !depth->post_bed) return done(GCE_ERR_OOM, "out of host memory");
+        depth->payload_bytes = (2 * (int64_t)GCE_STATS_WORDS + 2 * nb + 2 * (int64_t)depth->n_regions) * 8;
+    }
+    auto engine_payload = [&](gce_engine *x) -> int {
+        if (!depth) return GCE_OK;
+        const int64_t *pay = nullptr; gce_payload_layout lay;
+        return gce_stats_payload_device(x, coverage_step, depth->n_regions, depth->region_tid, depth->region_start, depth->region_end, &pay, &lay);
+    };
     if (n_shards > 1) {
         // ---- several engines: each indexes the stream it received, keeps its shard, runs it and assembles its records -- side by side, one host
         //      thread per engine, nothing exchanged; then the streams are merged on the first engine's device
@@ -1628,7 +1658,7 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
             if (n0 > 0 && (c2 = gce_raw_select_shard(x, n_shards, r, plan_mode)) != GCE_OK) return failr(c2);
             t_idx[(size_t)r] = now_s() - a0;
             gce_result rs;
-            if (n0 > 0 && ((c2 = gce_process(x)) != GCE_OK || (c2 = gce_result_device(x, &rs)) != GCE_OK || (c2 = gce_raw_build_output(x, &b2, &o2)) != GCE_OK)) return failr(c2);
+            if (n0 > 0 && ((c2 = gce_process(x)) != GCE_OK || (c2 = gce_result_device(x, &rs)) != GCE_OK || (c2 = gce_raw_build_output(x, &b2, &o2)) != GCE_OK || (c2 = engine_payload(x)) != GCE_OK)) return failr(c2);
             gce_timing tm; if (n0 > 0 && gce_get_timing(x, &tm) == GCE_OK) kms[(size_t)r] = tm.total_ms;
             nrec[(size_t)r] = n0;
         });
@@ -1653,10 +1683,25 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
         if ((rc = gce_result_device(e, &res)) != GCE_OK) return done(rc, gce_last_error(e));
         out->n_reads = res.n_reads; out->n_out = res.n_out; out->pre = res.pre; out->post = res.post;
         if ((rc = gce_raw_build_output(e, &body, &n_out)) != GCE_OK) return done(rc, gce_last_error(e));
+        if ((rc = engine_payload(e)) != GCE_OK) return done(rc, gce_last_error(e));
         out->drain_s = now_s() - t0; t0 = now_s();
         if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after process + output records %ld MB\n", status_kb("VmRSS:") >> 10);
     }
     }   // (one engine)
+    // ---- the depth statistics of the report: the engines' payloads (computed above, each on its own Stats blocks) summed in device memory, to the host once
+    if (depth && n_rec > 0) {
+        std::vector<gce_engine *> all; all.push_back(e); for (auto *x : mir) all.push_back(x);
+        const int64_t *pay = nullptr; gce_payload_layout lay;
+        if ((rc = gce_stats_payload_sum(all.data(), (int32_t)all.size(), &pay, &lay)) != GCE_OK) return done(rc, gce_last_error(e));
+        std::vector<int64_t> host((size_t)lay.total_words);
+        if ((rc = gce_stats_payload_read(e, pay, lay.total_words, host.data())) != GCE_OK) return done(rc, gce_last_error(e));
+        const int64_t nb = depth->n_bins; const int32_t nreg = depth->n_regions;
+        if (lay.n_bins != nb || lay.n_regions != nreg) return done(GCE_ERR_INVALID, "payload layout");
+        memcpy(&depth->pre, host.data(), sizeof(gce_stats)); memcpy(&depth->post, host.data() + GCE_STATS_WORDS, sizeof(gce_stats));
+        const int64_t *d0 = host.data() + lay.stats_words;
+        memcpy(depth->pre_depth, d0, (size_t)nb * 8); memcpy(depth->post_depth, d0 + nb, (size_t)nb * 8);
+        memcpy(depth->pre_bed, d0 + 2 * nb, (size_t)nreg * 8); memcpy(depth->post_bed, d0 + 2 * nb + nreg, (size_t)nreg * 8);
+    }
     // ---- the output file: header bytes + the record stream from HBM, in pieces; deflate by all threads, written in order
     const size_t opl = strlen(out_path);
     if (opl >= 3 && strcmp(out_path + opl - 3, "sam") == 0) {
@@ -1921,6 +1966,24 @@ int gce_run_bam(const char *in_path, const char *out_path, const char *fasta_pat
     if (!in_path || !out_path || !params || !out) return GCE_ERR_INVALID;
     if (getenv("GCE_BAM_HOSTCODEC")) return gce_run_bam_hostcodec(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err);
     return run_bam_impl(in_path, out_path, fasta_path, params, threads, chunk_reads, level, out, err, 1, nullptr, 0);
+}
+
+void gce_depth_run_free(gce_depth_run *d) {
+    if (!d) return;
+    free(d->bin_off); free(d->pre_depth); free(d->post_depth); free(d->pre_bed); free(d->post_bed);
+    if (d->region_tid || d->region_start || d->region_end) gce_bed_free(d->n_regions, d->region_tid, d->region_start, d->region_end, nullptr);
+    memset(d, 0, sizeof *d);
+}
+
+// gce_run_bam / gce_run_bam_sharded with the depth statistics of the reference's report: see include/gencore_amd.h.
+int gce_run_bam_depth(const char *in_path, const char *out_path, const char *fasta_path, const char *bed_path, int32_t coverage_step, const gce_params *params,
+                      int32_t n_shards, const int32_t *devices, int32_t plan_mode, int threads, int level, gce_bam_run *out, gce_depth_run *depth, char err[256]) {
+    if (!depth || n_shards < 1 || n_shards > 64 || (n_shards > 1 && !devices)) return GCE_ERR_INVALID;
+    gce_params prm;
+    if (params && n_shards == 1 && devices) { prm = *params; prm.device = devices[0]; params = &prm; }
+    const int rc = run_bam_impl(in_path, out_path, fasta_path, params, threads, 0, level, out, err, n_shards, n_shards > 1 ? devices : nullptr, plan_mode, bed_path, coverage_step, depth);
+    if (rc != GCE_OK) gce_depth_run_free(depth);
+    return rc;
 }
 
 // Gencore::consensus() for one file over SEVERAL engines on the GPU codec (src/gencore.cpp:164-205): see run_bam_impl.  The host

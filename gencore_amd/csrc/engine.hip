@@ -95,8 +95,8 @@ struct gce_engine {
     gce_timing timing{};
     int64_t n = 0, n_pre = 0;            // reads processed; reads counted by the pre-Stats (one more when --quit_after_contig cut the stream)
     // depth statistics (gce_depth_stats)
-    DevBuf dp_binoff, dp_regoff, dp_rs, dp_re, dp_pmax, dp_sorted, dp_depth, dp_bed;
-    std::vector<int64_t> h_binoff, h_depth_pre, h_depth_post, h_bed_pre, h_bed_post;
+    DevBuf dp_binoff, dp_regoff, dp_rs, dp_re, dp_pmax, dp_sorted, dp_depth, dp_bed, dp_where;      // dp_depth: the Stats-merge payload (gce_stats_payload_device)
+    std::vector<int64_t> h_binoff, h_depth_pre, h_depth_post, h_bed_pre, h_bed_post; int64_t payload_words = 0;
     // host result copies
     std::vector<uint8_t> r_kind; HostRaw r_seq, r_qual; std::vector<uint32_t> r_src, r_qsrc, r_mate; std::vector<int32_t> r_nm; std::vector<int16_t> r_fr, r_rr;
     std::vector<uint64_t> r_soff, r_qoff;
@@ -175,7 +175,7 @@ void gce_destroy(gce_engine *e) {
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
     for (DevBuf *b : {&e->zo_slots, &e->zo_sizes, &e->zo_off, &e->zo_out, &e->p16_flag, &e->p16_list}) b->release();
     for (DevBuf *b : {&e->sh_tickall, &e->sh_shard, &e->sh_flag, &e->sh_sel, &e->sh_core, &e->sh_qoff, &e->sh_coff, &e->sh_soff, &e->sh_loff, &e->sh_nm, &e->sh_nmt, &e->sh_mioff, &e->sh_tick, &e->sh_roff, &e->sh_nmpos, &e->sh_keys, &e->sh_stage}) b->release();
-    for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed}) b->release();
+    for (DevBuf *b : {&e->dp_binoff, &e->dp_regoff, &e->dp_rs, &e->dp_re, &e->dp_pmax, &e->dp_sorted, &e->dp_depth, &e->dp_bed, &e->dp_where}) b->release();
     for (auto ev : e->up_events) (void)hipEventDestroy(ev);
     if (e->up_stream) { (void)hipStreamSynchronize(e->up_stream); (void)hipStreamDestroy(e->up_stream); }
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
@@ -1034,9 +1034,23 @@ int gce_drain(gce_engine *e, gce_result *out) {
 }
 
 // Stats::statDepth / Bed::statDepth for the processed stream: see gce_depth.hpp and include/gencore_amd.h.
-int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_t *r_tid, const int32_t *r_start, const int32_t *r_end, gce_depth *out) {
-    if (!e || !out || step <= 0 || n_regions < 0 || (n_regions > 0 && (!r_tid || !r_start || !r_end))) return GCE_ERR_INVALID;
-    if (!e->processed) return fail(e, GCE_ERR_INVALID, "gce_depth_stats before gce_process");
+// BED counts from the kernel's order (regions grouped by contig) to the order of the file, and the two Stats blocks in front of the payload
+__global__ void k_payload_finish(const StreamInfo *si, const int32_t *where, int32_t n_regions, const unsigned long long *bed_grouped, int32_t nreg, long long *payload, int64_t nbins) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * GCE_STATS_WORDS) payload[i] = i < GCE_STATS_WORDS ? si->pre[i] : si->post[i - GCE_STATS_WORDS];
+    if (i < n_regions) {
+        const int w = where[i];
+        long long *bed = payload + 2 * GCE_STATS_WORDS + 2 * nbins;
+        bed[i] = w >= 0 ? (long long)bed_grouped[w] : 0; bed[n_regions + i] = w >= 0 ? (long long)bed_grouped[nreg + w] : 0;
+    }
+}
+
+// Everything the final Stats merge of a multi-GPU run adds up (stats.cpp:39-46,56-83, bed.cpp:64-79, gencore.cpp:181-184) as ONE buffer of int64 in
+// device memory: [pre Stats][post Stats][pre depth bins][post depth bins][pre BED counts][post BED counts] -- all additive over key-range shards, so a
+// multi-GPU run merges it with one all-reduce(sum) (bench.py) or one add per engine (gce_raw_merge_outputs).  See include/gencore_amd.h.
+int gce_stats_payload_device(gce_engine *e, int32_t step, int32_t n_regions, const int32_t *r_tid, const int32_t *r_start, const int32_t *r_end, const int64_t **payload, gce_payload_layout *layout) {
+    if (!e || !payload || !layout || step <= 0 || n_regions < 0 || (n_regions > 0 && (!r_tid || !r_start || !r_end))) return GCE_ERR_INVALID;
+    if (!e->processed || e->dev_error) return fail(e, GCE_ERR_INVALID, "gce_stats_payload_device before a successful gce_process");
     (void)hipSetDevice(e->prm.device);
     hipStream_t s = e->stream;
     const int nt = (int)e->target_len.size();
@@ -1061,23 +1075,49 @@ int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_
     auto up = [&](DevBuf &d, const void *src, size_t bytes) -> int { HIPCHK(d.ensure(bytes + 64)); if (bytes) HIPCHK(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s)); return GCE_OK; };
     int rc;
     if ((rc = up(e->dp_binoff, e->h_binoff.data(), (nt + 1) * 8)) || (rc = up(e->dp_regoff, off.data(), (nt + 1) * 4)) || (rc = up(e->dp_rs, rs.data(), (size_t)nreg * 4)) ||
-        (rc = up(e->dp_re, re.data(), (size_t)nreg * 4)) || (rc = up(e->dp_pmax, pm.data(), (size_t)nreg * 4)) || (rc = up(e->dp_sorted, sorted.data(), sorted.size()))) return rc;
-    HIPCHK(e->dp_depth.ensure((size_t)nbins * 16 + 64)); HIPCHK(e->dp_bed.ensure((size_t)nreg * 16 + 64));
-    HIPCHK(hipMemsetAsync(e->dp_depth.p, 0, (size_t)nbins * 16, s)); HIPCHK(hipMemsetAsync(e->dp_bed.p, 0, (size_t)nreg * 16 + 16, s));
+        (rc = up(e->dp_re, re.data(), (size_t)nreg * 4)) || (rc = up(e->dp_pmax, pm.data(), (size_t)nreg * 4)) || (rc = up(e->dp_sorted, sorted.data(), sorted.size())) ||
+        (rc = up(e->dp_where, where.data(), (size_t)n_regions * 4))) return rc;
+    const int64_t words = 2 * GCE_STATS_WORDS + 2 * nbins + 2 * (int64_t)n_regions;
+    HIPCHK(e->dp_depth.ensure((size_t)words * 8 + 64)); HIPCHK(e->dp_bed.ensure((size_t)nreg * 16 + 64));
+    HIPCHK(hipMemsetAsync(e->dp_depth.p, 0, (size_t)words * 8, s)); HIPCHK(hipMemsetAsync(e->dp_bed.p, 0, (size_t)nreg * 16 + 16, s));
     DepthCtx c; c.bin_off = e->dp_binoff.as<int64_t>(); c.n_targets = nt; c.step = step; c.reg_off = e->dp_regoff.as<int32_t>();
     c.r_start = e->dp_rs.as<int32_t>(); c.r_end = e->dp_re.as<int32_t>(); c.r_pmax = e->dp_pmax.as<int32_t>(); c.contig_sorted = e->dp_sorted.as<uint8_t>();
-    unsigned long long *dpre = e->dp_depth.as<unsigned long long>(), *dpost = dpre + nbins, *bpre = e->dp_bed.as<unsigned long long>(), *bpost = bpre + nreg;
+    long long *pay = e->dp_depth.as<long long>();
+    unsigned long long *dpre = (unsigned long long *)pay + 2 * GCE_STATS_WORDS, *dpost = dpre + nbins, *bpre = e->dp_bed.as<unsigned long long>(), *bpost = bpre + nreg;
     const uint64_t n = (uint64_t)e->n_pre, no = (uint64_t)e->n_out;
-    if (n) hipLaunchKernelGGL(k_depth, dim3(cdiv(n, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)nullptr, n, c, dpre, bpre);
-    if (no) hipLaunchKernelGGL(k_depth, dim3(cdiv(no, 256)), dim3(256), 0, s, e->dev_batch.core, (const uint32_t *)e->o_src.p, no, c, dpost, bpost);
-    e->h_depth_pre.resize(nbins); e->h_depth_post.resize(nbins);
-    std::vector<int64_t> bp(nreg), bq(nreg);
-    if (nbins) { HIPCHK(hipMemcpyAsync(e->h_depth_pre.data(), dpre, nbins * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(e->h_depth_post.data(), dpost, nbins * 8, hipMemcpyDeviceToHost, s)); }
-    if (nreg) { HIPCHK(hipMemcpyAsync(bp.data(), bpre, (size_t)nreg * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(bq.data(), bpost, (size_t)nreg * 8, hipMemcpyDeviceToHost, s)); }
+    if (n) hipLaunchKernelGGL(k_depth, dim3(cdiv(n, DP_T * DP_RPT)), dim3(DP_T), 0, s, e->dev_batch.core, (const uint32_t *)nullptr, n, c, dpre, bpre);
+    if (no) hipLaunchKernelGGL(k_depth, dim3(cdiv(no, DP_T * DP_RPT)), dim3(DP_T), 0, s, e->dev_batch.core, (const uint32_t *)e->o_src.p, no, c, dpost, bpost);
+    const int fin = std::max(2 * GCE_STATS_WORDS, (int)n_regions);
+    hipLaunchKernelGGL(k_payload_finish, dim3(cdiv(fin, 256)), dim3(256), 0, s, (const StreamInfo *)e->si.p, (const int32_t *)e->dp_where.p, n_regions, (const unsigned long long *)e->dp_bed.p, nreg, pay, nbins);
+    HIPCHK(hipGetLastError());
+    layout->stats_words = 2 * GCE_STATS_WORDS; layout->n_targets = nt; layout->n_bins = nbins; layout->n_regions = n_regions; layout->total_words = words; layout->bin_off = e->h_binoff.data();
+    e->payload_words = words;
+    *payload = (const int64_t *)pay;
+    return GCE_OK;
+}
+
+// the payload (or the sum gce_stats_payload_sum left on this engine's device) on the host
+int gce_stats_payload_read(gce_engine *e, const int64_t *payload, int64_t n_words, int64_t *host) {
+    if (!e || !payload || !host || n_words < 0) return GCE_ERR_INVALID;
+    (void)hipSetDevice(e->prm.device);
+    if (n_words) HIPCHK(hipMemcpyAsync(host, payload, (size_t)n_words * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GCE_OK;
+}
+
+int gce_depth_stats(gce_engine *e, int32_t step, int32_t n_regions, const int32_t *r_tid, const int32_t *r_start, const int32_t *r_end, gce_depth *out) {
+    if (!e || !out) return GCE_ERR_INVALID;
+    const int64_t *pay = nullptr; gce_payload_layout lay;
+    int rc = gce_stats_payload_device(e, step, n_regions, r_tid, r_start, r_end, &pay, &lay);
+    if (rc != GCE_OK) return rc;
+    hipStream_t s = e->stream;
+    const int64_t nbins = lay.n_bins;
+    e->h_depth_pre.resize(nbins); e->h_depth_post.resize(nbins); e->h_bed_pre.assign(n_regions, 0); e->h_bed_post.assign(n_regions, 0);
+    const int64_t *d0 = pay + lay.stats_words;
+    if (nbins) { HIPCHK(hipMemcpyAsync(e->h_depth_pre.data(), d0, nbins * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(e->h_depth_post.data(), d0 + nbins, nbins * 8, hipMemcpyDeviceToHost, s)); }
+    if (n_regions) { HIPCHK(hipMemcpyAsync(e->h_bed_pre.data(), d0 + 2 * nbins, (size_t)n_regions * 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(e->h_bed_post.data(), d0 + 2 * nbins + n_regions, (size_t)n_regions * 8, hipMemcpyDeviceToHost, s)); }
     HIPCHK(hipStreamSynchronize(s));
-    e->h_bed_pre.assign(n_regions, 0); e->h_bed_post.assign(n_regions, 0);
-    for (int k = 0; k < n_regions; k++) if (where[k] >= 0) { e->h_bed_pre[k] = bp[where[k]]; e->h_bed_post[k] = bq[where[k]]; }
-    out->n_targets = nt; out->bin_off = e->h_binoff.data(); out->pre_depth = e->h_depth_pre.data(); out->post_depth = e->h_depth_post.data();
+    out->n_targets = lay.n_targets; out->bin_off = e->h_binoff.data(); out->pre_depth = e->h_depth_pre.data(); out->post_depth = e->h_depth_post.data();
     out->n_regions = n_regions; out->pre_bed = e->h_bed_pre.data(); out->post_bed = e->h_bed_post.data();
     return GCE_OK;
 }

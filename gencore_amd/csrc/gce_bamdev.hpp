@@ -727,6 +727,36 @@ int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t pla
     e->sh_tickall.release(); e->sh_shard.release(); e->sh_flag.release();
     return GCE_OK;
 }
+// The Stats payloads of several engines (gce_stats_payload_device, same step and regions on every one) added into engs[0]'s, device to device.
+int gce_stats_payload_sum(gce_engine **engs, int32_t n_engs, const int64_t **payload, gce_payload_layout *layout) {
+    if (!engs || n_engs < 1 || !payload || !layout || !engs[0]) return GCE_ERR_INVALID;
+    gce_engine *e = engs[0];
+    const int nt = (int)e->target_len.size();
+    if (e->h_binoff.size() != (size_t)nt + 1 || !e->dp_depth.p) return fail(e, GCE_ERR_INVALID, "gce_stats_payload_sum before gce_stats_payload_device");
+    const int64_t nbins = e->h_binoff[nt];
+    // (the number of regions is what is left of the buffer behind the Stats blocks and the bins: every engine was given the same list)
+    for (int r = 1; r < n_engs; r++) if (!engs[r] || engs[r]->h_binoff != e->h_binoff || !engs[r]->dp_depth.p || engs[r]->payload_words != e->payload_words) return fail(e, GCE_ERR_INVALID, "gce_stats_payload_sum: the engines' payloads differ in shape");
+    const int64_t words = e->payload_words;
+    (void)hipSetDevice(e->prm.device);
+    hipStream_t s = e->stream;
+    if (n_engs > 1) {
+        DevBuf tmp; HIPCHK(tmp.ensure((size_t)words * 8 + 64));
+        for (int r = 1; r < n_engs; r++) {
+            gce_engine *x = engs[r];
+            (void)hipSetDevice(x->prm.device); HIPCHK(hipStreamSynchronize(x->stream)); (void)hipSetDevice(e->prm.device);      // x's payload kernels are through
+            const hipError_t ce = x->prm.device == e->prm.device ? hipMemcpyAsync(tmp.p, x->dp_depth.p, (size_t)words * 8, hipMemcpyDeviceToDevice, s)
+                                                                  : hipMemcpyPeerAsync(tmp.p, e->prm.device, x->dp_depth.p, x->prm.device, (size_t)words * 8, s);
+            if (ce != hipSuccess) return fail(e, GCE_ERR_HIP, "payload sum: device-to-device copy");
+            hipLaunchKernelGGL(k_add_i64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, e->dp_depth.as<long long>(), (const long long *)tmp.p, (int)words);
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        tmp.release();
+    }
+    layout->stats_words = 2 * GCE_STATS_WORDS; layout->n_targets = nt; layout->n_bins = nbins; layout->n_regions = (int32_t)((words - 2 * GCE_STATS_WORDS - 2 * nbins) / 2); layout->total_words = words;
+    layout->bin_off = e->h_binoff.data();
+    *payload = e->dp_depth.as<int64_t>();
+    return GCE_OK;
+}
 // After every engine's gce_raw_build_output: the shards' record streams (each in bamComp order) merged into ONE stream in bamComp order over the
 // whole file -- (tid, pos, mtid, mpos, isize, place in the input stream), gencore.h:19-47 -- in engs[0]'s output buffer, so that the writer
 // streams it like a single engine's; the Stats blocks summed device to device into engs[0]'s (no host bounce of the blocks, no collective).

@@ -284,6 +284,24 @@ typedef struct gce_depth {
 int gce_depth_stats(gce_engine *e, int32_t coverage_step, int32_t n_regions, const int32_t *region_tid, const int32_t *region_start,
                     const int32_t *region_end, gce_depth *out);
 
+/* Everything the final Stats merge of a multi-GPU run adds up, as ONE int64 buffer in DEVICE memory (counters + histogram + per-contig depth
+ * bins + BED region counts; the buffers the reference makes at src/gencore.cpp:181-184 and fills at src/stats.cpp:39-46,56-83, src/bed.cpp:64-79):
+ *     [pre Stats: GCE_STATS_WORDS][post Stats: GCE_STATS_WORDS][pre depth: n_bins][post depth: n_bins][pre BED counts: n_regions][post BED counts: n_regions]
+ * Every word is additive over key-range shards of one stream: N ranks merge it with one all-reduce(sum) over RCCL (bench.py), N engines of one process with one
+ * add per engine (gce_run_bam_depth).  Depth bins as in gce_depth (1 + target_len / coverage_step per contig, contigs back to back; bin_off: host array of
+ * n_targets + 1 entries owned by the engine); BED counts in the order the regions were given (a region whose contig is not in the header counts 0).
+ * Valid until the next gce_process / gce_depth_stats / gce_stats_payload_device of this engine.  (Addition under ABI v3, round 5.) */
+typedef struct gce_payload_layout {
+    int32_t stats_words;          /* 2 * GCE_STATS_WORDS */
+    int32_t n_targets;
+    int64_t n_bins;               /* depth bins of one block (pre or post) */
+    int32_t n_regions;
+    int64_t total_words;          /* stats_words + 2 * n_bins + 2 * n_regions */
+    const int64_t *bin_off;       /* [n_targets + 1] */
+} gce_payload_layout;
+int gce_stats_payload_device(gce_engine *e, int32_t coverage_step, int32_t n_regions, const int32_t *region_tid, const int32_t *region_start,
+                             const int32_t *region_end, const int64_t **payload, gce_payload_layout *layout);
+
 int gce_get_timing(gce_engine *e, gce_timing *out);
 /* The two Stats blocks of the last gce_process in DEVICE memory: 2 x GCE_STATS_WORDS int64, pre then post -- for the final Stats merge
  * of a multi-GPU run (one RCCL all-reduce(sum); all fields are additive, src/stats.h:47-65) without a bounce through the host. */
@@ -456,6 +474,31 @@ int gce_run_bam_sharded_hostcodec(const char *in_path, const char *out_path, con
 int gce_raw_attach_mirror(gce_engine *e, gce_engine *mirror);
 int gce_raw_select_shard(gce_engine *e, int32_t world, int32_t rank, int32_t plan_mode);
 int gce_raw_merge_outputs(gce_engine **engs, int32_t n_engs, uint64_t *body_bytes, int64_t *n_out_total, gce_stats *pre, gce_stats *post, int64_t *n_reads_total);
+/*   gce_stats_payload_sum (after every engine's gce_stats_payload_device with the same step and regions): the payloads of engs[1..] added into
+ *     engs[0]'s in device memory (device-to-device copies, no host bounce, no collective): the merged depth / BED vectors of one file over several engines. */
+int gce_stats_payload_sum(gce_engine **engs, int32_t n_engs, const int64_t **payload, gce_payload_layout *layout);
+/* The payload (an engine's own, or the sum on engs[0]) copied to the host: n_words int64. */
+int gce_stats_payload_read(gce_engine *e, const int64_t *payload, int64_t n_words, int64_t *host);
+
+/* gce_run_bam / gce_run_bam_sharded WITH the depth statistics of the reference's report (Options::coverageStep, Options::bedFile; src/stats.cpp:56-83,
+ * src/bed.cpp:64-79,111-168): n_shards == 1 runs one engine on devices[0] (devices NULL: params->device), n_shards > 1 the sharded runner on the GPU
+ * codec.  After the consensus run every engine computes its Stats payload on its GPU (gce_stats_payload_device: the reads it holds are resident),
+ * the payloads are summed in device memory (gce_stats_payload_sum) and come back here once.  bed_path may be NULL (no regions).  The arrays of
+ * `depth` are malloc'ed: gce_depth_run_free.  depth->pre / post are the Stats blocks AS THEY WERE SUMMED IN THE PAYLOAD (equal to out->pre / out->post). */
+typedef struct gce_depth_run {
+    int32_t  n_targets;
+    int64_t  n_bins;
+    int64_t *bin_off;             /* [n_targets + 1] */
+    int64_t *pre_depth, *post_depth;      /* [n_bins] */
+    int32_t  n_regions;
+    int32_t *region_tid, *region_start, *region_end;   /* the BED file's regions in file order (gce_bed_load) */
+    int64_t *pre_bed, *post_bed;          /* [n_regions] */
+    gce_stats pre, post;
+    int64_t  payload_bytes;       /* size of the one buffer a multi-GPU run merges */
+} gce_depth_run;
+int gce_run_bam_depth(const char *in_path, const char *out_path, const char *fasta_path, const char *bed_path, int32_t coverage_step, const gce_params *params,
+                      int32_t n_shards, const int32_t *devices, int32_t plan_mode, int threads, int level, gce_bam_run *out, gce_depth_run *depth, char err[256]);
+void gce_depth_run_free(gce_depth_run *depth);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,9 @@ def test_two_ranks_equal_one_engine(built):
     for blk in ("pre", "post"):
         assert a[blk] == b[blk], (blk, a[blk], b[blk])
     assert a["pre_hist_sum"] == b["pre_hist_sum"] and a["post_hist_sum"] == b["post_hist_sum"]
+    # the depth bins and BED region counts travel in the same buffer (gce_stats_payload_device): sums and position-weighted checksums of the four vectors
+    assert a["depth"] == b["depth"] and a["depth"]["pre_depth"]["sum"] > a["depth"]["post_depth"]["sum"] > 0 and a["depth"]["pre_bed"]["sum"] > 0
+    assert b["depth"]["payload_bytes"] == 8 * (228 + 2 * b["depth"]["depth_bins"] + 2 * b["depth"]["bed_regions"])
     assert two["value"] > 0 and two["config"]["pairs_per_gpu"] > 0
 
 

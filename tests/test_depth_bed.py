@@ -98,3 +98,36 @@ def test_depth_stats_on_the_engine(built, oracle, workload, n_pairs, step, shuff
     assert np.array_equal(g_pre_d, pre_d) and np.array_equal(g_post_d, post_d)
     assert np.array_equal(g_pre_b, pre_b) and np.array_equal(g_post_b, post_b)
     assert pre_d.sum() > post_d.sum() > 0 and (workload != "cfg3" or pre_b.sum() > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n_pairs,shards,mode,step", [("cfg3", 30000, 1, 0, 10000), ("cfg3", 30000, 3, 0, 10000), ("cfg2", 20000, 4, 0, 1000), ("cfg5", 3000, 2, 1, 250)])
+def test_file_runners_carry_the_depth_statistics(built, oracle, tmp_path, workload, n_pairs, shards, mode, step):
+    """gce_run_bam_depth: the file runners (one engine, and the sharded runner on the GPU codec: several engines on device 0 here) with Options::coverageStep and
+    a BED file.  Every engine adds up its own reads and records on its GPU (gce_stats_payload_device), the payloads -- Stats blocks + depth bins + region counts in
+    ONE buffer -- are summed in device memory (gce_stats_payload_sum).  Depth bins and region counts equal the oracle's over the whole stream
+    (src/stats.cpp:56-83, src/bed.cpp:64-79), the Stats blocks inside the payload equal the runner's own."""
+    import pybam
+    from gencore_amd.bamio import run_bam_depth
+    from test_bamio import records_of
+    d, batch, prm0, regions = depth_case(workload, n_pairs)
+    tl = np.asarray(d.target_len, np.uint32)
+    targets = [("chr%d" % (i + 1), int(l)) for i, l in enumerate(tl)]
+    src, dst, bed = (str(tmp_path / x) for x in ("in.bam", "out.bam", "panel.bed"))
+    pybam.write_bam(src, records_of(batch), targets)
+    with open(bed, "w") as f:
+        f.write("# panel\n")
+        for t, a, z in regions:
+            f.write("chr%d\t%d\t%d\tr\n" % (t + 1, a, z))
+        f.write("chrNotInHeader\t5\t50\tx\n")                                    # kept in the list with tid -1 (bed.cpp:151-166 drops it from the map): counts 0
+    want_t = oracle.run(batch, prm0, [])                                         # (no FASTA in either run)
+    off, pre_d, post_d, pre_b, post_b = oracle.depth_stats(batch, want_t, d.target_len, step, regions)
+    prm = default_params(umi_prefix="auto", cluster_size_req=d.info["supporting_reads"])
+    run, got = run_bam_depth(src, dst, prm, [0] * shards, step, bed=bed, plan_mode=mode, threads=4)
+    assert run.n_out > 0 and got["regions"][:len(regions)] == regions and got["regions"][-1][0] == -1
+    assert np.array_equal(got["bin_off"], off)
+    assert np.array_equal(got["pre_depth"], pre_d) and np.array_equal(got["post_depth"], post_d)
+    assert np.array_equal(got["pre_bed"][:-1], pre_b) and np.array_equal(got["post_bed"][:-1], post_b) and got["pre_bed"][-1] == 0 and got["post_bed"][-1] == 0
+    assert got["pre"] == bytes(run.pre) and got["post"] == bytes(run.post)
+    assert got["pre"] == bytes(want_t.pre) and got["post"] == bytes(want_t.post)
+    assert got["payload_bytes"] == 8 * (2 * 114 + 2 * len(pre_d) + 2 * (len(regions) + 1))

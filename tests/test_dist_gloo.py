@@ -29,14 +29,20 @@ def _worker(rank, world, port, seed, q):
     tick, ev_tid, ev_pos = stream_context(batch.core, over["flush_period"])
     sub, idx = shard_by_plan(batch, plan_shards(batch.core, world, "range"), rank, tick)
     r = oracle_py.run(sub, fuzzgen.make_params(over, contig_len), reference, events=(ev_tid, ev_pos))
-    stats = torch.from_numpy(np.concatenate([r.pre.as_array(), r.post.as_array()]))
+    # the payload of the final Stats merge (gce_stats_payload_device lays it out the same way): both Stats blocks, the per-contig depth bins
+    # and the BED region counts of this rank's reads and records, ONE buffer, ONE all-reduce(sum)
+    step, regions = 50, [(0, 10 * k, 10 * k + 35) for k in range(0, int(contig_len[0]) // 10, 7)]
+    off, pre_d, post_d, pre_b, post_b = oracle_py.depth_stats(sub, r, contig_len, step, regions)
+    stats = torch.from_numpy(np.concatenate([r.pre.as_array(), r.post.as_array(), pre_d, post_d, pre_b, post_b]))
     dist.barrier()
-    dist.all_reduce(stats)                     # the final Stats merge
+    dist.all_reduce(stats)
     n_out = torch.tensor([int((r.out_flag != 0).sum())])
     dist.all_reduce(n_out)
     if rank == 0:
         whole = oracle_py.run(batch, fuzzgen.make_params(over, contig_len), reference)
-        want = np.concatenate([whole.pre.as_array(), whole.post.as_array()])
+        _, w_pre_d, w_post_d, w_pre_b, w_post_b = oracle_py.depth_stats(batch, whole, contig_len, step, regions)
+        want = np.concatenate([whole.pre.as_array(), whole.post.as_array(), w_pre_d, w_post_d, w_pre_b, w_post_b])
+        assert w_pre_d.sum() > 0 and w_pre_b.sum() > 0
         q.put((bool(np.array_equal(stats.numpy(), want)), int(n_out.item()), int((whole.out_flag != 0).sum())))
     dist.destroy_process_group()
 
