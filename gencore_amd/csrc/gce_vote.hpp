@@ -31,6 +31,16 @@
 // (-> k_score2 scores just those pairs).
 #pragma once
 
+#ifdef VB_BIG              // experiment: 512 threads per batch of weight 192 (32 groups, 64 sides: still one wave for the per-side phases), four workgroups per CU
+#define VB_T 512
+#define VB_W 192
+#define VB_GDIV 32
+#define VB_CCAP 512
+#define VB_RCAP 768
+#endif
+#ifndef VB_GDIV
+#define VB_GDIV 16
+#endif
 #ifndef VB_T
 #define VB_T 256           // threads per batch
 #endif
@@ -38,8 +48,8 @@
 #define VB_W 96            // batch capacity in weight units (weight of a group = max(pairs, VB_MINW); a handed-on deep group takes a whole batch).  64 -> 96 in round 4:
                            // a batch's fixed phases and barriers carry half as many pairs again and pass A fills its lanes (k_vote 3.07 -> 2.89 ms)
 #endif
-static_assert(VB_W + 32 <= 128, "P1 finds a pair's group by a bytewise compare of 7-bit pair indices");
-#define VB_MINW (VB_W / 16) // smallest weight of a group: <= 16 groups per batch (P1's bytewise group search, one lane per (group, side) in a wave)
+static_assert(VB_W + 32 <= 256, "pair indices of a batch are bytes");
+#define VB_MINW (VB_W / VB_GDIV) // smallest weight of a group: <= 16 (32) groups per batch (one lane per (group, side) in a wave)
 #define VB_MAXG (VB_W / VB_MINW)
 #define VB_MAXP (VB_W + 32)                // a batch's last group may reach over the end: < VB_W + 32 pairs
 #define VB_SIDES (2 * VB_MAXG)
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
     __shared__ uint16_t s_ipre[VB_PRE], s_cpre[VB_PRE];                            // (entries behind VB_SIDES: 0xFFFF, see vb_find_wave)
     __shared__ uint8_t s_wbase[VB_SIDES][VB_COLS / 32];                            // place in the SIDE's contested-column list (<= VB_SMAX) of the first column of every 32-column word (P5b -> P7)
-    __shared__ __attribute__((aligned(16))) uint8_t s_glp0[VB_MAXG];
+    __shared__ __attribute__((aligned(16))) uint16_t s_glp0[VB_MAXG];              // first pair of every group (unused entries: 0x7FFF)
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
     __shared__ int s_ng, s_np;
     __shared__ uint8_t s_ord[VB_SIDES];                                            // pass A: the sides in the order of their depth (P2b)
@@ -222,9 +232,9 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         const int ng = __popcll(im);                                                   // (groups of a batch are consecutive: im = low bits)
         int x = deep ? 0 : (int)np, pre = x;
         pre = wave_scan_incl(pre);
-        if (in) { s_ggi[lane] = gi; s_gbeg[lane] = gb_; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint8_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
+        if (in) { s_ggi[lane] = gi; s_gbeg[lane] = gb_; s_gnp[lane] = (uint8_t)(deep ? 0u : np); s_glp0[lane] = (uint16_t)(pre - x); s_gflag[lane] = deep ? 1 : 0; }
         if (lane == ng - 1) s_np = pre;
-        if (lane < VB_MAXG && !in) s_glp0[lane] = 127;                                 // (P1's bytewise search)
+        if (lane < VB_MAXG && !in) s_glp0[lane] = 0x7FFF;                              // (P1's packed search)
         if (lane == 0) s_ng = ng;
         if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
@@ -250,13 +260,16 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     VB_TICK(0);
     // ---------------------------------------------------------------- P1: pairs -> read descriptors, overlap window
     if (tid < npairs) {
-        // group of the pair = (number of groups that start at or in front of it) - 1: the 16 starts (< 127; unused entries hold 127) in one
-        // LDS load, compared bytewise -- (0x80 | tid) - start keeps bit 7 iff start <= tid, no borrow crosses a byte
-        int j;
+        // group of the pair = (number of groups that start at or in front of it) - 1: the starts (< 0x7FFF; unused entries hold 0x7FFF) as 16-bit
+        // halves of LDS words, compared in pairs -- (0x8000 | tid) - start keeps bit 15 iff start <= tid, no borrow crosses a half
+        int j = -1;
         {
-            const uint4 g4 = *reinterpret_cast<const uint4 *>(s_glp0);
-            const uint32_t tb = 0x80808080u | (0x01010101u * (uint32_t)tid);
-            j = __popc((tb - g4.x) & 0x80808080u) + __popc((tb - g4.y) & 0x80808080u) + __popc((tb - g4.z) & 0x80808080u) + __popc((tb - g4.w) & 0x80808080u) - 1;
+            const uint32_t tb = 0x80008000u | (0x00010001u * (uint32_t)tid);
+#pragma unroll
+            for (int q = 0; q < VB_MAXG / 8; q++) {
+                const uint4 g4 = reinterpret_cast<const uint4 *>(s_glp0)[q];
+                j += __popc((tb - g4.x) & 0x80008000u) + __popc((tb - g4.y) & 0x80008000u) + __popc((tb - g4.z) & 0x80008000u) + __popc((tb - g4.w) & 0x80008000u);
+            }
         }
         const uint32_t slot = s_gbeg[j] + (uint32_t)(tid - (int)s_glp0[j]);
         const uint32_t L = w.gpl[slot], R = w.gpr[slot];
@@ -581,7 +594,8 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         // sides [s0, s1): the longest run whose columns fit (a side has <= VB_SMAX of them).  One look per lane and a ballot -- the walk
         // `while (s_cpre[s1 + 1] - s_cpre[s0] <= VB_CCAP) s1++` was 32 dependent LDS round trips in every wave of the block
         const int fits_ = lane < VB_SIDES && (lane < s0 || (int)s_cpre[lane + 1] - (int)s_cpre[s0] <= VB_CCAP);
-        const int s1 = __ffsll((long long)~__ballot(fits_)) - 1;                                // first side that does not fit (prefixes ascend: every later one does not either); 32 if all do
+        const unsigned long long nofit_ = ~__ballot(fits_);
+        const int s1 = nofit_ ? __ffsll((long long)nofit_) - 1 : 64;                            // first side that does not fit (prefixes ascend: every later one does not either); VB_SIDES if all do
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
