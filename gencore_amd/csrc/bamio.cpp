@@ -1385,29 +1385,33 @@ static int run_bam_impl(const char *in_path, const char *out_path, const char *f
         lap("up to the header");
         int r2;
         if (devices) prm.device = devices[0];
-        if ((r2 = gce_create(&prm, &e)) != GCE_OK) { emsg = gce_status_message(r2); return r2; }
-        for (int32_t r = 1; r < n_shards; r++) {                                          // one engine per further shard, on its own device
-            gce_params pr = prm; pr.device = devices[r];
-            gce_engine *x = nullptr;
-            if ((r2 = gce_create(&pr, &x)) != GCE_OK) { emsg = gce_status_message(r2); return r2; }
-            mir.push_back(x);
-        }
-        if (getenv("GCE_RAW_TIMING")) fprintf(stderr, "gce_run_bam: RSS after gce_create %ld MB\n", status_kb("VmRSS:") >> 10);
+        // One host thread per engine: gce_create, the reference, and the raw stream's buffers (gce_raw_begin: a few GB of hipMalloc per engine, 0.15 s per GB on a
+        // fresh process -- the four engines of a sharded run, set up one after the other, were 0.4 - 1.7 s of "input pipeline" on some boxes) side by side; on a
+        // multi-GPU node every device allocates for itself.  The FASTA file is read once, in front.
+        int32_t nc = 0; const char *const *ids = nullptr; const char *const *seqs = nullptr; const int64_t *flen = nullptr;
         if (fasta_path && *fasta_path) {
             if ((r2 = gce_fasta_load(fasta_path, threads, &fa)) != GCE_OK) { emsg = "cannot read the FASTA file"; return r2; }
-            int32_t nc; const char *const *ids; const char *const *seqs; const int64_t *flen;
             gce_fasta_get(fa, &nc, &ids, &seqs, &flen);
-            for (int32_t r = 0; r < n_shards; r++) {
-                gce_engine *x = r ? mir[(size_t)r - 1] : e;
-                for (size_t t = 0; t < lens.size(); t++)                                 // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
-                    for (int32_t c = 0; c < nc; c++)
-                        if (names[t] == ids[c] && (r2 = gce_set_reference_ascii(x, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { emsg = gce_last_error(x); return r2; }
-            }
-            gce_fasta_free(fa); fa = nullptr;                                            // (packed in HBM: the host copy goes)
         }
-        lap("gce_create + reference");
-        if ((r2 = gce_raw_begin(e, capacity)) != GCE_OK) { emsg = gce_last_error(e); return r2; }
-        for (gce_engine *x : mir) if ((r2 = gce_raw_begin(x, capacity)) != GCE_OK || (r2 = gce_raw_attach_mirror(e, x)) != GCE_OK) { emsg = gce_last_error(x); return r2; }
+        std::vector<gce_engine *> made((size_t)std::max(n_shards, 1), nullptr);
+        std::vector<int> rcs((size_t)made.size(), GCE_OK); std::vector<std::string> msgs(made.size());
+        auto setup = [&](int32_t r) {
+            gce_params pr = prm; if (devices) pr.device = devices[r];
+            gce_engine *x = nullptr; int c2;
+            if ((c2 = gce_create(&pr, &x)) != GCE_OK) { rcs[(size_t)r] = c2; msgs[(size_t)r] = gce_status_message(c2); return; }
+            made[(size_t)r] = x;
+            for (size_t t = 0; t < lens.size() && fa; t++)                               // Reference::getData looks contigs up by BAM target name (reference.cpp:43-53)
+                for (int32_t c = 0; c < nc; c++)
+                    if (names[t] == ids[c] && (c2 = gce_set_reference_ascii(x, (int32_t)t, seqs[c], flen[c])) != GCE_OK) { rcs[(size_t)r] = c2; msgs[(size_t)r] = gce_last_error(x); return; }
+            if ((c2 = gce_raw_begin(x, capacity)) != GCE_OK) { rcs[(size_t)r] = c2; msgs[(size_t)r] = gce_last_error(x); }
+        };
+        if (made.size() == 1) setup(0);
+        else { std::vector<std::thread> th; for (int32_t r = 0; r < n_shards; r++) th.emplace_back(setup, r); for (auto &t : th) t.join(); }
+        e = made[0]; for (size_t r = 1; r < made.size(); r++) if (made[r]) mir.push_back(made[r]);       // (owned by `done` from here on)
+        if (fa) { gce_fasta_free(fa); fa = nullptr; }                                    // (packed in HBM: the host copy goes)
+        for (size_t r = 0; r < made.size(); r++) if (rcs[r] != GCE_OK) { emsg = msgs[r]; return rcs[r]; }
+        lap("gce_create + reference + gce_raw_begin (a thread per engine)");
+        for (gce_engine *x : mir) if ((r2 = gce_raw_attach_mirror(e, x)) != GCE_OK) { emsg = gce_last_error(x); return r2; }
         return GCE_OK;
     };
     auto bam_header_bytes = [&]() {                                                       // BAM magic, text, contig table (SAMv1 4.2)

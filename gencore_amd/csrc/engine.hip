@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -21,15 +22,20 @@
 
 namespace {
 
+// what the calling thread spent in hipMalloc / hipFree (GCE_RAW_TIMING prints it per gce_process: the question behind the sharded runner's slow boxes)
+static thread_local double t_alloc_s = 0.0; static thread_local long t_alloc_n = 0; static thread_local size_t t_alloc_bytes = 0;
+static inline double mono_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
+        const double t0 = mono_s();
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        t_alloc_s += mono_s() - t0; t_alloc_n++; t_alloc_bytes += want;
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -554,7 +560,17 @@ static void si_canary(gce_engine *e, const char *phase) {
 #endif
 
 // Every clusterByUMI of the stream (src/gencore.cpp:355 periodic, :409 end of file) + outputPair bookkeeping + the output order.
+static int gce_process_impl(gce_engine *e);
 int gce_process(gce_engine *e) {
+    static const bool tlog = getenv("GCE_RAW_TIMING") != nullptr;
+    if (!tlog) return gce_process_impl(e);
+    const double a0 = t_alloc_s, w0 = mono_s(); const long n0 = t_alloc_n; const size_t b0 = t_alloc_bytes;
+    const int rc = gce_process_impl(e);
+    fprintf(stderr, "gce_process (device %d): %.4f s wall, of it %.4f s in %ld hipMalloc / hipFree calls for %.2f GB; kernels %.1f ms\n", e ? e->prm.device : -1, mono_s() - w0, t_alloc_s - a0, t_alloc_n - n0,
+            (double)(t_alloc_bytes - b0) / 1e9, e ? e->timing.total_ms : 0.0);
+    return rc;
+}
+static int gce_process_impl(gce_engine *e) {
     if (!e) return GCE_ERR_INVALID;
     if (!e->host_mode && !e->device_mode) return fail(e, GCE_ERR_INVALID, "nothing submitted");
     if (e->processed) return fail(e, GCE_ERR_INVALID, "gce_process called twice without a new submit (the stream was mutated in place)");
@@ -920,7 +936,14 @@ int gce_process(gce_engine *e) {
     //      (every read emitted): nothing here needs a host round trip.
     OutTable o{};
     if (N > 0 && e->dev_error == 0) {
-        const size_t seq_cap = hb.seq_bytes + 16 * n1 + 64, qual_cap = hb.qual_bytes + 16 * n1 + 64;
+        // worst case: every read emitted.  The sum of the reads' bytes is at most the blobs' size -- and at most reads x longest read (k_describe's lq_max, on the
+        // host since the first look at StreamInfo): on the raw-stream path the "blobs" are the whole inflated file (names, CIGARs and tags included, and the SAME
+        // 2.4 GB for bases and qualities), and sizing both outputs by it was 5 of the 9 GB an engine allocated for 8 M reads
+        size_t seq_cap = hb.seq_bytes + 16 * n1 + 64, qual_cap = hb.qual_bytes + 16 * n1 + 64;
+        if (e->h_si.lq_max >= 0) {
+            const size_t lqm = (size_t)e->h_si.lq_max;
+            seq_cap = std::min(seq_cap, n1 * ((lqm + 1) / 2 + 16) + 64); qual_cap = std::min(qual_cap, n1 * (lqm + 16) + 64);
+        }
         ENS(o_src, n1 * 4); ENS(o_kind, n1); ENS(o_qsrc, n1 * 4); ENS(o_nm, n1 * 4); ENS(o_fr, n1 * 2); ENS(o_rr, n1 * 2); ENS(o_mate, n1 * 4);
         ENS(o_soff, n1 * 8); ENS(o_qoff, n1 * 8); ENS(o_seq, seq_cap); ENS(o_qual, qual_cap);
         ENS(o_key, n1 * sizeof(OutKey)); ENS(o_rec, n1 * sizeof(OutRec)); ENS(o_ksoff, n1 * 8); ENS(o_kqoff, n1 * 8); ENS(o_krow, n1 * 4); const unsigned nblk_O = cdiv(n1, OUT_TILE); ENS(o_part3, (size_t)nblk_O * 24 + 64);
