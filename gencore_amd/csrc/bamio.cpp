@@ -1247,7 +1247,7 @@ int gce_run_bam_hostcodec(const char *in_path, const char *out_path, const char 
                 if (strcmp(ids[c], bi.target_name[t]) == 0 && (rc = gce_set_reference_ascii(e, t, seqs[c], lens[c])) != GCE_OK) return done(rc, gce_last_error(e));
     }
     double t0 = now_s();
-    if (bi.mi_bytes == 0) { if ((rc = gce_reserve(e, bi.n_records, bi.qname_bytes, bi.cigar_words, bi.seq_bytes, bi.qual_bytes)) != GCE_OK) return done(rc, gce_last_error(e)); }
+    if ((rc = gce_reserve(e, bi.n_records, bi.qname_bytes, bi.cigar_words, bi.seq_bytes, bi.qual_bytes)) != GCE_OK) return done(rc, gce_last_error(e));     // (MI tags travel on the streamed path since round 5)
     if (chunk_reads <= 0) chunk_reads = 1 << 21;
     int32_t tickets[2] = {-1, -1};
     int64_t k = 0;
@@ -1256,7 +1256,7 @@ int gce_run_bam_hostcodec(const char *in_path, const char *out_path, const char 
         if (tickets[sl] >= 0 && (rc = gce_submit_wait(e, tickets[sl])) != GCE_OK) return done(rc, gce_last_error(e));   // the slot's previous copy
         gce_batch b;
         if ((rc = gce_bam_chunk(f, first, std::min(chunk_reads, bi.n_records - first), sl, &b)) != GCE_OK) return done(rc, "chunk");
-        if (bi.mi_bytes == 0) rc = gce_submit_async(e, &b, &tickets[sl]); else rc = gce_submit(e, &b);
+        rc = gce_submit_async(e, &b, &tickets[sl]);
         if (rc != GCE_OK) return done(rc, gce_last_error(e));
     }
     out->submit_s = now_s() - t0; t0 = now_s();

@@ -73,7 +73,7 @@ struct gce_engine {
     // streamed submission (gce_reserve): batches go straight to HBM on their own stream while the caller prepares the next one
     bool reserved = false; hipStream_t up_stream = nullptr; std::vector<hipEvent_t> up_events;
     hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2]{};      // deep streams: k_score2 beside the hand-on + k_deep_prepare (gce_process)
-    size_t rs_n = 0, rs_q = 0, rs_c = 0, rs_s = 0, rs_l = 0, st_n = 0, st_q = 0, st_c = 0, st_s = 0, st_l = 0;
+    size_t rs_n = 0, rs_q = 0, rs_c = 0, rs_s = 0, rs_l = 0, st_n = 0, st_q = 0, st_c = 0, st_s = 0, st_l = 0, st_m = 0; bool dev_concat = false;
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
@@ -257,7 +257,7 @@ int gce_reset(gce_engine *e) {
     e->h_core.clear(); e->h_qoff.clear(); e->h_coff.clear(); e->h_soff.clear(); e->h_loff.clear(); e->h_mioff.clear(); e->h_tick.clear();
     e->h_qname.clear(); e->h_mi.clear(); e->h_cigar.clear(); e->h_seq.clear(); e->h_qual.clear(); e->h_nmt.clear(); e->h_nm.clear();
     e->have_mi = e->have_tick = e->host_mode = e->device_mode = e->processed = e->raw_mode = false; e->n = 0; e->n_out = 0; e->shard_n = -1; e->shard_cut_done = false;
-    e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = 0;                     // a reservation (gce_reserve) stays
+    e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = e->st_m = 0; e->dev_concat = false;   // a reservation (gce_reserve) stays
     return GCE_OK;
 }
 
@@ -295,7 +295,7 @@ __global__ void k_add_u64(uint64_t *a, uint64_t n, uint64_t base) {
 
 // Pre-size the HBM copy of a stream whose totals are known (a BAM file that was indexed, gce_bam_get_info): from then on
 // gce_submit / gce_submit_async copy every batch straight into place -- no host staging, and the copy of batch k overlaps whatever
-// the caller does to prepare batch k + 1.  MI tags and gce_batch.tick are not supported on this path (use plain gce_submit).
+// the caller does to prepare batch k + 1.  MI tags and gce_batch.tick travel too (their buffers grow with the batches).
 int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar_words, size_t seq_bytes, size_t qual_bytes) {
     if (!e || n_reads < 0) return GCE_ERR_INVALID;
     if (e->host_mode || e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_reserve after a submit");
@@ -310,6 +310,85 @@ int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar
     return GCE_OK;
 }
 
+// a buffer of the engine's own copy of the stream that holds `used` bytes and must take `need`: kept, or replaced by a larger one with the old bytes moved
+// (on the upload stream, behind the copies already queued there)
+static hipError_t grow_keep(DevBuf &d, size_t used, size_t need, hipStream_t s) {
+    if (d.p && need <= d.cap) return hipSuccess;
+    DevBuf nb;
+    hipError_t rc = nb.ensure(need + need / 2 + 256);
+    if (rc != hipSuccess) return rc;
+    if (used && d.p && (rc = hipMemcpyAsync(nb.p, d.p, used, hipMemcpyDeviceToDevice, s)) != hipSuccess) { nb.release(); return rc; }
+    if ((rc = hipStreamSynchronize(s)) != hipSuccess) { nb.release(); return rc; }
+    d.release(); d = nb;
+    return hipSuccess;
+}
+__global__ void k_rebase_mioff(uint64_t *a, uint64_t n, uint64_t base) {     // MI offsets of a batch -> offsets of the stream (UINT64_MAX = no tag stays)
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != 0xFFFFFFFFFFFFFFFFull) a[i] += base;
+}
+
+// One batch behind the batches the engine's own copy of the stream already holds (b_* buffers, st_* fill levels), asynchronously on the upload stream: from host
+// memory (gce_submit_async / gce_submit on a reserved engine) or from device memory (the second and further gce_submit_device of a stream).  The buffers grow when
+// there is no reservation or the batch exceeds it.  MI tags and per-read ticks travel too (round 5: a UMI-tagged file, or a key-range shard, through the streamed
+// path -- bamutil.cpp:23-38, gencore.cpp:319-322).
+static int append_batch(gce_engine *e, const gce_batch *b, hipMemcpyKind kind) {
+    const size_t n = (size_t)b->n_reads;
+    if (!n) return GCE_OK;
+    if (!b->core || !b->qname_off || !b->qname || !b->cigar_off || !b->seq_off || !b->seq || !b->qual_off || !b->qual || !b->nm || !b->nm_type)
+        return fail(e, GCE_ERR_INVALID, "null array in gce_batch");
+    if (e->st_n > 0 && (b->tick != nullptr) != e->have_tick) return fail(e, GCE_ERR_INVALID, "gce_batch.tick must be given for every batch of a stream or for none");
+    if (!e->up_stream) HIPCHK(hipStreamCreate(&e->up_stream));
+    hipStream_t s = e->up_stream;
+    const bool mi = b->mi && b->mi_off;
+    HIPCHK(grow_keep(e->b_core, e->st_n * sizeof(gce_core), (e->st_n + n) * sizeof(gce_core) + 64, s)); HIPCHK(grow_keep(e->b_nm, e->st_n * 4, (e->st_n + n) * 4 + 64, s)); HIPCHK(grow_keep(e->b_nmt, e->st_n, e->st_n + n + 64, s));
+    HIPCHK(grow_keep(e->b_qoff, e->st_n * 8, (e->st_n + n) * 8 + 64, s)); HIPCHK(grow_keep(e->b_coff, e->st_n * 8, (e->st_n + n) * 8 + 64, s));
+    HIPCHK(grow_keep(e->b_soff, e->st_n * 8, (e->st_n + n) * 8 + 64, s)); HIPCHK(grow_keep(e->b_loff, e->st_n * 8, (e->st_n + n) * 8 + 64, s));
+    HIPCHK(grow_keep(e->b_qname, e->st_q, e->st_q + b->qname_bytes + 64, s)); HIPCHK(grow_keep(e->b_cigar, e->st_c * 4, (e->st_c + b->cigar_words) * 4 + 64, s));
+    HIPCHK(grow_keep(e->b_seq, e->st_s, e->st_s + b->seq_bytes + 64, s)); HIPCHK(grow_keep(e->b_qual, e->st_l, e->st_l + b->qual_bytes + 64, s));
+    auto cp = [&](DevBuf &d, size_t at, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync((char *)d.p + at, src, bytes, kind, s) : hipSuccess; };
+    HIPCHK(cp(e->b_core, e->st_n * sizeof(gce_core), b->core, n * sizeof(gce_core)));
+    HIPCHK(cp(e->b_nm, e->st_n * 4, b->nm, n * 4)); HIPCHK(cp(e->b_nmt, e->st_n, b->nm_type, n));
+    HIPCHK(cp(e->b_qoff, e->st_n * 8, b->qname_off, n * 8)); HIPCHK(cp(e->b_coff, e->st_n * 8, b->cigar_off, n * 8));
+    HIPCHK(cp(e->b_soff, e->st_n * 8, b->seq_off, n * 8)); HIPCHK(cp(e->b_loff, e->st_n * 8, b->qual_off, n * 8));
+    HIPCHK(cp(e->b_qname, e->st_q, b->qname, b->qname_bytes)); HIPCHK(cp(e->b_cigar, e->st_c * 4, b->cigar, b->cigar_words * 4));
+    HIPCHK(cp(e->b_seq, e->st_s, b->seq, b->seq_bytes)); HIPCHK(cp(e->b_qual, e->st_l, b->qual, b->qual_bytes));
+    const unsigned nb = (unsigned)((n + 255) / 256);                                // offsets of the batch -> offsets of the stream
+    if (e->st_q) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_qoff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_q);
+    if (e->st_c) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_coff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_c);
+    if (e->st_s) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_soff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_s);
+    if (e->st_l) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_loff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_l);
+    if (b->tick) {
+        HIPCHK(grow_keep(e->b_tick, e->st_n * 8, (e->st_n + n) * 8 + 64, s));
+        HIPCHK(cp(e->b_tick, e->st_n * 8, b->tick, n * 8));
+        e->have_tick = true;
+    }
+    if (mi || e->have_mi) {                                                         // MI offsets: UINT64_MAX for the reads of batches without tags
+        const bool first = !e->have_mi;
+        HIPCHK(grow_keep(e->b_mioff, first ? 0 : e->st_n * 8, (e->st_n + n) * 8 + 64, s));
+        if (first && e->st_n) HIPCHK(hipMemsetAsync(e->b_mioff.p, 0xFF, e->st_n * 8, s));
+        if (mi) {
+            HIPCHK(grow_keep(e->b_mi, e->st_m, e->st_m + b->mi_bytes + 64, s));
+            HIPCHK(cp(e->b_mioff, e->st_n * 8, b->mi_off, n * 8)); HIPCHK(cp(e->b_mi, e->st_m, b->mi, b->mi_bytes));
+            if (e->st_m) hipLaunchKernelGGL(k_rebase_mioff, dim3(nb), dim3(256), 0, s, e->b_mioff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_m);
+            e->st_m += b->mi_bytes;
+        } else HIPCHK(hipMemsetAsync((char *)e->b_mioff.p + e->st_n * 8, 0xFF, n * 8, s));
+        e->have_mi = true;
+    }
+    e->st_n += n; e->st_q += b->qname_bytes; e->st_c += b->cigar_words; e->st_s += b->seq_bytes; e->st_l += b->qual_bytes;
+    return GCE_OK;
+}
+// the engine's own copy of the stream as the batch gce_process works on
+static void publish_own_copy(gce_engine *e) {
+    gce_batch &d = e->dev_batch; memset(&d, 0, sizeof d);
+    d.n_reads = (int64_t)e->st_n; d.core = e->b_core.as<gce_core>();
+    d.qname_off = e->b_qoff.as<uint64_t>(); d.qname = e->b_qname.as<char>(); d.cigar_off = e->b_coff.as<uint64_t>(); d.cigar = e->b_cigar.as<uint32_t>();
+    d.seq_off = e->b_soff.as<uint64_t>(); d.seq = e->b_seq.as<uint8_t>(); d.qual_off = e->b_loff.as<uint64_t>(); d.qual = e->b_qual.as<uint8_t>();
+    d.nm = e->b_nm.as<int32_t>(); d.nm_type = e->b_nmt.as<uint8_t>();
+    d.qname_bytes = e->st_q; d.cigar_words = e->st_c; d.seq_bytes = e->st_s; d.qual_bytes = e->st_l;
+    if (e->have_mi) { d.mi_off = e->b_mioff.as<uint64_t>(); d.mi = e->b_mi.as<char>(); d.mi_bytes = e->st_m; }
+    if (e->have_tick) d.tick = e->b_tick.as<uint64_t>();
+}
+
 // One batch of a reserved stream, asynchronously: the caller's buffers must stay untouched until gce_submit_wait(ticket) (or
 // gce_process) returns.  *ticket may be NULL.
 int gce_submit_async(gce_engine *e, const gce_batch *b, int32_t *ticket) {
@@ -317,33 +396,13 @@ int gce_submit_async(gce_engine *e, const gce_batch *b, int32_t *ticket) {
     if (!e->reserved) return fail(e, GCE_ERR_INVALID, "gce_submit_async needs gce_reserve");
     if (e->device_mode && !e->processed) return fail(e, GCE_ERR_INVALID, "gce_submit after gce_submit_device");
     if (e->processed) gce_reset(e);
-    if (b->mi || b->tick) return fail(e, GCE_ERR_INVALID, "MI tags / ticks are not supported on the reserved path");
-    const size_t n = (size_t)b->n_reads;
-    if (e->st_n + n > e->rs_n || e->st_q + b->qname_bytes > e->rs_q || e->st_c + b->cigar_words > e->rs_c || e->st_s + b->seq_bytes > e->rs_s || e->st_l + b->qual_bytes > e->rs_l)
-        return fail(e, GCE_ERR_INVALID, "batch exceeds the reservation");
     (void)hipSetDevice(e->prm.device);
     e->host_mode = true;
-    hipStream_t s = e->up_stream;
-    if (n) {
-        if (!b->core || !b->qname_off || !b->qname || !b->cigar_off || !b->seq_off || !b->seq || !b->qual_off || !b->qual || !b->nm || !b->nm_type)
-            return fail(e, GCE_ERR_INVALID, "null array in gce_batch");
-        auto cp = [&](DevBuf &d, size_t at, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync((char *)d.p + at, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
-        HIPCHK(cp(e->b_core, e->st_n * sizeof(gce_core), b->core, n * sizeof(gce_core)));
-        HIPCHK(cp(e->b_nm, e->st_n * 4, b->nm, n * 4)); HIPCHK(cp(e->b_nmt, e->st_n, b->nm_type, n));
-        HIPCHK(cp(e->b_qoff, e->st_n * 8, b->qname_off, n * 8)); HIPCHK(cp(e->b_coff, e->st_n * 8, b->cigar_off, n * 8));
-        HIPCHK(cp(e->b_soff, e->st_n * 8, b->seq_off, n * 8)); HIPCHK(cp(e->b_loff, e->st_n * 8, b->qual_off, n * 8));
-        HIPCHK(cp(e->b_qname, e->st_q, b->qname, b->qname_bytes)); HIPCHK(cp(e->b_cigar, e->st_c * 4, b->cigar, b->cigar_words * 4));
-        HIPCHK(cp(e->b_seq, e->st_s, b->seq, b->seq_bytes)); HIPCHK(cp(e->b_qual, e->st_l, b->qual, b->qual_bytes));
-        const unsigned nb = (unsigned)((n + 255) / 256);                            // offsets of the batch -> offsets of the stream
-        if (e->st_q) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_qoff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_q);
-        if (e->st_c) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_coff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_c);
-        if (e->st_s) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_soff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_s);
-        if (e->st_l) hipLaunchKernelGGL(k_add_u64, dim3(nb), dim3(256), 0, s, e->b_loff.as<uint64_t>() + e->st_n, (uint64_t)n, (uint64_t)e->st_l);
-        e->st_n += n; e->st_q += b->qname_bytes; e->st_c += b->cigar_words; e->st_s += b->seq_bytes; e->st_l += b->qual_bytes;
-    }
+    int rc = append_batch(e, b, hipMemcpyHostToDevice);
+    if (rc != GCE_OK) return rc;
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev, s));
+    HIPCHK(hipEventRecord(ev, e->up_stream));
     e->up_events.push_back(ev);
     if (ticket) *ticket = (int32_t)e->up_events.size() - 1;
     return GCE_OK;
@@ -394,13 +453,30 @@ int gce_submit(gce_engine *e, const gce_batch *b) {
     return GCE_OK;
 }
 
+// Caller-owned device memory, zero copy -- for ONE batch.  A second gce_submit_device before gce_process makes the engine keep its own copy of the stream: the
+// first batch and every further one are appended device to device (round 5; before, a stream had to be one batch).  The in-place mutations of the path
+// (pair.cpp:158-159, group.cpp:525) then hit the engine's copy; the results come back through the compact blobs either way.
 int gce_submit_device(gce_engine *e, const gce_batch *b) {
     if (!e || !b || b->n_reads < 0) return GCE_ERR_INVALID;
     if (e->processed) gce_reset(e);
-    if (e->host_mode || e->device_mode) return fail(e, GCE_ERR_INVALID, "gce_submit_device takes exactly one batch per gce_process");
-    e->device_mode = true;
-    e->dev_batch = *b;
-    e->have_tick = b->tick != nullptr;
+    if (e->host_mode) return fail(e, GCE_ERR_INVALID, "gce_submit_device after gce_submit");
+    (void)hipSetDevice(e->prm.device);
+    if (!e->device_mode) {
+        e->device_mode = true; e->dev_concat = false;
+        e->dev_batch = *b;
+        e->have_tick = b->tick != nullptr;
+        return GCE_OK;
+    }
+    int rc;
+    if (!e->dev_concat) {                                                          // the batch that came first, into the engine's own buffers
+        const gce_batch first = e->dev_batch;
+        e->st_n = e->st_q = e->st_c = e->st_s = e->st_l = e->st_m = 0; e->have_tick = false; e->have_mi = false;
+        if ((rc = append_batch(e, &first, hipMemcpyDeviceToDevice)) != GCE_OK) return rc;
+        e->dev_concat = true;
+    }
+    if ((rc = append_batch(e, b, hipMemcpyDeviceToDevice)) != GCE_OK) return rc;
+    HIPCHK(hipStreamSynchronize(e->up_stream));                                    // (the caller may free its batch when this returns)
+    publish_own_copy(e);
     return GCE_OK;
 }
 
@@ -409,12 +485,7 @@ static int upload(gce_engine *e) {
         HIPCHK(hipStreamSynchronize(e->up_stream));
         for (auto ev : e->up_events) (void)hipEventDestroy(ev);
         e->up_events.clear();
-        gce_batch &d = e->dev_batch; memset(&d, 0, sizeof d);
-        d.n_reads = (int64_t)e->st_n; d.core = e->b_core.as<gce_core>();
-        d.qname_off = e->b_qoff.as<uint64_t>(); d.qname = e->b_qname.as<char>(); d.cigar_off = e->b_coff.as<uint64_t>(); d.cigar = e->b_cigar.as<uint32_t>();
-        d.seq_off = e->b_soff.as<uint64_t>(); d.seq = e->b_seq.as<uint8_t>(); d.qual_off = e->b_loff.as<uint64_t>(); d.qual = e->b_qual.as<uint8_t>();
-        d.nm = e->b_nm.as<int32_t>(); d.nm_type = e->b_nmt.as<uint8_t>();
-        d.qname_bytes = e->st_q; d.cigar_words = e->st_c; d.seq_bytes = e->st_s; d.qual_bytes = e->st_l;
+        publish_own_copy(e);
         return GCE_OK;
     }
     struct { DevBuf *d; const void *src; size_t bytes; const void **dst; } items[] = {

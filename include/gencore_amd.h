@@ -242,7 +242,9 @@ int gce_set_flush_events(gce_engine *e, int32_t n_events, const int32_t *ev_tid,
 int gce_submit(gce_engine *e, const gce_batch *batch);
 /* Same, but every pointer in *batch is a DEVICE pointer that stays valid until the next gce_submit_device / gce_reset /
  * gce_destroy; seq/qual are mutated in place in the caller's HBM buffers (zero-copy path used by bench.py and by a
- * GPU BAM decoder).  One batch per gce_process. */
+ * GPU BAM decoder).  ONE batch per gce_process is zero copy.  Further calls before gce_process append to the stream (round 5): the engine then keeps its
+ * own copy -- the first batch and every further one are copied device to device when the second call is made; a batch may be freed as soon as the call that
+ * appended it returns, and the in-place mutations hit the engine's copy (results come back through the compact blobs of gce_result either way). */
 int gce_submit_device(gce_engine *e, const gce_batch *batch);
 
 /* Replaces: every clusterByUMI call of the stream (src/gencore.cpp:355 periodic, :409 end of file), the
@@ -261,7 +263,8 @@ int gce_result_device(gce_engine *e, gce_result *out);
  * HBM copy once, then every gce_submit / gce_submit_async copies its batch straight into place on a separate HIP stream -- the
  * copy of batch k overlaps the caller's preparation of batch k+1 (src/gencore.cpp:205-274 interleaves sam_read1 and
  * addToCluster the same way).  With gce_submit_async the caller's buffers must stay untouched until gce_submit_wait(ticket)
- * or gce_process returns.  MI tags and gce_batch.tick are not supported on this path. */
+ * or gce_process returns.  MI tags (gce_batch.mi / mi_off) and per-read ticks (gce_batch.tick; every batch of a stream or none) travel on this path too
+ * (round 5); a batch that exceeds the reservation makes the buffers grow instead of failing. */
 int gce_reserve(gce_engine *e, int64_t n_reads, size_t qname_bytes, size_t cigar_words, size_t seq_bytes, size_t qual_bytes);
 int gce_submit_async(gce_engine *e, const gce_batch *batch, int32_t *ticket);
 int gce_submit_wait(gce_engine *e, int32_t ticket);

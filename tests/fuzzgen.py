@@ -96,6 +96,7 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=Fals
                 name += ":" + ua + ("_" + ub if rng.random() < 0.5 else "")
             elif umi_mode == "duplex":
                 name += ":UMI_" + (ua + "_" + ub if strand == 0 else ub + "_" + ua)
+            mi_tag = ua if (umi_mode == "mi" and rng.random() < 0.85) else None      # MI:Z tag (bamutil.cpp:23-38); a pair without one falls back to its name
             qf = [rng.choice(QUALS) for _ in fseq]
             qr = [rng.choice(QUALS) for _ in rseq]
             if exotic:          # IUPAC codes (BAM nibbles outside A,C,G,T,N) and out-of-spec quals: generic-kernel paths
@@ -110,6 +111,8 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=Fals
             nm_type = rng.choice(["C", "C", "C", "S", "i"])
             r1 = dict(qname=name, flag=f_flag, tid=tid, pos=fp, cigar=fcg, mtid=tid, mpos=rp_, isize=tlen, seq=fseq, qual=qf, nm=fnm, nm_type=nm_type)
             r2 = dict(qname=name, flag=r_flag, tid=tid, pos=rp_, cigar=rcg, mtid=tid, mpos=fp, isize=-tlen, seq=rseq, qual=qr, nm=rnm, nm_type=nm_type)
+            if mi_tag is not None:
+                r1["mi"] = mi_tag; r2["mi"] = mi_tag
             roll = rng.random()
             if cross:                                       # mate on another contig: each read clusters alone (negative right)
                 r1.update(mtid=cross_tid, mpos=cross_pos, isize=0)
@@ -147,7 +150,7 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=Fals
         else:
             reference.append((oracle_py.pack_reference(s), len(s)))
     over = dict(
-        umi_prefix={"none": "", "prefix": "UMI", "colon": "", "duplex": "UMI"}[umi_mode],
+        umi_prefix={"none": "", "prefix": "UMI", "colon": "", "duplex": "UMI", "mi": ""}[umi_mode],
         flush_period=period if period is not None else rng.choice([7, 23, 50, 200, 10000]),
         cluster_size_req=rng.choice([1, 1, 2, 3]),
         proper_umi_diff_threshold=rng.choice([0, 1, 1, 2]),

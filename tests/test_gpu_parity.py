@@ -586,3 +586,102 @@ def test_two_stream_order_on_small_streams(built, seed, monkeypatch):
         kw["deep"] = 80
     batch, over, reference, contig_len = fuzzgen.make_case(seed, **kw)
     run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,umi_mode,use_tick", [(21, "prefix", False), (22, "mi", False), (23, "mi", True), (24, "duplex", True)])
+def test_streamed_submit_carries_mi_tags_and_ticks(built, seed, umi_mode, use_tick):
+    """gce_reserve + gce_submit_async in several batches (the streamed host path of INTEGRATION 2) with MI:Z tags (src/bamutil.cpp:23-38) and with per-read
+    global ticks + the stream's flush events (a key-range shard, src/gencore.cpp:319-322): the same result as the oracle on the whole stream.  Some batches
+    of the `mi` streams carry no tag at all (their reads fall back to the name)."""
+    import ctypes as C
+    from gencore_amd import capi
+    from gencore_amd.batch import table_from_rows
+    from gencore_amd.engine import Engine
+    from gencore_amd.shard import slice_batch, stream_context
+    from oracle import oracle_py
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=150, umi_mode=umi_mode, period=17)
+    prm = fuzzgen.make_params(over, contig_len)
+    want = oracle_py.run(batch, prm, reference)
+    assert want.status == 0
+    tick = ev = None
+    if use_tick:
+        tick, et, ep = stream_context(batch.core, over["flush_period"])
+        ev = (et, ep)
+    E = Engine(prm)
+    try:
+        for tid, (nib, ln) in enumerate(reference):
+            if nib is not None:
+                E.set_reference(tid, nib, ln)
+        if ev is not None:
+            E.set_flush_events(*ev)
+        st = batch.as_struct()
+        assert E.lib.gce_reserve(E._h, batch.n, st.qname_bytes, st.cigar_words, st.seq_bytes, st.qual_bytes) == 0
+        cuts = [0, batch.n // 5, batch.n // 2, batch.n // 2, (3 * batch.n) // 4, batch.n]
+        keep = []
+        for a, z in zip(cuts[:-1], cuts[1:]):
+            sub = slice_batch(batch, np.arange(a, z))
+            if tick is not None:
+                sub.tick = np.ascontiguousarray(tick[a:z], np.uint64)
+            keep.append(sub)
+            s2 = sub.as_struct()
+            t = C.c_int32(-1)
+            rc = E.lib.gce_submit_async(E._h, C.byref(s2), C.byref(t))
+            assert rc == 0, E.lib.gce_last_error(E._h)
+        E.finish()
+        got = E.output(batch)
+    finally:
+        E.close()
+    diffs = diff_results(batch, got, want) + check_output_order(batch, got.rows)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,umi_mode", [(31, "prefix"), (32, "mi")])
+def test_several_device_batches_per_process(built, seed, umi_mode):
+    """gce_submit_device more than once before gce_process: the engine appends the batches device to device into its own copy of the stream."""
+    import ctypes as C
+    import torch
+    from gencore_amd.engine import Engine
+    from oracle import oracle_py
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=150, umi_mode=umi_mode, period=23)
+    prm = fuzzgen.make_params(over, contig_len)
+    want = oracle_py.run(batch, prm, reference)
+    assert want.status == 0
+    E = Engine(prm)
+    try:
+        for tid, (nib, ln) in enumerate(reference):
+            if nib is not None:
+                E.set_reference(tid, nib, ln)
+        cuts = [0, batch.n // 3, (2 * batch.n) // 3, batch.n]
+        from gencore_amd.capi import GceBatch
+        from gencore_amd.shard import slice_batch
+
+        def device_struct(sub):
+            st, keep = GceBatch(), []
+            st.n_reads = sub.n
+            for f in sub.FIELDS:
+                a_ = getattr(sub, f)
+                if a_ is None or (a_.size == 0 and f in ("mi", "mi_off")):
+                    setattr(st, f, None); continue
+                raw = np.concatenate([a_.view(np.uint8).reshape(-1), np.zeros(64, np.uint8)])      # (device blobs must be readable past their end)
+                t_ = torch.from_numpy(raw).cuda()
+                keep.append(t_); setattr(st, f, t_.data_ptr())
+            st.qname_bytes, st.cigar_words, st.seq_bytes, st.qual_bytes = sub.qname.size, sub.cigar.size, sub.seq.size, sub.qual.size
+            st.mi_bytes = 0 if sub.mi is None else sub.mi.size
+            st.tick = None
+            return st, keep
+        for a, z in zip(cuts[:-1], cuts[1:]):
+            sub = slice_batch(batch, np.arange(a, z))
+            st, keep = device_struct(sub)
+            assert E.lib.gce_submit_device(E._h, C.byref(st)) == 0, E.lib.gce_last_error(E._h)
+            if a > 0:
+                del keep                                                     # (a batch behind the first may go as soon as the call returns)
+            else:
+                first_keep = keep
+        E.finish()
+        got = E.output(batch)
+    finally:
+        E.close()
+    diffs = diff_results(batch, got, want) + check_output_order(batch, got.rows)
+    assert not diffs, "\n".join(diffs)
