@@ -31,6 +31,13 @@
 // (-> k_score2 scores just those pairs).
 #pragma once
 
+#ifdef VB_WAVE             // experiment: ONE wave per batch of weight 24 (8 groups, 16 sides): no workgroup barrier waits for another wave, the bytes pass A fetched are
+#define VB_T 64            // voted on a few microseconds later
+#define VB_W 24
+#define VB_GDIV 8
+#define VB_CCAP 96
+#define VB_RCAP 160
+#endif
 #ifdef VB_BIG              // experiment: 512 threads per batch of weight 192 (32 groups, 64 sides: still one wave for the per-side phases), four workgroups per CU
 #define VB_T 512
 #define VB_W 192
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         }
     }
     for (int k = tid; k < VB_SIDES * (VB_COLS / 32); k += VB_T) (&s_cmask[0][0])[k] = 0u;
-    if (tid >= 64 && tid < 64 + VB_PRE - VB_SIDES - 1) { const int k = VB_SIDES + 1 + tid - 64; s_ipre[k] = 0xFFFF; s_cpre[k] = 0xFFFF; s_jpre[k] = 0xFFFF; }
+    { const int t2 = VB_T > 64 ? tid - 64 : tid; if (t2 >= 0 && t2 < VB_PRE - VB_SIDES - 1) { const int k = VB_SIDES + 1 + t2; s_ipre[k] = 0xFFFF; s_cpre[k] = 0xFFFF; s_jpre[k] = 0xFFFF; } }      // (the second wave, where there is one)
     if (tid >= VB_T - 4 * VB_SIDES) {                                                  // (the last waves: the first one is busy with the groups)
         const int k = tid - (VB_T - 4 * VB_SIDES);
         s_hm[k] = 0u;                                                                   // s_hm, s_single, s_vm, s_unf are adjacent

@@ -19,7 +19,7 @@ for seed in range(first, first + count):
     kw = dict(n_mol=n_mol + seed % 40, exotic=seed % 3 == 0)
     if seed % 5 == 0: kw["period"] = 3 + seed % 50
     if seed % 7 == 0: kw["deep"] = 20 + seed % 90
-    if seed % 4 == 1: kw["umi_mode"] = ("none", "prefix", "colon", "duplex")[seed // 4 % 4]
+    if seed % 4 == 1: kw["umi_mode"] = ("none", "prefix", "colon", "duplex", "mi")[seed // 4 % 5]
     b, over, ref, cl = fuzzgen.make_case(seed, **kw)
     p = fuzzgen.make_params(over, cl)
     want = oracle_py.run(b, p, ref)
