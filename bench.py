@@ -11,8 +11,10 @@ A "step" = one gce_process() pass of the whole hot path (clustering scan -> pair
 template pick + column vote -> duplex/filter/tags -> Stats -> output order + compaction) over one synthetic
 coordinate-sorted stream that is already resident in HBM (gce_submit_device).  Every step (warm-up included) gets its
 own pristine copy of the mutable seq/qual blobs, so no work is skipped or cached.
-Multi-GPU (N > 1): ONE stream of N x pairs-per-GPU pairs (default workload cfg4s = BASELINE configs[3]) is planned by
-every rank, cut into N key ranges of equal read count (gencore_amd/synth.py plan/materialise, cuts fall inside contigs);
+Multi-GPU (N > 1): ONE stream of N x pairs-per-GPU pairs is planned by every rank -- by default the workload of the one-GPU line, cfg3, N times as
+large (10 M pairs PER GPU, the panel's targets grow with the stream): the per-GPU work is what it is at N = 1, so value(N) / value(1) is a scaling
+figure (rounds 1-4 ran cfg4s = BASELINE configs[3] at N > 1, 12.5 M pairs per GPU at depth 16: another workload than the N = 1 line it is divided by;
+`--workload cfg4s` still runs it) --, cut into N key ranges of equal read count (gencore_amd/synth.py plan/materialise, cuts fall inside contigs);
 each rank materialises and processes only its own range, with the global ticks and the stream's flush events handed
 to the engine — no data-path collective, one RCCL all-reduce for the Stats merge.  Weak scaling (per-GPU work fixed).
 """
@@ -102,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4s | cfg5 (gencore_amd/synth.py); default cfg3 on 1 GPU, cfg4s on N > 1")
+    ap.add_argument("--workload", default=None, help="cfg2 | cfg3 | cfg4s | cfg5 (gencore_amd/synth.py); default cfg3 at every N (N > 1: N x as many pairs, cut into N key ranges)")
     ap.add_argument("--pairs", type=int, default=None, help="override the workload's pair count (per GPU)")
     ap.add_argument("--scale", type=float, default=None, help="genome scale of cfg3 (1.0 = hg19 lengths, the default here)")
     ap.add_argument("--bed-targets", type=int, default=None, help="override the number of BED targets of cfg3 (0 = molecules spread uniformly)")
@@ -147,7 +149,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    workload = args.workload or ("cfg3" if world == 1 else "cfg4s")
+    workload = args.workload or "cfg3"
 
     import __graft_entry__ as ge
     if rank == 0:

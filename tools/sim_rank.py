@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """What rank R of an N-GPU `bench.py --gpus N` run does, on ONE GPU and without torch.distributed: plan the whole cfg4s stream,
-materialise the rank's key range, run one engine step with ticks + flush events.  python tools/sim_rank.py RANK WORLD [pairs_per_gpu]"""
+materialise the rank's key range, run one engine step with ticks + flush events.  python tools/sim_rank.py RANK WORLD [pairs_per_gpu] [workload: cfg3 (bench.py's default at every N since round 5) | cfg4s]"""
 import ctypes as C
 import os
 import sys
@@ -14,11 +14,12 @@ import bench  # noqa: E402
 from gencore_amd import capi, synth  # noqa: E402
 
 rank, world = int(sys.argv[1]), int(sys.argv[2])
-per_gpu = int(sys.argv[3]) if len(sys.argv) > 3 else synth.CONFIGS["cfg4s"]["n_pairs"]
+wl = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
+per_gpu = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else synth.CONFIGS[wl]["n_pairs"]
 dev = torch.device("cuda", 0)
 lib = capi.load_library()
 t0 = time.time()
-data = synth.generate("cfg4s", n_pairs=per_gpu * world, seed=0, device=dev, shard=(rank, world), scale=0.125 * world)
+data = synth.generate(wl, n_pairs=per_gpu * world, seed=0, device=dev, shard=(rank, world), scale=(0.125 * world if wl == "cfg4s" else 1.0))
 torch.cuda.synchronize()
 t_gen = time.time() - t0
 ctx = data.stream_context
