@@ -28,15 +28,15 @@ def test_header_symbols_exported(built):
 def test_struct_layouts_match_header(built, tmp_path):
     from gencore_amd import capi
     src = tmp_path / "probe.c"
-    src.write_text('#include <stdio.h>\n#include "gencore_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",sizeof(gce_core),sizeof(gce_params),'
+    src.write_text('#include <stdio.h>\n#include "gencore_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",sizeof(gce_core),sizeof(gce_params),'
                    'sizeof(gce_batch),sizeof(gce_stats),sizeof(gce_result),sizeof(gce_timing),sizeof(gce_depth),sizeof(gce_bam_info),'
-                   'sizeof(gce_bam_run));return 0;}\n')
+                   'sizeof(gce_bam_run),sizeof(gce_payload_layout),sizeof(gce_depth_run));return 0;}\n')
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [capi.CORE_DTYPE.itemsize, C.sizeof(capi.GceParams), C.sizeof(capi.GceBatch), C.sizeof(capi.GceStats),
                      C.sizeof(capi.GceResult), C.sizeof(capi.GceTiming), C.sizeof(capi.GceDepth), C.sizeof(capi.GceBamInfo),
-                     C.sizeof(capi.GceBamRun)]
+                     C.sizeof(capi.GceBamRun), C.sizeof(capi.GcePayloadLayout), C.sizeof(capi.GceDepthRun)]
 
 
 def test_defaults_match_reference_options(built):
