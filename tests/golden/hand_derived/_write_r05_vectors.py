@@ -132,3 +132,45 @@ write(dict(
              rec("d", 147, 110, "20M", 100, -30, RR, Q(37, 20))],
     expected_status=0,
     expected=[out("a", 99, 100, "20M", L20, Q(30, 15) + [18] + Q(30, 4), 0, 4), out("a", 147, 110, "20M", ra, Q(37, 20), 1, 4)]))
+
+# ------------------------------------------------------------------------------------------------ 4: the reference arbitration flips the top base
+REFC = [dict(name="c0", length=100000, sequence=dict(repeat="ACGT", times=25000))]
+R20 = "TTGCAAGCTTCGATGCAAGC"
+lg = L20[:7] + "G" + L20[8:]            # G instead of the reference's T in column 7 (position 107)
+write(dict(
+    name="reference_arbitration_flips_the_top_base_to_a_high_quality_minority",
+    cites=["src/group.cpp:362-367", "src/group.cpp:394-417", "src/group.cpp:442-457", "src/group.cpp:470-494", "src/group.cpp:503-526", "src/group.cpp:528-573", "src/reference.cpp:33-70"],
+    derivation=(
+        "Contig c0 = ACGT x 25000 is the reference.  One cluster (0, 100, 419), three pairs a, b, c, all 20M, qualities 37, mates 300 bases apart (no overlap: every score is "
+        "qual2score(37) = 8).  Left reads: a and b show G in column 7 (position 107, reference T), c shows T.  Template a (identical CIGARs and lengths: first qname), three voters.  "
+        "Column 7: G 2 votes / score 16 / top quality 37, T 1 vote / score 8 / quals 37.  Top = G (16), topNum 2; second = T, secNum 1, quals[T] = 37 > lowQuality: 'high quality "
+        "secondary', and topNum 2 < 3: needToCheckRef (group.cpp:450-456).  The template has isize != 0, the reference is loaded, refbase = T.  The loop of :474-487 finds voter c "
+        "with the reference's base at quality 37 >= highQuality: topBase = T, refBaseQual = 37; topQual 37 >= moderate, so no forcing; topBase == ref: topQual = refBaseQual = 37.  "
+        "The MINORITY base wins because the reference agrees with it: the template's G is overwritten by T (diff 1); the old base was not the reference's, the new one is: "
+        "mismatchInc-- = -1 (:516-520), and NM (type C) goes from 1 to 0 (:569-571).  Every other column is unanimous, quality 37.  Right reads identical: unchanged.  FR = 3."),
+    params={}, contigs=REFC,
+    records=[rec("a", 99, 100, "20M", 400, 320, lg, Q(37, 20), nm=1), rec("b", 99, 100, "20M", 400, 320, lg, Q(37, 20), nm=1), rec("c", 99, 100, "20M", 400, 320, L20, Q(37, 20)),
+             rec("a", 147, 400, "20M", 100, -320, R20, Q(37, 20)), rec("b", 147, 400, "20M", 100, -320, R20, Q(37, 20)), rec("c", 147, 400, "20M", 100, -320, R20, Q(37, 20))],
+    expected_status=0,
+    expected=[out("a", 99, 100, "20M", L20, Q(37, 20), 0, 3), out("a", 147, 400, "20M", R20, Q(37, 20), 0, 3)]))
+
+# ------------------------------------------------------------------------------------------------ 5: no voter of moderate quality: the reference's base, with what supports it
+la5 = L20[:5] + "A" + L20[6:]           # A instead of the reference's C in column 5 (position 105)
+qa5 = Q(37, 5) + [11] + Q(37, 3) + [12] + Q(37, 10)
+qb5 = Q(37, 5) + [12] + Q(37, 3) + [11] + Q(37, 10)
+write(dict(
+    name="low_top_quality_takes_the_reference_base_with_the_quality_that_supports_it",
+    cites=["src/group.cpp:394-428", "src/group.cpp:459-467", "src/group.cpp:470-494", "src/group.cpp:503-526", "src/pair.cpp:77-86"],
+    derivation=(
+        "Reference ACGT x 25000.  One cluster (0, 100, 419), two pairs a and b, 20M, no mate overlap.  Both left reads show A in column 5 where the reference has C (position 105), with "
+        "qualities 11 (a) and 12 (b); both show the reference's C in column 9 with qualities 12 (a) and 11 (b); every other quality is 37.  Template a, two voters.  Column 5: one "
+        "base, scores qual2score(11) + qual2score(12) = 2 + 2 = 4 (both below lowQuality 15: 'bad'), topQual 12, secNum 0.  4 < baseScoreReq 6: no fast accept, needToCheckRef "
+        "(:421-428).  refbase = C; no voter shows C: refBaseQual stays 0; topQual 12 < moderateQuality 20: topBase = C (:488-490); topBase == ref: topQual = refBaseQual = 0 (:491-494): "
+        "the reference's base is written with quality ZERO ('masked for downstream processing'), diff 1, mismatchInc-- = -1.  Column 9: the same scores, but the base IS the "
+        "reference's: refBaseQual = max(12, 11) = 12, topBase = C = the template's own base: nothing is written, quality = refBaseQual = 12.  NM (type C) 1 -> 0.  Every other column: "
+        "scores 8 + 8 = 16, quality 37.  Right reads identical: unchanged.  FR = 2."),
+    params={}, contigs=REFC,
+    records=[rec("a", 99, 100, "20M", 400, 320, la5, qa5, nm=1), rec("b", 99, 100, "20M", 400, 320, la5, qb5, nm=1),
+             rec("a", 147, 400, "20M", 100, -320, R20, Q(37, 20)), rec("b", 147, 400, "20M", 100, -320, R20, Q(37, 20))],
+    expected_status=0,
+    expected=[out("a", 99, 100, "20M", L20, Q(37, 5) + [0] + Q(37, 3) + [12] + Q(37, 10), 0, 2), out("a", 147, 400, "20M", R20, Q(37, 20), 0, 2)]))
