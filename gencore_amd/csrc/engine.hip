@@ -77,9 +77,9 @@ struct gce_engine {
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
     // work buffers
-    DevBuf umi_ptr, umi_len, has_mi, rdesc, spatch, slot, score, out_flag, orec, out_index, nmx;
+    DevBuf uinfo, rdesc, spatch, slot, score, out_flag, orec, out_index, nmx;
     // output table (gce_result): device arrays + host copies
-    DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_soff, o_qoff, o_seq, o_qual, o_key, o_rec, o_ksoff, o_kqoff, o_krow, o_part3, ref_ascii;
+    DevBuf o_src, o_kind, o_qsrc, o_nm, o_fr, o_rr, o_mate, o_soff, o_qoff, o_seq, o_qual, o_key, o_rec, o_ksoff, o_kqoff, o_krow, o_rank64, o_part3, ref_ascii;
     int64_t n_out = 0; size_t out_seq_bytes = 0, out_qual_bytes = 0; int dev_error = 0; uint32_t dev_error_read = 0;
     DevBuf lrec, lout, bhdr, blk_base, ev_tid, ev_pos, ev_read, table, toff;
     // the raw BAM stream in HBM (gce_bamdev.hpp)
@@ -170,9 +170,9 @@ void gce_destroy(gce_engine *e) {
     (void)hipSetDevice(e->prm.device);
     (void)hipStreamSynchronize(e->stream);
     DevBuf *all[] = {&e->d_ref_ptr, &e->d_ref_len, &e->d_ref_win, &e->d_target_len, &e->d_target_cum, &e->b_core, &e->b_qoff, &e->b_qname, &e->b_coff, &e->b_cigar, &e->b_soff,
-                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->umi_ptr, &e->umi_len, &e->has_mi, &e->rdesc, &e->spatch,
+                     &e->b_seq, &e->b_loff, &e->b_qual, &e->b_nm, &e->b_nmt, &e->b_mioff, &e->b_mi, &e->b_tick, &e->uinfo, &e->rdesc, &e->spatch,
                      &e->slot, &e->score, &e->out_flag, &e->orec, &e->out_index, &e->nmx, &e->o_src, &e->o_kind, &e->o_qsrc, &e->o_nm, &e->o_fr, &e->o_rr, &e->o_mate,
-                     &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
+                     &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_rank64, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
                      &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
@@ -757,8 +757,8 @@ static int gce_process_impl(gce_engine *e) {
     const size_t qual_bytes = hb.qual_bytes ? hb.qual_bytes : 1;
     const size_t nsb1 = (size_t)(n_sblk > 0 ? n_sblk : 1);
 #define ENS(buf, bytes) HIPCHK(e->buf.ensure(bytes))
-    ENS(umi_ptr, n1 * 8); ENS(umi_len, n1 * 2); ENS(has_mi, n1); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(score, qual_bytes + 64);
-    ENS(out_flag, n1 + 16); ENS(nmx, n1 * 4); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
+    ENS(uinfo, n1 * 8); ENS(rdesc, n1 * sizeof(ReadDescP)); ENS(spatch, n1 * 4); ENS(slot, n1 * 4 + 16); ENS(score, qual_bytes + 64);
+    ENS(out_flag, n1 + 144);       /* (k_out_mate reads whole 64-byte blocks of flags) */ ENS(nmx, n1 * 4); ENS(orec, n1 * sizeof(OutRec)); ENS(out_index, n1 * 4);
     ENS(lrec, nsb1 * SB_READS * sizeof(LeadRec)); ENS(lout, nsb1 * SB_READS * sizeof(LeadOut));
     ENS(bhdr, nsb1 * sizeof(BlkHdr)); ENS(blk_base, nsb1 * 4);
     ENS(ev_tid, (size_t)max_events * 4); ENS(ev_pos, (size_t)max_events * 4); ENS(ev_read, (size_t)max_events * 4);
@@ -769,7 +769,7 @@ static int gce_process_impl(gce_engine *e) {
     ENS(deep_list, (n1 / 64 + 64) * 16); w.deep_list = e->deep_list.p;
     const unsigned nblk_N = cdiv(n1, SCAN_TILE);
     ENS(scan_part, std::max<size_t>(2 * nsb1, (size_t)2 * nblk_N) * 8 + 16);    /* 2 x: the group-side flags (<= 2 per read); the scan blocks' totals behind those of k_num_reduce's blocks */ ENS(si, sizeof(StreamInfo));
-    w.umi_ptr = e->umi_ptr.as<const char *>(); w.umi_len = e->umi_len.as<uint16_t>(); w.has_mi = e->has_mi.as<uint8_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
+    w.uinfo = e->uinfo.as<uint64_t>(); w.rdesc = e->rdesc.as<ReadDescP>(); w.spatch = e->spatch.as<uint32_t>();
     w.slot = e->slot.as<uint32_t>(); w.score = e->score.as<int8_t>();
     w.out_flag = e->out_flag.as<uint8_t>(); w.nmx = e->nmx.as<uint32_t>(); w.orec = e->orec.as<OutRec>(); w.out_index = e->out_index.as<uint32_t>();
     w.lrec = e->lrec.as<LeadRec>(); w.lout = e->lout.as<LeadOut>(); w.bhdr = e->bhdr.as<BlkHdr>(); w.blk_base = e->blk_base.as<uint32_t>();
@@ -848,6 +848,7 @@ static int gce_process_impl(gce_engine *e) {
     w.cl_npairs = e->cl_npairs.as<uint32_t>(); w.cl_ngroups = e->cl_ngroups.as<uint32_t>(); w.cl_gbase = e->cl_gbase.as<uint32_t>();
     w.cl_nresult = e->cl_nresult.as<uint32_t>(); w.cl_hasumi = e->cl_hasumi.as<uint8_t>();
     uint32_t NG = 0;
+    bool si_behind_describe = false;               // the host's copy of StreamInfo holds what k_describe found (read-length range)
     if (C > 0 && e->dev_error == 0) {
         // (gpl / gpr need no clearing: every reader -- k_vote, k_score2 behind the slot flags, the per-side kernels, k_group_tail -- looks at the pair slots
         //  [g_begin, g_begin + g_np) of a group only, and the pairing kernels write both words of every one of those)
@@ -913,6 +914,7 @@ static int gce_process_impl(gce_engine *e) {
         CANARY("EV_PAIRING");
         if ((rc = read_si(e)) != GCE_OK) return rc;
         HIPCHK(hipGetLastError());
+        si_behind_describe = true;
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
@@ -1017,18 +1019,21 @@ static int gce_process_impl(gce_engine *e) {
         }
         ENS(o_src, n1 * 4); ENS(o_kind, n1); ENS(o_qsrc, n1 * 4); ENS(o_nm, n1 * 4); ENS(o_fr, n1 * 2); ENS(o_rr, n1 * 2); ENS(o_mate, n1 * 4);
         ENS(o_soff, n1 * 8); ENS(o_qoff, n1 * 8); ENS(o_seq, seq_cap); ENS(o_qual, qual_cap);
-        ENS(o_key, n1 * sizeof(OutKey)); ENS(o_rec, n1 * sizeof(OutRec)); ENS(o_ksoff, n1 * 8); ENS(o_kqoff, n1 * 8); ENS(o_krow, n1 * 4); const unsigned nblk_O = cdiv(n1, OUT_TILE); ENS(o_part3, (size_t)nblk_O * 24 + 64);
+        ENS(o_key, n1 * sizeof(OutKey)); ENS(o_rec, n1 * sizeof(OutRec)); ENS(o_ksoff, n1 * 8); ENS(o_kqoff, n1 * 8); ENS(o_krow, n1 * 4); ENS(o_rank64, (n1 / 64 + 2) * 4); const unsigned nblk_O = cdiv(n1, OUT_TILE); ENS(o_part3, (size_t)nblk_O * 24 + 64);
         o.src = e->o_src.as<uint32_t>(); o.kind = e->o_kind.as<uint8_t>(); o.qname_src = e->o_qsrc.as<uint32_t>(); o.nm_new = e->o_nm.as<int32_t>();
         o.fr = e->o_fr.as<int16_t>(); o.rr = e->o_rr.as<int16_t>(); o.mate = e->o_mate.as<uint32_t>();
         o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
-        o.key = e->o_key.as<OutKey>(); o.rec = e->o_rec.as<OutRec>(); o.ksoff = e->o_ksoff.as<uint64_t>(); o.kqoff = e->o_kqoff.as<uint64_t>(); o.krow = e->o_krow.as<uint32_t>(); o.part3 = e->o_part3.as<uint64_t>();
+        o.key = e->o_key.as<OutKey>(); o.rec = e->o_rec.as<OutRec>(); o.ksoff = e->o_ksoff.as<uint64_t>(); o.kqoff = e->o_kqoff.as<uint64_t>(); o.krow = e->o_krow.as<uint32_t>(); o.rank64 = e->o_rank64.as<uint32_t>(); o.part3 = e->o_part3.as<uint64_t>();
         hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups
         CANARY("k_stats");
         hipLaunchKernelGGL(k_out_reduce, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
         CANARY("k_out_reduce");
         hipLaunchKernelGGL(k_out_partials, dim3(1), dim3(1024), 0, s, o, (uint64_t)nblk_O, w);
         CANARY("k_out_partials");
-        hipLaunchKernelGGL(k_out_meta, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
+        // every emitted read of one length (k_describe's range, final on the host once the look behind the pairing phase has happened): no offset lists in LDS
+        const bool lq_uniform = si_behind_describe && e->h_si.lq_max >= 0 && e->h_si.lq_min == e->h_si.lq_max;
+        if (lq_uniform) hipLaunchKernelGGL(k_out_meta<true>, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o, (int)e->h_si.lq_max);
+        else hipLaunchKernelGGL(k_out_meta<false>, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o, -1);
         CANARY("k_out_meta");
         const unsigned og = std::min<unsigned>(cdiv(n1, 256), 8192u);
         hipLaunchKernelGGL(k_out_rows, dim3(og), dim3(256), 0, s, w, o);

@@ -605,7 +605,8 @@ __global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Wo
                 else src2 = b.qname + b.qname_off[i];
                 int s0, l0;
                 if (!d_umi_slice(src2, p, s0, l0, hm ? -1 : (int)k.l_qname - 1)) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); s0 = 0; l0 = 0; }
-                w.umi_ptr[i] = src2 + s0; w.umi_len[i] = (uint16_t)l0; w.has_mi[i] = hm;
+                if (l0 > UINFO_MAXLEN) { raise_error(w.si, GCE_ERR_UMI_PARSE, (uint32_t)i); l0 = 0; }
+                w.uinfo[i] = uinfo_pack((hm ? b.mi_off[i] : b.qname_off[i]) + (uint64_t)s0, hm != 0, k.l_qname, l0);
             }
         }
     }

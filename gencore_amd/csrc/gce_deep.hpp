@@ -412,7 +412,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             for (uint32_t i = tid; i < n; i += PD_T) {
                 const uint32_t m = w.members[start + i];
                 const int64_t dq = (int64_t)(b.qname_off[m] - q0);
-                if (w.umi_len[m] > 16 || dq > 0x7FFF0000ll || dq < -0x7FFF0000ll) bad = 1;
+                if (d_umi_len(w, m) > 16 || dq > 0x7FFF0000ll || dq < -0x7FFF0000ll) bad = 1;
             }
             if (bad) s_flag = 1;
         }
@@ -430,12 +430,12 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         // ---- 1. name windows + sort
         {
             const char *n0 = d_qname(b, w.members[start]);
-            const int l0 = (int)b.core[w.members[start]].l_qname - 1;
+            const int l0 = d_lqname(w, w.members[start]) - 1;
             int cp = 0x7FFFFFFF;
             for (uint32_t i = tid; i < n; i += PD_T) {
                 const uint32_t m = w.members[start + i];
                 const char *mq = d_qname(b, m);
-                const int lim = min(l0, (int)b.core[m].l_qname - 1);
+                const int lim = min(l0, d_lqname(w, m) - 1);
                 int l = 0;
                 while (l + 8 <= lim) {                                               // 8 bytes at a time, then the first differing byte
                     const uint64_t x = *(const u64_unaligned *)(n0 + l) ^ *(const u64_unaligned *)(mq + l);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         for (int i = tid; i < P; i += PD_T) {
             if (i < (int)n) {
                 const uint32_t my = w.members[start + i];
-                const int nl = (int)b.core[my].l_qname - 1;
+                const int nl = d_lqname(w, my) - 1;
                 uint64_t k2[2];
                 load_be_words<2>(d_qname(b, my) + cp, max(nl - cp, 0), k2);
                 s_key[i][0] = k2[0]; s_key[i][1] = k2[1];
@@ -523,14 +523,14 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                 isf_m |= (uint64_t)f_ << u; isl_m |= (uint64_t)l_ << u;
                 if (!f_) {                                                     // setRight: UMI of the pair so far vs this read's (pair.cpp:201-212)
                     const uint32_t pv = s_rd[s_perm[sidx - 1]];
-                    const int lp = w.umi_len[pv], lq = w.umi_len[q];
+                    const int lp = d_umi_len(w, pv), lq = d_umi_len(w, q);
                     if (lp != 0) {
                         uint64_t x[2], y[2];
-                        load_be_words<2>(w.umi_ptr[pv], lp, x); load_be_words<2>(w.umi_ptr[q], lq, y);     // (<= 16 bytes: checked above)
+                        load_be_words<2>(d_umi_ptr(b, w, pv), lp, x); load_be_words<2>(d_umi_ptr(b, w, q), lq, y);     // (<= 16 bytes: checked above)
                         if (lp != lq || x[0] != y[0] || x[1] != y[1]) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
                     }
                 }
-                if (l_ && w.umi_len[q]) any_umi = 1;
+                if (l_ && d_umi_len(w, q)) any_umi = 1;
                 firsts += f_;
             }
         }
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
                     const uint16_t m = s_pr[i] != PD_NONE16 ? s_pr[i] : s_pl[i];   // the pair's UMI is its last read's (pair.cpp:188-216)
                     const uint32_t ui = w.members[start + m];
                     uint64_t k2[2];
-                    load_be_words<2>(w.umi_ptr[ui], (int)w.umi_len[ui], k2);
+                    load_be_words<2>(d_umi_ptr(b, w, ui), (int)d_umi_len(w, ui), k2);
                     s_key[i][0] = k2[0]; s_key[i][1] = k2[1];
                     s_perm[i] = (uint16_t)i;
                 } else s_perm[i] = PD_NONE16;

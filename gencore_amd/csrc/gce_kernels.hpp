@@ -28,7 +28,7 @@ static_assert(sizeof(OutRec) == 16, "OutRec must stay 16 bytes");
 
 struct Work {
     // per read
-    const char **umi_ptr; uint16_t *umi_len; uint8_t *has_mi;
+    uint64_t *uinfo;                     // per clustered read: where its UMI lies, its length, its name's length -- ONE word (uinfo_pack, below)
     ReadDescP *rdesc;
     uint32_t *spatch;                    // per read: overlap score patch (start | len << 16), GCE_PATCH_CONST, or 0
     uint32_t *slot;                      // per clustered read: leader of its scan block | rank in the leader's run << 16 (gce_cluster.hpp)
@@ -67,6 +67,23 @@ struct Work {
     uint64_t *scan_part;
     StreamInfo *si;
 };
+
+// The UMI of a clustered read (BamUtil::getUMI, bamutil.cpp:23-112: a slice of its name, or its MI:Z tag) and the length of its name in ONE 64-bit word per read:
+//   bits 0..39 offset of the UMI in the blob it lies in | bit 40: that blob is the MI blob (else the names) | bits 41..48 core.l_qname | bits 49..63 UMI length
+// Rounds 1-4 kept a pointer, a 16-bit length and a byte in three arrays: three scattered 64-byte sectors per read wherever a read's UMI was looked at (the
+// pairing kernels, k_group_tail) and one more (the core record) for the name's length.  UMIs beyond 32767 bytes are refused by k_describe.
+#define UINFO_MAXLEN 32767
+__device__ __forceinline__ uint64_t uinfo_pack(uint64_t off, bool from_mi, int l_qname, int len) {
+    return (off & 0xFFFFFFFFFFull) | ((uint64_t)(from_mi ? 1 : 0) << 40) | ((uint64_t)(l_qname & 0xFF) << 41) | ((uint64_t)(len & 0x7FFF) << 49);
+}
+__device__ __forceinline__ const char *uinfo_ptr(const DevBatch &b, uint64_t v) { return (((v >> 40) & 1ull) ? b.mi : b.qname) + (v & 0xFFFFFFFFFFull); }
+__device__ __forceinline__ int uinfo_len(uint64_t v) { return (int)(v >> 49); }
+__device__ __forceinline__ bool uinfo_hm(uint64_t v) { return ((v >> 40) & 1ull) != 0; }
+__device__ __forceinline__ int uinfo_lqname_pad(uint64_t v) { return ((int)((v >> 41) & 0xFFu) + 3) & ~3; }            // (= d_lqname_pad of the read's core record)
+__device__ __forceinline__ const char *d_umi_ptr(const DevBatch &b, const Work &w, uint64_t i) { return uinfo_ptr(b, w.uinfo[i]); }
+__device__ __forceinline__ int d_umi_len(const Work &w, uint64_t i) { return uinfo_len(w.uinfo[i]); }
+__device__ __forceinline__ bool d_umi_hm(const Work &w, uint64_t i) { return uinfo_hm(w.uinfo[i]); }
+__device__ __forceinline__ int d_lqname(const Work &w, uint64_t i) { return (int)((w.uinfo[i] >> 41) & 0xFFu); }            // core.l_qname of a clustered read
 
 enum : uint8_t { RP_PENDING = 0, RP_OUT_SSCS = 1, RP_OUT_DCS = 2, RP_DROPPED = 3, RP_CONSUMED = 4 };
 // rp_nm: >= 0 the new NM byte, -1 untouched, NM_DEFER + mismatchInc (k_vote): the delta of a template whose NM tag has not been looked at yet
@@ -188,7 +205,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
             last = (i == n - 1) || d_strcmp(d_qname(b, w.sorted[start + i + 1]), mq) != 0;
             if (!first) {       // setRight: `if(!mUMI.empty() && umi!=mUMI) error_exit` (pair.cpp:201-212)
                 uint32_t pv = w.sorted[start + i - 1];
-                if (w.umi_len[pv] != 0 && !d_bytes_equal(w.umi_ptr[pv], w.umi_len[pv], w.umi_ptr[q], w.umi_len[q])) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
+                if (d_umi_len(w, pv) != 0 && !d_bytes_equal(d_umi_ptr(b, w, pv), d_umi_len(w, pv), d_umi_ptr(b, w, q), d_umi_len(w, q))) raise_error(w.si, GCE_ERR_UMI_MISMATCH, q);
             }
         }
         unsigned long long fm = __ballot(first);
@@ -196,7 +213,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
         if (valid) {
             if (first) { w.pl[start + pidx] = q; if (last) w.pr[start + pidx] = NONE32; }
             if (last && !first) w.pr[start + pidx] = q;
-            if (last) { w.pu[start + pidx] = q; if (w.umi_len[q]) any_umi = 1; }
+            if (last) { w.pu[start + pidx] = q; if (d_umi_len(w, q)) any_umi = 1; }
         }
         npairs += __popcll(fm);
     }
@@ -212,9 +229,9 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
         // UMIs of <= 24 bytes as three zero-padded words per pair in scratch: equal words <=> equal strings
         bool longu = false;
         for (uint32_t i = lane; i < npairs; i += 64) {
-            const uint32_t ui = w.pu[start + i]; const int ul = w.umi_len[ui];
+            const uint32_t ui = w.pu[start + i]; const int ul = d_umi_len(w, ui);
             uint64_t u3[3];
-            load_be_words<3>(w.umi_ptr[ui], min(ul, 24), u3);
+            load_be_words<3>(d_umi_ptr(b, w, ui), min(ul, 24), u3);
             kw[3 * i] = u3[0]; kw[3 * i + 1] = u3[1]; kw[3 * i + 2] = u3[2];
             if (ul > 24) longu = true;
         }
@@ -222,7 +239,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
         WAVE_SYNC();
         for (uint32_t i = lane; i < npairs; i += 64) {
             uint32_t ui = w.pu[start + i];
-            const char *up = w.umi_ptr[ui]; int ul = w.umi_len[ui];
+            const char *up = d_umi_ptr(b, w, ui); int ul = d_umi_len(w, ui);
             uint32_t cnt = 0;
             if (!longu) {
                 const uint64_t a0 = kw[3 * i], a1 = kw[3 * i + 1], a2 = kw[3 * i + 2];
@@ -233,7 +250,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
                 }
                 for (uint32_t j = npairs & ~3u; j < npairs; j++) cnt += (kw[3 * j] == a0 && kw[3 * j + 1] == a1 && kw[3 * j + 2] == a2);
             } else
-            for (uint32_t j = 0; j < npairs; j++) { uint32_t uj = w.pu[start + j]; cnt += d_bytes_equal(up, ul, w.umi_ptr[uj], w.umi_len[uj]); }
+            for (uint32_t j = 0; j < npairs; j++) { uint32_t uj = w.pu[start + j]; cnt += d_bytes_equal(up, ul, d_umi_ptr(b, w, uj), d_umi_len(w, uj)); }
             pc[start + i] = cnt;
             w.pg[start + i] = NONE32;
         }
@@ -245,7 +262,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
             for (uint32_t i = lane; i < npairs; i += 64) {
                 if (w.pg[start + i] != NONE32) continue;
                 uint32_t ui = w.pu[start + i], cnt = pc[start + i];
-                const char *up = w.umi_ptr[ui]; int ul = w.umi_len[ui];
+                const char *up = d_umi_ptr(b, w, ui); int ul = d_umi_len(w, ui);
                 bool better = best == NONE32 || cnt > bcnt || (cnt == bcnt && d_slice_cmp(up, ul, bu, bl) < 0);
                 if (better) { best = i; bcnt = cnt; bu = up; bl = ul; }
             }
@@ -253,7 +270,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
                 uint32_t ob = __shfl_xor(best, o), oc = __shfl_xor(bcnt, o);
                 if (ob == NONE32) continue;
                 uint32_t oui = w.pu[start + ob];
-                const char *ou = w.umi_ptr[oui]; int ol = w.umi_len[oui];
+                const char *ou = d_umi_ptr(b, w, oui); int ol = d_umi_len(w, oui);
                 bool better;
                 if (best == NONE32) better = true;
                 else if (oc != bcnt) better = oc > bcnt;
@@ -266,7 +283,7 @@ __device__ void pairing_generic(const DevBatch &b, const DevParams &p, const Wor
                 bool take = false;
                 if (i < npairs && w.pg[start + i] == NONE32) {
                     uint32_t ui = w.pu[start + i];
-                    take = d_umi_diff(w.umi_ptr[ui], w.umi_len[ui], bu, bl) <= thr;
+                    take = d_umi_diff(d_umi_ptr(b, w, ui), d_umi_len(w, ui), bu, bl) <= thr;
                     if (take) w.pg[start + i] = ngroups;
                 }
                 absorbed += __popcll(__ballot(take));
@@ -318,12 +335,13 @@ __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, cons
     if (mode == THR_NEVER) { if (lane == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; } return; }
     const int thr = mode == THR_PROPER ? p.proper_thr : p.unproper_thr;
     bool defer = n > 64;
-    uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0;
+    uint32_t my = NONE32; int nl = 0; const char *nm = nullptr; int ul = 0; uint64_t ui_ = 0;
     if (!defer && lane < (int)n) {
         my = w.members[start + lane];
-        nl = (int)b.core[my].l_qname - 1;
+        ui_ = w.uinfo[my];
+        nl = (int)((ui_ >> 41) & 0xFFu) - 1;
         nm = d_qname(b, my);
-        ul = w.umi_len[my];
+        ul = uinfo_len(ui_);
     }
     if (!defer && __any(nl > 64 || ul > 24)) defer = true;
     if (defer) { if (lane == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; return; }
@@ -411,7 +429,7 @@ __device__ void pairing_fast_cluster(const DevBatch &b, const DevParams &p, cons
     const uint32_t pidx = __popcll(LT);                     // distinct names before mine
     // every read's UMI as big-endian words in registers (<= 24 bytes, checked above): no byte loops over global memory below
     uint64_t ruw[3];
-    load_be_words<3>(act ? w.umi_ptr[my] : nullptr, act ? ul : 0, ruw);
+    load_be_words<3>(act ? uinfo_ptr(b, ui_) : nullptr, act ? ul : 0, ruw);
     {   // setRight (pair.cpp:201-212): the UMI must equal the pair's current UMI if that is non-empty.  The pair's current
         // read is the predecessor in arrival order = the largest read index among the same-name reads before mine.
         unsigned long long prev = act ? (EQ & LOW) : 0ull;
@@ -1143,8 +1161,10 @@ __device__ uint32_t side_consensus(const DevBatch &b, const DevParams &p, const 
 // (BamUtil::getUMI, bamutil.cpp:23-38, after BamUtil::copyQName).
 __device__ inline void d_record_umi(const DevBatch &b, const DevParams &p, const Work &w, uint32_t rec, uint32_t name_src,
                                     const char *&u, int &ul) {
-    if (w.has_mi[rec]) { u = w.umi_ptr[rec]; ul = w.umi_len[rec]; return; }
-    if (!w.has_mi[name_src]) { u = w.umi_ptr[name_src]; ul = w.umi_len[name_src]; return; }
+    const uint64_t vr = w.uinfo[rec];
+    if (uinfo_hm(vr)) { u = uinfo_ptr(b, vr); ul = uinfo_len(vr); return; }
+    const uint64_t vn = name_src == rec ? vr : w.uinfo[name_src];
+    if (!uinfo_hm(vn)) { u = uinfo_ptr(b, vn); ul = uinfo_len(vn); return; }
     const char *q = d_qname(b, name_src); int s0, l0;
     d_umi_slice(q, p, s0, l0);
     u = q + s0; ul = l0;
@@ -1746,6 +1766,8 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
     const uint32_t G = w.cl_ngroups[c];
     const bool single = np == 1 && w.gpr[begin] == NONE32;
     uint32_t qsl = left, qsr = right;                                     // BamUtil::copyQName sources (== the record itself if unchanged)
+    // the two templates' name lengths and UMI places: one word each (round 5; core record + UMI pointer + UMI length + MI flag were four sectors per side)
+    const uint64_t uL = left != NONE32 ? w.uinfo[left] : 0ull, uR = right != NONE32 ? w.uinfo[right] : 0ull;
     if (!single) {
         if (cflags & 2) {                                                 // cross-contig cluster: group.cpp:79-99,109-112
             uint32_t ntc = NONE32; int bl = 0;
@@ -1759,7 +1781,7 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
                 qsl = ntc;
             }
         } else if (left != NONE32 && right != NONE32) {                   // group.cpp:114-123
-            if (d_lqname_pad(b.core[left]) <= d_lqname_pad(b.core[right])) qsr = left;
+            if (uinfo_lqname_pad(uL) <= uinfo_lqname_pad(uR)) qsr = left;
             else qsl = right;
         }
     }
@@ -1768,10 +1790,18 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
     const bool duplex_cluster = (cflags & 1) && !p.disable_duplex && G >= 2;
     const char *u = nullptr; int ul = 0;                                  // Pair::setLeft / setRight (pair.cpp:188-216)
     if ((cflags & 1) || b.mi) {
-        if (left != NONE32) d_record_umi(b, p, w, left, qsl, u, ul);
+        auto rec_umi = [&](uint64_t vrec, uint32_t src, const char *&uo, int &ulo) {       // d_record_umi on the words already here
+            if (uinfo_hm(vrec)) { uo = uinfo_ptr(b, vrec); ulo = uinfo_len(vrec); return; }
+            const uint64_t vn = src == left ? uL : (src == right ? uR : w.uinfo[src]);
+            if (!uinfo_hm(vn)) { uo = uinfo_ptr(b, vn); ulo = uinfo_len(vn); return; }
+            const char *q = d_qname(b, src); int s0, l0;
+            d_umi_slice(q, p, s0, l0);
+            uo = q + s0; ulo = l0;
+        };
+        if (left != NONE32) rec_umi(uL, qsl, u, ul);
         if (right != NONE32) {
             const char *u2; int ul2;
-            d_record_umi(b, p, w, right, qsr, u2, ul2);
+            rec_umi(uR, qsr, u2, ul2);
             if (left != NONE32 && ul != 0) {                               // (two word loads per side instead of a byte loop with a data-dependent exit)
                 bool same = ul == ul2;
                 if (same && u == u2) { }                                    // both records carry the same read's name (the usual case): nothing to fetch

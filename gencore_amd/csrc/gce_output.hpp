@@ -26,6 +26,7 @@ struct OutTable {
     uint64_t *seq_off, *qual_off; uint8_t *seq, *qual;
     // indexed by k (emitted reads in input order)
     OutKey *key; OutRec *rec; uint64_t *ksoff, *kqoff; uint32_t *krow;
+    uint32_t *rank64;                    // [reads / 64]: emitted reads in front of read 64 q (k_out_meta -> k_out_mate)
     uint64_t *part3;                     // [tiles][3]: records, base units, quality units
 };
 #define GCE_POST_SLOTS 64
@@ -98,19 +99,26 @@ __global__ __launch_bounds__(1024) void k_out_partials(OutTable o, uint64_t npar
     if (threadIdx.x == 0) { w.si->n_out = s_carry[0]; w.si->out_units = (s_carry[1] << 32) | (s_carry[2] & 0xFFFFFFFFull); }
 }
 
-__global__ __launch_bounds__(OUT_T) void k_out_meta(DevBatch b, Work w, OutTable o) {
+// Round 5: the gather runs over the tile's COMPACTED list.  A thread used to deal with the emitted reads among its eight one after the other -- eight rounds of
+// (scattered loads -> stores) per wave, each waiting for its loads: 239 us for 0.65 GB.  Now the tile's emitted reads are listed in LDS behind the scan (their place
+// in the tile, their kind, where their bytes go when the lengths differ), thread t takes the t-th of them: one round of loads in flight per 512 records, stores to
+// consecutive k.  UNIFORM (every emitted read has the same length: the host's look at k_describe's range): no offset lists, 12 KB of LDS instead of 44.
+// rank64[q] = emitted reads in front of read 64 q: k_out_mate finds a mate's place in the list with it (two loads instead of a bisection of 21 dependent probes).
+template <bool UNIFORM>
+__global__ __launch_bounds__(OUT_T) void k_out_meta(DevBatch b, Work w, OutTable o, int lq_uniform) {
     __shared__ uint64_t s_w[OUT_T / 64][3];
     __shared__ long long s_stat[OUT_T / 64][6];
+    __shared__ uint16_t s_idx[OUT_TILE];
+    __shared__ uint8_t s_kind[OUT_TILE];
+    __shared__ uint32_t s_so[UNIFORM ? 1 : OUT_TILE], s_qo[UNIFORM ? 1 : OUT_TILE];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint64_t i0 = (uint64_t)blockIdx.x * OUT_TILE + 8 * (uint64_t)threadIdx.x;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * OUT_TILE, i0 = tile0 + 8 * (uint64_t)threadIdx.x;
     const uint64_t f8 = out_flags8(w, i0, (uint64_t)b.n);
-    // the thread's counts: the lengths come first (the scan needs them), everything else in the second walk
     uint32_t lqs[8]; uint64_t cnt = 0, us = 0, uq = 0;
-    const int lq_u = w.si->lq_min == w.si->lq_max ? w.si->lq_max : -1;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         lqs[j] = 0;
-        if ((f8 >> (8 * j)) & 0xFF) { lqs[j] = lq_u >= 0 ? (uint32_t)lq_u : (uint32_t)b.core[i0 + j].l_qseq; cnt++; const uint64_t un = out_units_of(lqs[j]); us += un >> 32; uq += un & 0xFFFFFFFFull; }
+        if ((f8 >> (8 * j)) & 0xFF) { lqs[j] = UNIFORM ? (uint32_t)lq_uniform : (uint32_t)b.core[i0 + j].l_qseq; cnt++; const uint64_t un = out_units_of(lqs[j]); us += un >> 32; uq += un & 0xFFFFFFFFull; }
     }
     uint64_t xc = cnt, xs = us, xq = uq;                                                  // inclusive wave scans
     for (int q = 1; q < 64; q <<= 1) {
@@ -119,22 +127,33 @@ __global__ __launch_bounds__(OUT_T) void k_out_meta(DevBatch b, Work w, OutTable
     }
     if (lane == 63) { s_w[wv][0] = xc; s_w[wv][1] = xs; s_w[wv][2] = xq; }
     __syncthreads();
-    uint64_t kk = o.part3[3 * (uint64_t)blockIdx.x] + xc - cnt, so = o.part3[3 * (uint64_t)blockIdx.x + 1] + xs - us, qo = o.part3[3 * (uint64_t)blockIdx.x + 2] + xq - uq;
-    for (int q = 0; q < wv; q++) { kk += s_w[q][0]; so += s_w[q][1]; qo += s_w[q][2]; }
-    long long st[6] = {0, 0, 0, 0, 0, 0};                     // writeBam -> mPostStats->addRead: reads, bases, unmapped reads / bases, mismatches, reads with mismatches
+    const uint64_t kbase = o.part3[3 * (uint64_t)blockIdx.x], sbase = o.part3[3 * (uint64_t)blockIdx.x + 1], qbase = o.part3[3 * (uint64_t)blockIdx.x + 2];
+    uint32_t kr = (uint32_t)(xc - cnt), sr = (uint32_t)(xs - us), qr = (uint32_t)(xq - uq), total = 0;      // places inside the tile
+    for (int q = 0; q < OUT_T / 64; q++) { const uint32_t c0 = (uint32_t)s_w[q][0]; if (q < wv) { kr += c0; sr += (uint32_t)s_w[q][1]; qr += (uint32_t)s_w[q][2]; } total += c0; }
+    if ((threadIdx.x & 7) == 0 && i0 < (uint64_t)b.n) o.rank64[i0 >> 6] = (uint32_t)(kbase + kr);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t kind = (uint32_t)(f8 >> (8 * j)) & 0xFFu;
         if (!kind) continue;
-        const uint64_t i = i0 + j;
+        s_idx[kr] = (uint16_t)(8 * threadIdx.x + j); s_kind[kr] = (uint8_t)kind;
+        if (!UNIFORM) { s_so[kr] = sr; s_qo[kr] = qr; const uint64_t un = out_units_of(lqs[j]); sr += (uint32_t)(un >> 32); qr += (uint32_t)un; }
+        kr++;
+    }
+    __syncthreads();
+    long long st[6] = {0, 0, 0, 0, 0, 0};                     // writeBam -> mPostStats->addRead: reads, bases, unmapped reads / bases, mismatches, reads with mismatches
+    const uint64_t un_u = out_units_of((uint32_t)lq_uniform);
+    for (uint32_t t2 = threadIdx.x; t2 < total; t2 += OUT_T) {
+        const uint64_t i = tile0 + s_idx[t2];
+        const uint32_t kind = s_kind[t2];
+        const uint64_t kk = kbase + t2;
         union { gce_core c; uint4 q[2]; } t; const uint4 *src = reinterpret_cast<const uint4 *>(b.core + i); t.q[0] = src[0]; t.q[1] = src[1];
-        union { OutKey k; uint4 q[2]; } key;
-        key.k.tid = t.c.tid; key.k.pos = t.c.pos; key.k.mtid = t.c.mtid; key.k.mpos = t.c.mpos; key.k.isize = t.c.isize; key.k.read = (uint32_t)i; key.k.lq = t.c.l_qseq; key.k.kind = kind;
+        const uint32_t nx = w.nmx[i];                                                      // k_describe: NM and "NM present" in one word
         union { OutRec r; uint4 q; } rc;
         rc.r.qname_src = (uint32_t)i; rc.r.mate = NONE32; rc.r.nm_new = -1; rc.r.fr = -1; rc.r.rr = -1; rc.r.pad = 0;                  // pass-through: written as it came
         if (kind == 1) rc.q = *reinterpret_cast<const uint4 *>(w.orec + i);
+        union { OutKey k; uint4 q[2]; } key;
+        key.k.tid = t.c.tid; key.k.pos = t.c.pos; key.k.mtid = t.c.mtid; key.k.mpos = t.c.mpos; key.k.isize = t.c.isize; key.k.read = (uint32_t)i; key.k.lq = t.c.l_qseq; key.k.kind = kind;
         const bool mapped = t.c.tid >= 0;
-        const uint32_t nx = w.nmx[i];                                                      // k_describe: NM and "NM present" in one word (two scattered loads less per record)
         const int nm = rc.r.nm_new >= 0 ? (int)rc.r.nm_new : (int)(nx >> 1);
         const int mism = (mapped && (nx & 1u)) ? nm : 0;
         st[0] += 1; st[1] += t.c.l_qseq; st[4] += mism;
@@ -143,9 +162,8 @@ __global__ __launch_bounds__(OUT_T) void k_out_meta(DevBatch b, Work w, OutTable
         w.out_index[kk] = (uint32_t)i;
         reinterpret_cast<uint4 *>(o.key + kk)[0] = key.q[0]; reinterpret_cast<uint4 *>(o.key + kk)[1] = key.q[1];
         *reinterpret_cast<uint4 *>(o.rec + kk) = rc.q;
+        const uint64_t so = UNIFORM ? sbase + (uint64_t)t2 * (un_u >> 32) : sbase + s_so[t2], qo = UNIFORM ? qbase + (uint64_t)t2 * (un_u & 0xFFFFFFFFull) : qbase + s_qo[t2];
         o.ksoff[kk] = so * 16; o.kqoff[kk] = qo * 16;
-        const uint64_t un = out_units_of(lqs[j]);
-        kk++; so += un >> 32; qo += un & 0xFFFFFFFFull;
     }
     for (int k = 0; k < 6; k++) { const long long v = wave_sum64(st[k]); if (lane == 0) s_stat[wv][k] = v; }
     __syncthreads();
@@ -242,16 +260,30 @@ __global__ __launch_bounds__(256) void k_out_gather(DevBatch b, Work w, OutTable
     }
 }
 
-// mate read -> mate row: the mate's place in the ascending list of emitted reads by bisection (a few cached probes per record instead of a
-// read-indexed row table: one scattered write + one scattered read per record), then its row
+// mate read -> mate row: the mate's place in the ascending list of emitted reads = emitted reads in front of its block of 64 (rank64, k_out_meta) + the
+// non-zero flags of that block in front of it -- one 64-byte sector of flags and one word, both addressed by the read index itself (rounds 2-4: a bisection
+// of out_index, 21 dependent probes per record: 42 us) --, then that record's row
 __global__ __launch_bounds__(256) void k_out_mate(Work w, OutTable o) {
     const uint32_t n_out = (uint32_t)w.si->n_out;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_out; k += gridDim.x * blockDim.x) {
         const uint32_t mr = o.rec[k].mate;
         if (mr == NONE32) continue;                            // (k_out_rows wrote NONE into the row)
-        uint32_t lo = 0, hi = n_out;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (w.out_index[mid] < mr) lo = mid + 1; else hi = mid; }
-        o.mate[o.krow[k]] = o.krow[lo];
+        const uint32_t blk = mr >> 6, within = mr & 63u;
+        uint32_t km = o.rank64[blk];
+        const uint64_t *f = reinterpret_cast<const uint64_t *>(w.out_flag + ((uint64_t)blk << 6));       // (the flag array is padded to a multiple of 64)
+        uint64_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = f[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int nb = (int)within - 8 * q;                // bytes of this word in front of the mate
+            if (nb <= 0) continue;
+            uint64_t x = v[q];
+            if (nb < 8) x &= (1ull << (8 * nb)) - 1ull;
+            const uint64_t nz = (((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+            km += (uint32_t)__popcll(nz);
+        }
+        o.mate[o.krow[k]] = o.krow[km];
     }
 }
 

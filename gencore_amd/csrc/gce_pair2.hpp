@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
     const char *up = nullptr;
     if (live && n <= (uint32_t)SUB && hl < (int)n) {
         my = w.members[start + hl];
-        nl = (int)b.core[my].l_qname - 1;
+        const uint64_t ui_ = w.uinfo[my];                          // name length, UMI place and length in one word (round 5: core record, UMI pointer and UMI length were three more sectors per read)
+        nl = (int)((ui_ >> 41) & 0xFFu) - 1;
         nm = d_qname(b, my);
-        ul = w.umi_len[my];
-        up = w.umi_ptr[my];                                 // (asked for with the name's place: where it is used it was two dependent round trips, pointer then bytes)
+        ul = uinfo_len(ui_);
+        up = uinfo_ptr(b, ui_);
     }
     const uint32_t toolong = sub_ballot<SUB>(nl > 64 || ul > 24, hb);
     if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
