@@ -65,6 +65,8 @@ struct gce_engine {
     // reference
     std::vector<DevBuf> ref_buf; std::vector<const uint8_t *> ref_ptr; std::vector<int64_t> ref_len, ref_win; bool have_win = false;
     DevBuf d_ref_ptr, d_ref_len, d_ref_win, d_target_len, d_target_cum;
+    // what the device copies of the five hold (gce_process uploads them only when something changed)
+    std::vector<const uint8_t *> up_ref_ptr; std::vector<int64_t> up_ref_len, up_win; std::vector<uint32_t> up_tl; const void *up_dev[5]{}; bool up_valid = false;
     // host staging (gce_submit)
     std::vector<gce_core> h_core; std::vector<uint64_t> h_qoff, h_coff, h_soff, h_loff, h_mioff;
     std::vector<char> h_qname, h_mi; std::vector<uint32_t> h_cigar; std::vector<uint8_t> h_seq, h_qual, h_nmt; std::vector<int32_t> h_nm; std::vector<uint64_t> h_tick;
@@ -72,7 +74,7 @@ struct gce_engine {
     bool have_mi = false, have_tick = false, have_events = false, host_mode = false, device_mode = false, processed = false;
     // streamed submission (gce_reserve): batches go straight to HBM on their own stream while the caller prepares the next one
     bool reserved = false; hipStream_t up_stream = nullptr; std::vector<hipEvent_t> up_events;
-    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2]{};      // deep streams: k_score2 beside the hand-on + k_deep_prepare (gce_process)
+    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[4]{};      // deep streams: k_score2 beside the hand-on + k_deep_prepare (gce_process)
     size_t rs_n = 0, rs_q = 0, rs_c = 0, rs_s = 0, rs_l = 0, st_n = 0, st_q = 0, st_c = 0, st_s = 0, st_l = 0, st_m = 0; bool dev_concat = false;
     gce_batch dev_batch{};              // device pointers (either uploaded or caller-owned)
     DevBuf b_core, b_qoff, b_qname, b_coff, b_cigar, b_soff, b_seq, b_loff, b_qual, b_nm, b_nmt, b_mioff, b_mi, b_tick;
@@ -95,7 +97,7 @@ struct gce_engine {
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf deep_list, k64, slow_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf deep_list, k64, slow_list, left_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     void *si_pin = nullptr, *si_pin_dev = nullptr; unsigned long long si_seq = 0;      // read_si: the block in mapped host memory + its sequence word
     gce_timing timing{};
@@ -175,7 +177,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_rank64, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->left_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
@@ -616,7 +618,7 @@ static void fill_many(hipStream_t s, std::initializer_list<FillSeg> segs) {
 static int aux_ready(gce_engine *e) {
     if (e->aux_stream) return GCE_OK;
     HIPCHK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&e->aux_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->aux_ev[1], hipEventDisableTiming));
+    for (auto &v : e->aux_ev) HIPCHK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
     return GCE_OK;
 }
 
@@ -680,21 +682,36 @@ static int gce_process_impl(gce_engine *e) {
     b.seq_off = hb.seq_off; b.seq = hb.seq; b.qual_off = hb.qual_off; b.qual = hb.qual; b.nm = hb.nm; b.nm_type = hb.nm_type;
     b.mi_off = hb.mi_off; b.mi = hb.mi; b.tick = e->have_tick ? hb.tick : nullptr;
 
-    // reference + params to the device
+    // reference + params to the device -- only when they changed since the last step (four small copies and two stream synchronisations per step otherwise:
+    // ~60 us of every 6 ms step in front of the first kernel)
     const int nref = (int)e->ref_ptr.size();
     HIPCHK(e->d_ref_ptr.ensure((size_t)(nref + 1) * 8)); HIPCHK(e->d_ref_len.ensure((size_t)(nref + 1) * 8));
-    if (nref) {
-        HIPCHK(hipMemcpyAsync(e->d_ref_ptr.p, e->ref_ptr.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->d_ref_len.p, e->ref_len.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
-    }
     HIPCHK(e->d_target_len.ensure(e->target_len.size() * 4 + 4));
-    if (!e->target_len.empty()) HIPCHK(hipMemcpyAsync(e->d_target_len.p, e->target_len.data(), e->target_len.size() * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e->d_target_cum.ensure(e->target_len.size() * 8 + 8));
-    if (!e->target_len.empty()) {
+    std::vector<int64_t> win;
+    if (e->have_win && nref) {                                                     // contigs staged whole: window = [0, length)
+        win.assign(2 * (size_t)nref, 0);
+        for (int t = 0; t < nref; t++) { const bool wd = 2 * (size_t)t + 1 < e->ref_win.size() && e->ref_win[2 * t + 1] > 0; win[2 * t] = wd ? e->ref_win[2 * t] : 0; win[2 * t + 1] = wd ? e->ref_win[2 * t + 1] : e->ref_len[t]; }
+        HIPCHK(e->d_ref_win.ensure(win.size() * 8));
+    }
+    const void *dev_now[5] = {e->d_ref_ptr.p, e->d_ref_len.p, e->d_target_len.p, e->d_target_cum.p, e->d_ref_win.p};
+    const bool same = e->up_valid && e->up_ref_ptr == e->ref_ptr && e->up_ref_len == e->ref_len && e->up_tl == e->target_len && e->up_win == win && memcmp(dev_now, e->up_dev, sizeof dev_now) == 0;
+    if (!same) {
+        e->up_valid = false;
+        if (nref) {
+            HIPCHK(hipMemcpyAsync(e->d_ref_ptr.p, e->ref_ptr.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->d_ref_len.p, e->ref_len.data(), (size_t)nref * 8, hipMemcpyHostToDevice, e->stream));
+        }
         std::vector<uint64_t> cum(e->target_len.size()); uint64_t acc = 0;
         for (size_t i = 0; i < cum.size(); i++) { cum[i] = acc; acc += e->target_len[i]; }
-        HIPCHK(hipMemcpyAsync(e->d_target_cum.p, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        if (!e->target_len.empty()) {
+            HIPCHK(hipMemcpyAsync(e->d_target_len.p, e->target_len.data(), e->target_len.size() * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->d_target_cum.p, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, e->stream));
+        }
+        if (!win.empty()) HIPCHK(hipMemcpyAsync(e->d_ref_win.p, win.data(), win.size() * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));                                       // (the sources are locals and vectors that may change)
+        e->up_ref_ptr = e->ref_ptr; e->up_ref_len = e->ref_len; e->up_tl = e->target_len; e->up_win = win; memcpy(e->up_dev, dev_now, sizeof dev_now);
+        e->up_valid = true;
     }
     DevParams p{};
     p.proper_thr = e->prm.proper_umi_diff_threshold; p.unproper_thr = e->prm.unproper_umi_diff_threshold;
@@ -727,15 +744,7 @@ static int gce_process_impl(gce_engine *e) {
         int bl = 1; while (bl < 32 && (1ull << bl) <= (uint64_t)mx) bl++;
         p.key_bt = bt; p.key_bl = bl;
     }
-    p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>(); p.ref_win = nullptr;
-    if (e->have_win && nref) {                                                     // contigs staged whole: window = [0, length)
-        std::vector<int64_t> win(2 * (size_t)nref, 0);
-        for (int t = 0; t < nref; t++) { const bool wd = 2 * (size_t)t + 1 < e->ref_win.size() && e->ref_win[2 * t + 1] > 0; win[2 * t] = wd ? e->ref_win[2 * t] : 0; win[2 * t + 1] = wd ? e->ref_win[2 * t + 1] : e->ref_len[t]; }
-        HIPCHK(e->d_ref_win.ensure(win.size() * 8));
-        HIPCHK(hipMemcpyAsync(e->d_ref_win.p, win.data(), win.size() * 8, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        p.ref_win = e->d_ref_win.as<int64_t>();
-    }
+    p.n_ref = nref; p.ref_data = e->d_ref_ptr.as<const uint8_t *>(); p.ref_len = e->d_ref_len.as<int64_t>(); p.ref_win = win.empty() ? nullptr : e->d_ref_win.as<int64_t>();
 
     // ---- allocations that only depend on N
     Work w{};
@@ -854,13 +863,13 @@ static int gce_process_impl(gce_engine *e) {
         //  [g_begin, g_begin + g_np) of a group only, and the pairing kernels write both words of every one of those)
         // three tiers: 16 lanes per cluster, then 32 for what that flags, then the full wave; each hand-over is a flag array
         // compacted by the scan kernels (never one shared append counter)
+        ENS(left_list, c1 * 4 + 64); w.left_list = e->left_list.as<uint32_t>();
         ENS(pf_flag, c1 + 64); ENS(pf_list, c1 * 4); ENS(pq_flag, c1 + 64); ENS(pq_list, c1 * 4); ENS(p16_flag, c1 + 64); ENS(p16_list, c1 * 4);
         w.pf_flag = e->pf_flag.as<uint8_t>(); w.pf_list = e->pf_list.as<uint32_t>(); w.pq_flag = e->pq_flag.as<uint8_t>(); w.pq_list = e->pq_list.as<uint32_t>(); w.p16_flag = e->p16_flag.as<uint8_t>(); w.p16_list = e->p16_list.as<uint32_t>();
         // size classes in front of the quarter-wave kernel (k_pair_classes) when a good share of the clusters is beyond it: mean cluster beyond 10 reads
         // (cfg3: 16 reads, 45 % of the clusters beyond 16 -- pairing 1.41 -> 1.26 ms; cfg2: 7 reads, nearly none -- the class pass would be 16 us for nothing)
         const bool pair_classes = (double)N > 10.0 * (double)C;
-        if (pair_classes) fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}});          // (pq_flag / p16_flag: every entry written by k_pair_classes)
-        else fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}, FillSeg{e->pq_flag.p, c1, 0u, 0u}});
+        if (!pair_classes) fill_many(s, {FillSeg{e->pf_flag.p, c1, 0u, 0u}, FillSeg{e->pq_flag.p, c1, 0u, 0u}});          // (with size classes every entry of the three flag arrays is written by k_pair_classes)
         const unsigned nbc = cdiv(C, SCAN_TILE);
         auto compact = [&](uint8_t *flag, uint32_t *list, unsigned long long *count) {
             hipLaunchKernelGGL(k_flag_reduce, dim3(nbc), dim3(256), 0, s, (const uint8_t *)flag, (uint64_t)C, w.scan_part);
@@ -871,26 +880,45 @@ static int gce_process_impl(gce_engine *e) {
         {   // experiment builds (tools/pair_stop.sh): time the truncated k_pairing_sub<16> (all clusters) and <32> (all clusters as well: no list) alone and stop
             hipEvent_t a_, b_, c_; (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventCreate(&c_);
             (void)hipEventRecord(a_, s);
-            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag, 0);
             (void)hipEventRecord(b_, s);
-            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pf_flag);
+            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pf_flag, 0);
             (void)hipEventRecord(c_, s); (void)hipEventSynchronize(c_);
             float m1 = 0, m2 = 0; (void)hipEventElapsedTime(&m1, a_, b_); (void)hipEventElapsedTime(&m2, b_, c_);
             fprintf(stderr, "k_pairing_sub up to tick %d: <16> %.3f ms, <32> over ALL clusters %.3f ms\n", PS_STOP, m1, m2);
             return fail(e, GCE_ERR_INVALID, "experiment build");
         }
 #endif
-        if (pair_classes) {
-            hipLaunchKernelGGL(k_pair_classes, dim3(cdiv(C, 256)), dim3(256), 0, s, (const uint32_t *)w.cl_n, C, w.p16_flag, w.pq_flag);
-            compact(w.p16_flag, w.p16_list, &w.si->n_p16_items);
-            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.p16_list, (const unsigned long long *)&w.si->n_p16_items, w.pq_flag);
-        } else hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag);
-        compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
-        hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag);
-        compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
-        hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
-        hipLaunchKernelGGL(k_pairing_deep<false>, dim3(256), dim3(PD_T), 0, s, b, p, w, (uint8_t *)nullptr);      // deep clusters in LDS; the rest -> pq_list
         ENS(pd_slab, PD_BIG_BLOCKS * PD_SLAB);
+        if (pair_classes) {
+            // the three register-resident tiers get their clusters BY SIZE beforehand (<= 16, <= 32, more) and run side by side: quarter- and half-wave kernels on the main
+            // stream, the full-wave kernel and the LDS instantiation of k_pairing_deep -- the long, thin tail of the phase: 93 + 60 us with a few thousand waves -- on the second
+            // one.  What a tier cannot take for its names / UMIs goes straight to the generic kernels' list (`direct`), which every tier would have handed it to in turn.
+            hipLaunchKernelGGL(k_pair_class_reduce, dim3(nbc), dim3(256), 0, s, (const uint32_t *)w.cl_n, C, w.scan_part);
+            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nbc, &w.si->n_p16_items, &w.si->n_pq_items);
+            hipLaunchKernelGGL(k_pair_class_apply, dim3(nbc), dim3(256), 0, s, (const uint32_t *)w.cl_n, C, (const uint64_t *)w.scan_part, w.p16_list, w.pq_list, w.pf_list, w.si);
+            static const bool tiers_aux = getenv("GCE_NO_AUX_STREAM") == nullptr;
+            hipStream_t s2 = s;
+            if (tiers_aux) {
+                if ((rc = aux_ready(e)) != GCE_OK) return rc;
+                s2 = e->aux_stream;
+                HIPCHK(hipEventRecord(e->aux_ev[0], s));
+                HIPCHK(hipStreamWaitEvent(s2, e->aux_ev[0], 0));
+            }
+            hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s2, b, p, w, C, (const uint32_t *)w.pf_list);
+            hipLaunchKernelGGL(k_pairing_deep<false>, dim3(256), dim3(PD_T), 0, s2, b, p, w, (uint8_t *)nullptr);      // deep clusters in LDS; the rest -> left_list
+            if (tiers_aux) HIPCHK(hipEventRecord(e->aux_ev[1], s2));
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.p16_list, (const unsigned long long *)&w.si->n_p16_items, w.pq_flag, 1);
+            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag, 1);
+            if (tiers_aux) HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));
+        } else {
+            hipLaunchKernelGGL(k_pairing_sub<16>, dim3(cdiv(C, 4 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, w.pq_flag, 0);
+            compact(w.pq_flag, w.pq_list, &w.si->n_pq_items);
+            hipLaunchKernelGGL(k_pairing_sub<32>, dim3(cdiv(C, 2 * WAVES_PER_BLOCK)), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pq_list, (const unsigned long long *)&w.si->n_pq_items, w.pf_flag, 0);
+            compact(w.pf_flag, w.pf_list, &w.si->n_pf_items);
+            hipLaunchKernelGGL(k_pairing_fast, dim3(2048), dim3(256), 0, s, b, p, w, C, (const uint32_t *)w.pf_list);
+            hipLaunchKernelGGL(k_pairing_deep<false>, dim3(256), dim3(PD_T), 0, s, b, p, w, (uint8_t *)nullptr);      // deep clusters in LDS; the rest -> left_list
+        }
         hipLaunchKernelGGL(k_pairing_deep<true>, dim3(PD_BIG_BLOCKS), dim3(PD_T), 0, s, b, p, w, e->pd_slab.as<uint8_t>());   // what that left for its size (<= 65 534 reads), arrays in device memory
         hipLaunchKernelGGL(k_pairing_slow<0>, dim3(1024), dim3(256), 0, s, b, p, w);
         hipLaunchKernelGGL(k_pairing_slow<1>, dim3(1024, 16), dim3(256), 0, s, b, p, w);      // y: a cluster's 64-read blocks over 16 waves
@@ -1024,7 +1052,7 @@ static int gce_process_impl(gce_engine *e) {
         o.fr = e->o_fr.as<int16_t>(); o.rr = e->o_rr.as<int16_t>(); o.mate = e->o_mate.as<uint32_t>();
         o.seq_off = e->o_soff.as<uint64_t>(); o.qual_off = e->o_qoff.as<uint64_t>(); o.seq = e->o_seq.as<uint8_t>(); o.qual = e->o_qual.as<uint8_t>();
         o.key = e->o_key.as<OutKey>(); o.rec = e->o_rec.as<OutRec>(); o.ksoff = e->o_ksoff.as<uint64_t>(); o.kqoff = e->o_kqoff.as<uint64_t>(); o.krow = e->o_krow.as<uint32_t>(); o.rank64 = e->o_rank64.as<uint32_t>(); o.part3 = e->o_part3.as<uint64_t>();
-        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups
+        hipLaunchKernelGGL(k_stats, dim3(1024), dim3(256), 0, s, b, w, (NG > 0 ? C : 0u), NG);     // Stats: clusters, groups  (round 5: on the second stream beside the output kernels it hid its 50 us and stretched k_out_reduce / k_out_partials by as much: not kept)
         CANARY("k_stats");
         hipLaunchKernelGGL(k_out_reduce, dim3(nblk_O), dim3(OUT_T), 0, s, b, w, o);
         CANARY("k_out_reduce");

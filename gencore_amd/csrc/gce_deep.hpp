@@ -403,7 +403,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         __syncthreads();
         const uint32_t li = s_li;
         if (li >= n_list) break;
-        const uint32_t c = BIG ? w.pq_list[li] : w.slow_list[li];
+        const uint32_t c = BIG ? w.left_list[li] : w.slow_list[li];
         const uint32_t start = w.cl_start[c], n = w.cl_n[c];
         bool take = BIG ? (n > PD_MAX && n <= PD_BIGMAX - 2) : (n > 64 && n <= PD_MAX);      // (BIG: only what the LDS instantiation left for its size)
         if (take) {
@@ -417,9 +417,9 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             if (bad) s_flag = 1;
         }
         __syncthreads();
-        if (!take || s_flag) { if (!BIG && tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }      // (BIG: the entry stays for the generic kernels)
+        if (!take || s_flag) { if (!BIG && tid == 0) w.left_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }      // (BIG: the entry stays for the generic kernels)
         const uint32_t mode = d_thr_mode(w.cl_ikey[c], w.si, p);
-        if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; if (BIG) w.pq_list[li] = NONE32; } continue; }
+        if (mode == THR_NEVER) { if (tid == 0) { w.cl_npairs[c] = 0; w.cl_ngroups[c] = 0; w.cl_hasumi[c] = 0; if (BIG) w.left_list[li] = NONE32; } continue; }
 #ifdef VB_PROF
         unsigned long long pd_prev_ = wall_clock64();
         if (threadIdx.x == 0) atomicAdd(&w.si->prof[30], 1ull);
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
             if (toolong) s_flag = 1;
         }
         __syncthreads();
-        if (s_flag) { __syncthreads(); if (!BIG && tid == 0) w.pq_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }   // hundreds of names behind one window: generic kernels
+        if (s_flag) { __syncthreads(); if (!BIG && tid == 0) w.left_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; continue; }   // hundreds of names behind one window: generic kernels
         PD_TICK(1);
         // ---- 2. pairs
         const int per = (P + PD_T - 1) / PD_T;                                     // sorted positions per thread (contiguous)
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(PD_T) void k_pairing_deep(DevBatch b, DevParams p, 
         if (tid == 0) {
             const bool cross = d_key(b.core[w.members[start]], p).right < 0;
             w.cl_npairs[c] = npairs; w.cl_ngroups[c] = ngroups; w.cl_hasumi[c] = (uint8_t)((any_umi ? 1 : 0) | (cross ? 2 : 0));
-            if (BIG) w.pq_list[li] = NONE32;                                       // done here: struck out of the generic kernels' list
+            if (BIG) w.left_list[li] = NONE32;                                       // done here: struck out of the generic kernels' list
         }
     }
 }

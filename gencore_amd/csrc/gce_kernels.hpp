@@ -55,6 +55,8 @@ struct Work {
     uint32_t *slow_list;                 // (group*2 + side) entries deferred to the generic consensus kernel
     uint8_t *pf_flag; uint32_t *pf_list;      // clusters the half-wave pairing kernel hands to the full-wave one (same scheme)
     uint8_t *pq_flag; uint32_t *pq_list;      // ... and the quarter-wave kernel to the half-wave one
+    uint32_t *left_list;                 // clusters left for k_pairing_deep<device memory> / the generic pairing kernels (count: si->n_slow_pair2).  A list of its own since round 5:
+                                         // it is appended to while the half-wave kernel still reads pq_list (the pairing tiers run side by side on two streams)
     uint8_t *p16_flag; uint32_t *p16_list;    // clusters of <= 16 reads, compacted: the quarter-wave kernel runs on full waves (k_pair_classes)
     void *deep_list;                       // DeepRec[] (gce_deep.hpp)
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void k_pairing_slow(DevBatch b, DevParams p, W
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t n_slow = w.si->n_slow_pair2;                                      // what k_pairing_deep (gce_deep.hpp) left over
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
-        const uint32_t c = w.pq_list[idx];
+        const uint32_t c = w.left_list[idx];
         if (c != NONE32) pairing_generic<PHASE>(b, p, w, c, lane, blockIdx.y, gridDim.y);      // (NONE32: taken by the device-memory instantiation of k_pairing_deep)
         WAVE_SYNC();
     }

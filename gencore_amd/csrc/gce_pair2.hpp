@@ -29,11 +29,46 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) { return (uint64
 // Size classes in front of the pairing kernels: the quarter-wave kernel used to run over ALL clusters and flag the ones of more than 16 reads for the
 // next one -- 45 % of cfg3's clusters, a dead quarter of a wave each, in a kernel that executes the same instruction stream whatever share of its lanes
 // is alive.  Now it gets the compacted list of the clusters it can take; the others are flagged for the half-wave kernel here.
-__global__ __launch_bounds__(256) void k_pair_classes(const uint32_t *cl_n, uint32_t n_clusters, uint8_t *f16, uint8_t *fq) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_clusters) return;
-    const bool small = cl_n[c] <= 16u;
-    f16[c] = small ? 1 : 0; fq[c] = small ? 0 : 1;
+// Round 5: the three lists (<= 16 reads, <= 32, more) come out of ONE compaction over cl_n -- counts of the first two classes in the halves of one 64-bit partial per tile
+// (k_scan_partials scans both at once; the third follows from the tile's place) -- instead of a flag pass and three flag compactions: 3 launches where there were 10.
+__device__ __forceinline__ int pair_class(uint32_t n) { return n <= 16u ? 0 : (n <= 32u ? 1 : 2); }        // (beyond 64 reads: the full-wave kernel hands the cluster on itself)
+__global__ __launch_bounds__(256) void k_pair_class_reduce(const uint32_t *cl_n, uint32_t n_clusters, uint64_t *part) {
+    __shared__ uint64_t s[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint64_t v = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        const uint64_t i = base + k * 256 + threadIdx.x;
+        if (i < n_clusters) { const int c = pair_class(cl_n[i]); v += c == 0 ? (1ull << 32) : (c == 1 ? 1ull : 0ull); }
+    }
+    v = (uint64_t)wave_sum64((long long)v);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(256) void k_pair_class_apply(const uint32_t *cl_n, uint32_t n_clusters, const uint64_t *part, uint32_t *l16, uint32_t *l32, uint32_t *l64, StreamInfo *si) {
+    __shared__ uint32_t s_w[4][2];
+    __shared__ uint32_t s_c0, s_c1;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    if (threadIdx.x == 0) { s_c0 = (uint32_t)(part[blockIdx.x] >> 32); s_c1 = (uint32_t)part[blockIdx.x]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) si->n_pf_items = (unsigned long long)n_clusters - si->n_p16_items - si->n_pq_items;     // (k_scan_partials left the other two totals)
+    __syncthreads();
+    for (int k = 0; k < SCAN_TILE / 256; k++) {
+        const uint64_t i = base + k * 256 + threadIdx.x;
+        const int c = i < n_clusters ? pair_class(cl_n[i]) : -1;
+        const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1);
+        if (lane == 0) { s_w[wv][0] = (uint32_t)__popcll(m0); s_w[wv][1] = (uint32_t)__popcll(m1); }
+        __syncthreads();
+        uint32_t o0 = s_c0, o1 = s_c1, t0 = 0, t1 = 0;
+        for (int q = 0; q < 4; q++) { if (q < wv) { o0 += s_w[q][0]; o1 += s_w[q][1]; } t0 += s_w[q][0]; t1 += s_w[q][1]; }
+        const uint32_t r0 = o0 + (uint32_t)lanes_below(m0), r1 = o1 + (uint32_t)lanes_below(m1);
+        if (c == 0) l16[r0] = (uint32_t)i;
+        else if (c == 1) l32[r1] = (uint32_t)i;
+        else if (c == 2) l64[(uint32_t)i - r0 - r1] = (uint32_t)i;           // clusters in front of i that are of neither of the first two classes
+        __syncthreads();
+        if (threadIdx.x == 0) { s_c0 += t0; s_c1 += t1; }
+        __syncthreads();
+    }
 }
 // SUB = lanes per cluster (32: two clusters per wave, 16: four).  `list` != nullptr: the clusters a narrower instantiation flagged.
 #ifdef PS_STOP                        // cumulative cost of the phases (tools/pair_stop.sh): the kernel ends at tick PS_STOP
@@ -42,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint32_t *cl_n, uint
 #define PS_TICK(k, live_) do { } while (0)
 #endif
 template <int SUB>
-__global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Work w, uint32_t n_clusters, const uint32_t *list, const unsigned long long *list_n, uint8_t *flag_out) {
+__global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Work w, uint32_t n_clusters, const uint32_t *list, const unsigned long long *list_n, uint8_t *flag_out, int direct) {
     constexpr int PER = 64 / SUB;
     const int lane = lane_id(), hl = lane & (SUB - 1), hb = lane & ~(SUB - 1);
     const uint32_t idx = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * PER + (uint32_t)(lane / SUB);
@@ -68,7 +103,10 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
         up = uinfo_ptr(b, ui_);
     }
     const uint32_t toolong = sub_ballot<SUB>(nl > 64 || ul > 24, hb);
-    if (live && (n > (uint32_t)SUB || toolong)) { if (hl == 0) flag_out[c] = 1; live = false; }    // the next wider kernel takes it
+    if (live && (n > (uint32_t)SUB || toolong)) {                                                  // the next wider kernel takes it -- or, when the tiers were given their clusters by size
+        if (hl == 0) { if (direct) w.left_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; else flag_out[c] = 1; }     // beforehand (direct: they run side by side), the generic kernels: what is left here then has
+        live = false;                                                                              // names beyond 64 bytes or UMIs beyond 24, which every tier up to those hands on
+    }
     if (!__any(live)) return;
     PS_TICK(0, my ^ (uint32_t)nl ^ (uint32_t)ul ^ (uint32_t)(uintptr_t)nm ^ (uint32_t)(uintptr_t)up);
     const bool act = live && hl < (int)n;
@@ -123,7 +161,7 @@ __global__ __launch_bounds__(256) void k_pairing_sub(DevBatch b, DevParams p, Wo
             for (int k = 0; k < 8; k++) if (k < nwords) { const uint64_t o = shfl64(nw[k], hb + sl); if (has && o != nw[k]) bad = true; }
         }
         const uint32_t badm = sub_ballot<SUB>(bad, hb);
-        if (live && badm) { if (hl == 0) w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; live = false; }     // false hash match: generic kernel
+        if (live && badm) { if (hl == 0) { if (direct) w.left_list[atomicAdd(&w.si->n_slow_pair2, 1u)] = c; else w.slow_list[atomicAdd(&w.si->n_slow_pair, 1u)] = c; } live = false; }     // false hash match: generic kernel (direct: slow_list is being consumed on the other stream)
     }
     if (!__any(live)) return;
     PS_TICK(2, EQ ^ (LOW << 1));
