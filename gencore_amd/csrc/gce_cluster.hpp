@@ -23,17 +23,21 @@
 //                  pre-Stats counters (stats.cpp:101-121) that pairing and the vote consume; independent of everything above
 #pragma once
 
-#define SB_T 256                         // threads per scan block
+#ifndef SB_T
+#define SB_T 512                         // threads per scan block (round 5: 256 -> 512, scan blocks of 1024 reads: a capture panel spreads a cluster's reads over ~540 reads of the stream,
+#endif                                   // so that a cluster met 2.06 blocks of 512 reads = leader runs = read-modify-writes of k_leaders, and meets 1.5 of 1024)
 #define SB_U 2                           // reads per thread
 #define SB_READS (SB_T * SB_U)           // reads per scan block
-#define SB_LDS_SLOTS 1024                // LDS hash slots for the <= 512 distinct keys of a block
+#define SB_LDS_SLOTS (2 * SB_READS)       // LDS hash slots for the <= SB_READS distinct keys of a block
+#define SB_OFF_BITS (SB_READS == 1024 ? 10 : 9)        // a read's place in its scan block
+static_assert(SB_READS == 512 || SB_READS == 1024, "LeadRec.info packs a place and a count of SB_READS");
 
-// What a leader hands to k_leaders.  info: bits 0..8 its offset inside the scan block; bits 9..18 the clustered reads of the block in
-// front of it (tick = block base + that + 1); bit 19 "odd" (an earlier flush event may have taken the key: run the event test).
+// What a leader hands to k_leaders.  info: bits 0..SB_OFF_BITS-1 its offset inside the scan block; the 11 bits above the clustered reads of the block in
+// front of it (tick = block base + that + 1); bit 22 "odd" (an earlier flush event may have taken the key: run the event test).
 // kw: the packed key word (d_pack_key) or 0 when the key does not fit it (k_leaders derives the key from the leader's key record).
 struct __attribute__((aligned(16))) LeadRec { unsigned long long kw; uint32_t info, runlen; };
 static_assert(sizeof(LeadRec) == 16, "LeadRec must stay 16 bytes");
-#define LI_ODD (1u << 19)
+#define LI_ODD (1u << 22)
 struct __attribute__((aligned(8))) BlkHdr { uint32_t n_lead, n_clu; };
 struct __attribute__((aligned(8))) LeadOut { uint32_t h, rb; };     // bucket; first in-cluster rank of the run | LO_OWNER
 #define LO_OWNER 0x80000000u
@@ -104,7 +108,7 @@ __device__ __forceinline__ unsigned long long d_exotic_key(uint32_t ikey, uint32
 #else
 #define CL_TICK(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Work w) {
+__global__ __launch_bounds__(SB_T, 2048 / SB_T) void k_cluster(DevBatch b, DevParams p, Work w) {
     __shared__ uint32_t s_slot[SB_LDS_SLOTS];
     __shared__ unsigned long long s_kw[SB_READS];
     __shared__ uint32_t s_cnt[SB_READS];
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(SB_T, 8) void k_cluster(DevBatch b, DevParams p, Wo
                 w.slot[idx[u]] = (uint32_t)s_num[leader[u]] | lrank[u] << 16;                 // (leader of the block, rank in its run): 9 + 9 bits, the block is idx / 512
                 if (leader[u] == id) {
                     union { LeadRec r; uint4 q; } o;
-                    o.r.kw = kw[u]; o.r.info = (uint32_t)id | inblock << 9 | (odd[u] ? LI_ODD : 0u); o.r.runlen = s_cnt[id];
+                    o.r.kw = kw[u]; o.r.info = (uint32_t)id | inblock << SB_OFF_BITS | (odd[u] ? LI_ODD : 0u); o.r.runlen = s_cnt[id];
                     *reinterpret_cast<uint4 *>(w.lrec + (size_t)blockIdx.x * SB_READS + s_num[id]) = o.q;
                 }
             } else w.slot[idx[u]] = NONE32;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256) void k_leaders(DevBatch b, DevParams p, Work w
     for (uint32_t kq = (uint32_t)lane; kq < nl; kq += 64) {
         const size_t LR = (size_t)blk * SB_READS + kq;
         union { LeadRec r; uint4 q; } in; in.q = *reinterpret_cast<const uint4 *>(w.lrec + LR);
-        const uint32_t off = in.r.info & 0x1FFu, rk = (in.r.info >> 9) & 0x3FFu;
+        const uint32_t off = in.r.info & ((1u << SB_OFF_BITS) - 1u), rk = (in.r.info >> SB_OFF_BITS) & 0x7FFu;
         const bool odd = (in.r.info & LI_ODD) != 0;
         const uint32_t idx = (uint32_t)(blk * SB_READS + off);
         ClusterKey key;
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(SB_T) void k_scatter(int64_t n, Work w) {
 }
 
 // ===================================================================================================== read descriptors (not formation)
-__global__ __launch_bounds__(256, 8) void k_describe(DevBatch b, DevParams p, Work w, int tiles_per_block) {
+__global__ __launch_bounds__(256, 7) void k_describe(DevBatch b, DevParams p, Work w, int tiles_per_block) {
     __shared__ long long s_stat[WAVES_PER_BLOCK][6];
     long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
     int lqmin = 0x7FFFFFFF, lqmax = -1;

@@ -1663,7 +1663,7 @@ __device__ void consensus_fast_side(const DevBatch &b, const DevParams &p, const
 }
 
 // global-memory consensus, one wave per (group, side): the sides on gen_list (grid-stride, count read on the device)
-__global__ __launch_bounds__(256, 6) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
+__global__ __launch_bounds__(256, 5) void k_consensus_fast(DevBatch b, DevParams p, Work w) {
     __shared__ __attribute__((aligned(16))) uint8_t s_res[WAVES_PER_BLOCK][2048 + 2560 + 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     // the count only exists on the device: a capped grid strides over the list (a wave takes one or two entries when the list is
@@ -1822,9 +1822,64 @@ __global__ __launch_bounds__(256) void k_group_tail(DevBatch b, DevParams p, Wor
 }
 
 // Duplex matching (cluster.cpp:119-168), one wave per cluster that has UMIs and at least two groups.
+// Round 5: a cluster of <= 64 groups keeps its groups in the LANES -- state, reads, merge count, and the two '_'-separated tokens of the UMI as zero-padded big-endian
+// words (UMI characters are never NUL, so equal words are equal strings: Cluster::isDuplex, cluster.cpp:246-258, is two 64-bit compares) -- and the walk from the
+// last group down is a broadcast and a ballot per group.  The walk over memory below (any number of groups, tokens of any length) loads every partner's UMI bytes
+// and state again for every group: ~8 dependent round trips per group on a one-wave chain, 305 us at cfg5 for clusters of ~45 groups.
+__device__ bool finish_cluster_lanes(const DevBatch &b, const DevParams &p, const Work &w, uint32_t g0, uint32_t G, int lane) {
+    const bool in = lane < (int)G;
+    const uint32_t gme = g0 + (uint32_t)lane;
+    uint32_t l = NONE32, r = NONE32, m = 0; uint64_t t0 = 0, t1 = 0; bool two = false, lng = false;
+    if (in) {
+        const char *u = w.rp_umi[gme]; const int ul = w.rp_umilen[gme];
+        l = w.rp_left[gme]; r = w.rp_right[gme]; m = w.rp_merge[gme];
+        int s0, l0, s1, l1;
+        two = d_split2(u, ul, s0, l0, s1, l1) == 2;
+        if (two) {
+            if (l0 > 8 || l1 > 8) lng = true;
+            else { uint64_t a[1], c2[1]; load_be_words<1>(u + s0, l0, a); load_be_words<1>(u + s1, l1, c2); t0 = a[0]; t1 = c2[0]; }
+        }
+    }
+    if (__any(lng)) return false;                            // a token beyond eight bytes: the walk over memory
+    int st = RP_PENDING;                                     // (k_group_tail left every group of such a cluster pending)
+    for (int idx = (int)G - 1; idx >= 0; idx--) {
+        if (__shfl(st, idx) == RP_CONSUMED) continue;        // (wave-uniform)
+        const uint64_t a0 = (uint64_t)__shfl((long long)t0, idx), a1 = (uint64_t)__shfl((long long)t1, idx);
+        const int atwo = __shfl((int)two, idx);
+        const bool hit = lane < idx && st == RP_PENDING && two && atwo && a0 == t1 && a1 == t0;
+        const unsigned long long hm = __ballot(hit);
+        const uint32_t gi = g0 + (uint32_t)idx;
+        const uint32_t l1 = (uint32_t)__shfl((int)l, idx), r1 = (uint32_t)__shfl((int)r, idx), m1 = (uint32_t)__shfl((int)m, idx);
+        if (hm) {
+            const int found = __ffsll((long long)hm) - 1;    // the first partner in group order (cluster.cpp:130-141)
+            const uint32_t g2 = g0 + (uint32_t)found;
+            const uint32_t l2 = (uint32_t)__shfl((int)l, found), r2 = (uint32_t)__shfl((int)r, found), m2 = (uint32_t)__shfl((int)m, found);
+            int diff = 0;
+            if (l1 != NONE32 && l2 != NONE32) diff += d_duplex_merge_bam(b, l1, l2, lane);
+            if (r1 != NONE32 && r2 != NONE32) diff += d_duplex_merge_bam(b, r1, r2, lane);
+            const bool outp = diff <= p.duplex_mismatch_thr && (int)(m1 + m2) >= p.cluster_size_req;
+            if (lane == idx) st = outp ? RP_OUT_DCS : RP_DROPPED;
+            if (lane == found) st = RP_CONSUMED;
+            if (lane == 0) {
+                w.rp_supp[gi] = (int)(m1 + m2);
+                w.rp_rmerge[gi] = m2;
+                w.rp_state[gi] = outp ? RP_OUT_DCS : RP_DROPPED;
+                w.rp_state[g2] = RP_CONSUMED;
+                if (outp) d_emit_pair(w, gi, true);
+            }
+            WAVE_SYNC();                                     // (the merged bases / qualities of this pair before anybody reads them again)
+        } else {
+            const bool outp = !p.duplex_only && (int)m1 >= p.cluster_size_req;
+            if (lane == idx) st = outp ? RP_OUT_SSCS : RP_DROPPED;
+            if (lane == 0) { w.rp_supp[gi] = (int)m1; w.rp_state[gi] = outp ? RP_OUT_SSCS : RP_DROPPED; if (outp) d_emit_pair(w, gi, false); }
+        }
+    }
+    return true;
+}
 __device__ void finish_cluster(const DevBatch &b, const DevParams &p, const Work &w, uint32_t c, int lane) {
     const uint32_t G = w.cl_ngroups[c];
     const uint32_t g0 = w.cl_gbase[c];
+    if (G <= 64u && finish_cluster_lanes(b, p, w, g0, G, lane)) return;
     for (int idx = (int)G - 1; idx >= 0; idx--) {
         uint32_t gi = g0 + idx;
         if (w.rp_state[gi] == RP_CONSUMED) continue;
