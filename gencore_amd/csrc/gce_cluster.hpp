@@ -569,7 +569,10 @@ __global__ __launch_bounds__(SB_T) void k_scatter(int64_t n, Work w) {
 }
 
 // ===================================================================================================== read descriptors (not formation)
-__global__ __launch_bounds__(256, 7) void k_describe(DevBatch b, DevParams p, Work w, int tiles_per_block) {
+#ifndef DESC_WPE
+#define DESC_WPE 8                       // (64 VGPRs and 44 bytes of scratch per lane; at seven waves -- 72 VGPRs, no scratch -- the kernel is 14 us SLOWER: profiles/r05_y_ab_round_start_vs_head.log)
+#endif
+__global__ __launch_bounds__(256, DESC_WPE) void k_describe(DevBatch b, DevParams p, Work w, int tiles_per_block) {
     __shared__ long long s_stat[WAVES_PER_BLOCK][6];
     long long st[6] = {0, 0, 0, 0, 0, 0};       // reads, bases, reads_unmapped, bases_unmapped, base_mismatches, reads_with_mismatches
     int lqmin = 0x7FFFFFFF, lqmax = -1;
