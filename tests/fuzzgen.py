@@ -20,7 +20,7 @@ def _mutate(seq, rate, rng):
     return "".join(out)
 
 
-def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=False):
+def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=False, umi_lens=(4, 6, 8)):
     """Returns (ReadBatch, params overrides dict, reference list [(nibble array|None, n_bases)], contig lengths)."""
     from oracle import oracle_py
     rng = random.Random(seed)
@@ -43,7 +43,7 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=Fals
         far = tid == 1 and rng.random() < 0.15
         start = rng.randint(10, contig_len[tid] - (ins if not far else 150000) - 3 * L - 20)
         depth = deep if (deep and m == 0) else rng.choice([1, 1, 2, 3, 4, 6, 9])
-        umi_a = "".join(rng.choice("ACGT") for _ in range(rng.choice([4, 6, 8])))
+        umi_a = "".join(rng.choice("ACGT") for _ in range(rng.choice(list(umi_lens))))
         umi_b = "".join(rng.choice("ACGT") for _ in range(len(umi_a)))
         cross = rng.random() < 0.08
         cross_tid = rng.choice([t for t in (0, 1, 2) if t != tid])

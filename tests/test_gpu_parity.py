@@ -70,6 +70,16 @@ def test_fuzz_deep_cluster(built, seed, deep):
         assert got.fr.max() >= 0
 
 
+@pytest.mark.parametrize("seed,deep,umi_lens", [(220, None, (10, 12)), (221, 40, (9,)), (222, 120, (4,)), (223, 90, (12,))])
+def test_duplex_matching_beyond_the_lane_path(built, seed, deep, umi_lens):
+    """Cluster::isDuplex (cluster.cpp:246-258) on the paths beside finish_cluster_lanes: UMI tokens beyond eight bytes (the groups' tokens do not fit the
+    64-bit words of the lanes: the walk over memory), and a deep cluster whose 4-base UMIs with errors fall into many groups (beyond 64: the same walk)."""
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, n_mol=12, umi_mode="duplex", deep=deep, umi_lens=umi_lens)
+    over["duplex_only"] = 0; over["disable_duplex"] = 0; over["duplex_mismatch_threshold"] = 80          # (so that partners found are merged, not dropped)
+    over["skip_low_complexity_cluster_threshold"] = 1000
+    run_both(batch, fuzzgen.make_params(over, contig_len), reference)
+
+
 @pytest.mark.parametrize("seed,deep,umi_mode", [(210, 2300, "duplex"), (211, 2700, "none"), (212, 5200, "prefix")])
 def test_cluster_beyond_the_lds_pairing_kernel(built, seed, deep, umi_mode):
     """> 4096 reads in one cluster: k_pairing_deep's LDS instantiation leaves it for its size, the device-memory instantiation (same
