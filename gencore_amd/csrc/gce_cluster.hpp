@@ -26,7 +26,9 @@
 #ifndef SB_T
 #define SB_T 512                         // threads per scan block (round 5: 256 -> 512, scan blocks of 1024 reads: a capture panel spreads a cluster's reads over ~540 reads of the stream,
 #endif                                   // so that a cluster met 2.06 blocks of 512 reads = leader runs = read-modify-writes of k_leaders, and meets 1.5 of 1024)
+#ifndef SB_U
 #define SB_U 2                           // reads per thread
+#endif
 #define SB_READS (SB_T * SB_U)           // reads per scan block
 #define SB_LDS_SLOTS (2 * SB_READS)       // LDS hash slots for the <= SB_READS distinct keys of a block
 #define SB_OFF_BITS (SB_READS == 1024 ? 10 : 9)        // a read's place in its scan block
