@@ -97,7 +97,7 @@ struct gce_engine {
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf deep_list, k64, slow_list, left_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf slow_args, deep_list, k64, slow_list, left_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     void *si_pin = nullptr, *si_pin_dev = nullptr; unsigned long long si_seq = 0;      // read_si: the block in mapped host memory + its sequence word
     gce_timing timing{};
@@ -177,7 +177,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_rank64, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->left_list, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->left_list, &e->slow_args, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
@@ -954,6 +954,11 @@ static int gce_process_impl(gce_engine *e) {
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
     w.rp_nm = e->rp_nm.as<int32_t>(); w.rp_qsl = e->rp_qsl.as<uint32_t>(); w.rp_qsr = e->rp_qsr.as<uint32_t>();
     if (NG > 0 && e->dev_error == 0) {
+        {   // argument blocks of the generic consensus kernel in device memory (gce_kernels.hpp); here, where the host has just waited for the GPU anyway: `w` is complete
+            SlowArgs sa; sa.b = b; sa.p = p; sa.w = w;
+            HIPCHK(e->slow_args.ensure(sizeof sa));
+            HIPCHK(hipMemcpyAsync(e->slow_args.p, &sa, sizeof sa, hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+        }
         // one launch for the five clears (spatch needs none: k_score2 writes the patch word of both reads of every pair it scores, and only those are read)
         fill_many(s, {FillSeg{e->gen_flag.p, g1 * 2, 0u, 0u},
                       FillSeg{e->rp_nm.p, g1 * 8, 0xFFu, 0u},                                  // -1: NM untouched
@@ -998,7 +1003,7 @@ static int gce_process_impl(gce_engine *e) {
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);
         }
         hipLaunchKernelGGL(k_vote_deep, dim3(1024), dim3(DV_T), 0, s, b, p, w);                 // deep sides, one block each; leaves what it cannot take
-        LAUNCH_EV(k_consensus_slow, dim3(512), dim3(256), s, e->ev[EV_CONSENSUS], b, p, w);
+        LAUNCH_EV(k_consensus_slow, dim3(512), dim3(256), s, e->ev[EV_CONSENSUS], (const SlowArgs *)e->slow_args.p);
         CANARY("EV_CONSENSUS");
         hipLaunchKernelGGL(k_group_tail, dim3(cdiv(NG, 256)), dim3(256), 0, s, b, p, w, NG);
         if (!p.disable_duplex) {                                                                  // duplex stage: flagged clusters, compacted, a wave each

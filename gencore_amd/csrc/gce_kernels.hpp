@@ -1173,16 +1173,21 @@ __device__ inline void d_record_umi(const DevBatch &b, const DevParams &p, const
 }
 
 // ---- generic (any depth, any nibble, any length) consensus of deferred group sides: LDS tallies, global scratch
-__global__ __launch_bounds__(256) void k_consensus_slow(DevBatch b, DevParams p, Work w) {
+// The three argument blocks come through DEVICE MEMORY (round 5): side_consensus is a real call that takes them by reference, and by-value kernel arguments whose address
+// is taken are copied into scratch in the kernel's prologue -- 992 bytes per lane, 124 MB written by every launch (512 blocks x 256 lanes) in front of the first look at the
+// list, as a rule for a few hundred sides (profiles/r05_z_hbm_traffic.csv).
+struct SlowArgs { DevBatch b; DevParams p; Work w; };
+__global__ __launch_bounds__(256) void k_consensus_slow(const SlowArgs *a) {
     __shared__ uint32_t s_tally[WAVES_PER_BLOCK][48 * 64];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const Work &w = a->w;
     const uint32_t n_slow = (uint32_t)w.si->n_slow;
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n_slow; idx += gridDim.x * WAVES_PER_BLOCK) {
         uint32_t e = w.slow_list[idx], gi = e >> 1; bool is_left = !(e & 1);
         if (w.gen_flag[e] == 2) continue;                                       // finished by k_vote_deep (gce_deep.hpp)
         uint32_t c = w.gl_cluster[gi], g = gi - w.cl_gbase[c], cstart = w.cl_start[c];
         uint32_t begin = w.grp_begin[cstart + g], np = w.grp_n[cstart + g];
-        uint32_t out = side_consensus(b, p, w, begin, np, is_left, s_tally[wv], lane, w.rp_nm + e);
+        uint32_t out = side_consensus(a->b, a->p, w, begin, np, is_left, s_tally[wv], lane, w.rp_nm + e);
         if (lane == 0) { if (is_left) w.rp_left[gi] = out; else w.rp_right[gi] = out; }
         WAVE_SYNC();
     }
