@@ -97,7 +97,7 @@ struct gce_engine {
     bool tab_clean = false; const void *tab_clean_ptr = nullptr;   // the bucket table is all-zero (k_scatter wipes what a step used)
     DevBuf cl_ikey, cl_start, cl_n, cl_npairs, cl_ngroups, cl_gbase, cl_nresult, cl_hasumi;
     DevBuf members, sorted, pl, pr, pu, pg, gpl, gpr, grp_begin, grp_n, gl_cluster, g_begin, g_np;
-    DevBuf slow_args, deep_list, k64, slow_list, left_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, slot_flag, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
+    DevBuf slow_args, deep_list, k64, slow_list, left_list, pf_flag, pf_list, pq_flag, pq_list, p16_flag, p16_list, pd_slab, gen_flag, gen_list, score_list, gw, g_wbase, vb_start, rp_left, rp_right, rp_merge, rp_rmerge, rp_umi, rp_umilen, rp_state, rp_supp, rp_nm, rp_qsl, rp_qsr, scan_part, si;
     StreamInfo h_si{};
     void *si_pin = nullptr, *si_pin_dev = nullptr; unsigned long long si_seq = 0;      // read_si: the block in mapped host memory + its sequence word
     gce_timing timing{};
@@ -177,7 +177,7 @@ void gce_destroy(gce_engine *e) {
                      &e->o_key, &e->o_rec, &e->o_ksoff, &e->o_kqoff, &e->o_krow, &e->o_rank64, &e->o_part3, &e->o_soff, &e->o_qoff, &e->o_seq, &e->o_qual, &e->ref_ascii, &e->lrec, &e->lout, &e->bhdr,
                      &e->blk_base, &e->ev_tid, &e->ev_pos, &e->ev_read, &e->table, &e->toff, &e->cl_ikey, &e->cl_start, &e->cl_n,
                      &e->cl_npairs, &e->cl_ngroups, &e->cl_gbase, &e->cl_nresult, &e->cl_hasumi, &e->members, &e->sorted, &e->pl, &e->pr, &e->pu,
-                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->left_list, &e->slow_args, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->slot_flag, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
+                     &e->pg, &e->gpl, &e->gpr, &e->grp_begin, &e->grp_n, &e->gl_cluster, &e->g_begin, &e->g_np, &e->deep_list, &e->k64, &e->slow_list, &e->pf_flag, &e->pf_list, &e->pq_flag, &e->pq_list, &e->left_list, &e->slow_args, &e->pd_slab, &e->gen_flag, &e->gen_list, &e->score_list, &e->gw, &e->g_wbase, &e->vb_start, &e->rp_left, &e->rp_right, &e->rp_merge, &e->rp_rmerge,
                      &e->rp_umi, &e->rp_umilen, &e->rp_state, &e->rp_supp, &e->rp_nm, &e->rp_qsl, &e->rp_qsr, &e->scan_part, &e->si};
     for (auto *b : all) b->release();
     for (DevBuf *b : {&e->z_comp, &e->z_dir, &e->z_err, &e->raw, &e->rw_bad, &e->rw_guess, &e->rw_leave, &e->rw_cnt, &e->rw_base, &e->rw_misc, &e->rw_tmp, &e->rw_off, &e->rw_ncig, &e->rw_nmpos, &e->rw_rsize, &e->rw_roff, &e->rw_body}) b->release();
@@ -946,9 +946,9 @@ static int gce_process_impl(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(slot_flag, n1); ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(score_list, n1 * 2 + 64);      /* (<= N / 2 pairs) */ ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4); ENS(rp_nm, g1 * 8); ENS(rp_qsl, g1 * 4); ENS(rp_qsr, g1 * 4);
-    w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.slot_flag = e->slot_flag.as<uint8_t>();
+    w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.score_list = e->score_list.as<uint32_t>();
     w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
     w.rp_merge = e->rp_merge.as<uint32_t>(); w.rp_rmerge = e->rp_rmerge.as<uint32_t>(); w.rp_umi = e->rp_umi.as<const char *>();
     w.rp_umilen = e->rp_umilen.as<uint16_t>(); w.rp_state = e->rp_state.as<uint8_t>(); w.rp_supp = e->rp_supp.as<int32_t>();
@@ -962,8 +962,7 @@ static int gce_process_impl(gce_engine *e) {
         // one launch for the five clears (spatch needs none: k_score2 writes the patch word of both reads of every pair it scores, and only those are read)
         fill_many(s, {FillSeg{e->gen_flag.p, g1 * 2, 0u, 0u},
                       FillSeg{e->rp_nm.p, g1 * 8, 0xFFu, 0u},                                  // -1: NM untouched
-                      FillSeg{e->rp_left.p, g1 * 4, 0xFFu, 0u}, FillSeg{e->rp_right.p, g1 * 4, 0xFFu, 0u},   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
-                      FillSeg{e->slot_flag.p, n1, 0u, 0u}});
+                      FillSeg{e->rp_left.p, g1 * 4, 0xFFu, 0u}, FillSeg{e->rp_right.p, g1 * 4, 0xFFu, 0u}});   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
         const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
 #ifdef VB_STOP
         {   // experiment builds (tools/vote_stop.sh): time the truncated k_vote alone and stop -- it leaves garbage behind
@@ -980,6 +979,7 @@ static int gce_process_impl(gce_engine *e) {
         // voter preparation (k_deep_prepare: a wave per side, latency) -- none of those reads a score or a quality; the votes wait for both.
         const bool deep_stream = ((double)N > 48.0 * (double)NG || getenv("GCE_FORCE_AUX_STREAM")) && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
         const unsigned cf_grid = cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u;
+        const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), 16384u);      // k_score2: waves stride over the list of handed-on pair slots (<= N / 2)
         auto compact_gen = [&]() {   // the flagged sides -> gen_list
             const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
             hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
@@ -990,14 +990,14 @@ static int gce_process_impl(gce_engine *e) {
             if ((rc = aux_ready(e)) != GCE_OK) return rc;
             HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand, the deep sides are on slow_list
             HIPCHK(hipStreamWaitEvent(e->aux_stream, e->aux_ev[0], 0));
-            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, e->aux_stream, b, p, w, (uint32_t)N, 1);
+            hipLaunchKernelGGL(k_score2, dim3(sc2_grid), dim3(256), 0, e->aux_stream, b, p, w);
             HIPCHK(hipEventRecord(e->aux_ev[1], e->aux_stream));
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (template + voter list of the deep sides: reads no score, no quality)
             compact_gen();
             HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));                                // the scores (and the rewritten qualities) stand
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);           // everything else on gen_list
         } else {
-            hipLaunchKernelGGL(k_score2, dim3(cdiv(N, WAVES_PER_BLOCK * 64)), dim3(256), 0, s, b, p, w, (uint32_t)N, 1);       // the handed-on groups only
+            hipLaunchKernelGGL(k_score2, dim3(sc2_grid), dim3(256), 0, s, b, p, w);       // the handed-on groups only
             compact_gen();
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (before k_consensus_fast appends the sides IT cannot take: those are not deep)
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);

@@ -64,6 +64,8 @@ struct StreamInfo {
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned long long prof[32];         // -DVB_PROF builds only: accumulated phase times of k_vote (tools/vote_prof.sh)
     unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
+    unsigned int n_score;                // pair slots of the groups k_vote handed on: k_score2's list (round 5: a list appended to by the group's lane; a flag per slot before,
+                                         // cleared and scanned over all N slots every step)
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
     unsigned int pair_next, pair_next2;  // ... and of k_pairing_deep (LDS / device-memory instantiation)

@@ -61,7 +61,7 @@ struct Work {
     void *deep_list;                       // DeepRec[] (gce_deep.hpp)
     uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
                                           // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
-    uint8_t *slot_flag;                   // pair slots of the groups whose sides were handed on (k_score2 scores only those)
+    uint32_t *score_list;                 // pair slots of the groups whose sides were handed on (k_score2 scores only those; count: si->n_score)
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     int32_t *rp_nm;                       // [2 x groups] NM byte patched into the side's template (group.cpp:570), -1 = untouched
     uint32_t *rp_qsl, *rp_qsr;            // per group: copyQName source of the left / right result record
@@ -585,12 +585,15 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 // LDS map, the pair's fields through ds_bpermute.  A unit costs one 8-byte load per array and side and one 8-byte score store
 // per side; only complete units are stored as words (the bytes behind the last overlap base belong to other patches).
 #define SC2_MAXU 1280        // >= 64 pairs x ceil(150 / 8); longer overlaps take more rounds of the unit map
-__global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w, uint32_t n_slots, int use_flags) {
+__global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w) {
     __shared__ uint8_t s_map[WAVES_PER_BLOCK][SC2_MAXU];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t slot = (blockIdx.x * WAVES_PER_BLOCK + wv) * 64 + lane;
+    const uint32_t n_list = w.si->n_score;
+    // a wave takes 64 entries of the list at a time (round 5: a wave per 64 SLOTS of the stream, 78 k blocks looking at flags that are nearly all zero, was 40 of the kernel's 57 us at cfg3)
+    for (uint32_t base = (blockIdx.x * WAVES_PER_BLOCK + wv) * 64u; base < n_list; base += gridDim.x * WAVES_PER_BLOCK * 64u) {
+    const uint32_t li = base + (uint32_t)lane;
     uint32_t L = NONE32, R = NONE32;
-    if (slot < n_slots && !(use_flags && !w.slot_flag[slot])) { L = w.gpl[slot]; if (L != NONE32) R = w.gpr[slot]; }
+    if (li < n_list) { const uint32_t slot = w.score_list[li]; L = w.gpl[slot]; if (L != NONE32) R = w.gpr[slot]; }
     int lstart = 0, rstart = 0, cmp = 0;
     uint64_t lso = 0, rso = 0, lqo = 0, rqo = 0;
     if (L != NONE32) {
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w,
             }
         }
         WAVE_SYNC();
+    }
     }
 }
 

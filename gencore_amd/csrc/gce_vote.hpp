@@ -27,7 +27,7 @@
 // columns, or — after a restore — rewritten here).  Scores are never materialised: no k_score2 launch, no score array traffic.
 //
 // A group with a side outside that scope (related odd reads, several classes of right reads on different positions, > 32 pairs, IUPAC codes, quals >= 128,
-// unusual score constants ...) is handed on UNTOUCHED, both sides: gen_flag (-> k_consensus_fast / k_consensus_slow) and slot_flag
+// unusual score constants ...) is handed on UNTOUCHED, both sides: gen_flag (-> k_consensus_fast / k_consensus_slow) and score_list
 // (-> k_score2 scores just those pairs).
 #pragma once
 
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
             const uint32_t gb = gb_;
-            for (uint32_t k = 0; k < np; k++) w.slot_flag[gb + k] = 1;
+            { const uint32_t at = atomicAdd(&w.si->n_score, np); for (uint32_t k = 0; k < np; k++) w.score_list[at + k] = gb + k; }
             // the DEEP sides (consensus_fast_side's test) go on slow_list here and now: k_deep_prepare starts right behind this kernel, beside k_score2
             // (a pass of k_consensus_fast over gen_list just to find them was 0.38 ms of cfg5's critical path)
             if ((np > 64u || (int)np > p.skip_low_complexity_thr) && !(np == 1u && w.gpr[gb] == NONE32)) {
@@ -402,8 +402,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             if (side == 0) {
                 const uint32_t gi = s_ggi[j];
                 w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
-                for (int k = 0; k < (int)s_gnp[j]; k++) w.slot_flag[s_gbeg[j] + k] = 1;
-                s_gflag[j] = 2;
+                s_gflag[j] = 2;                                                        // (P6 puts the group's pair slots on k_score2's list: once, with the groups found out of scope later)
             }
         }
         // pass-A items: 16-column chunks of the active sides, prefix over the sides
@@ -713,7 +712,8 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (s_gflag[j] == 2) {                                                          // found out of scope on the way: the whole group goes on, untouched
             if (side == 0) {
                 w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
-                for (int k = 0; k < (int)s_gnp[j]; k++) w.slot_flag[s_gbeg[j] + k] = 1;
+                const uint32_t np_ = s_gnp[j], at = atomicAdd(&w.si->n_score, np_);
+                for (uint32_t k = 0; k < np_; k++) w.score_list[at + k] = s_gbeg[j] + k;
             }
         } else if (s_gflag[j] == 0) {
             uint32_t *rp_out = side ? w.rp_right : w.rp_left;
