@@ -980,12 +980,6 @@ static int gce_process_impl(gce_engine *e) {
         const bool deep_stream = ((double)N > 48.0 * (double)NG || getenv("GCE_FORCE_AUX_STREAM")) && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
         const unsigned cf_grid = cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u;
         const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), 16384u);      // k_score2: waves stride over the list of handed-on pair slots (<= N / 2)
-        auto compact_gen = [&]() {   // the flagged sides -> gen_list
-            const uint64_t n2 = 2ull * NG; const unsigned nb2 = cdiv(n2, SCAN_TILE);
-            hipLaunchKernelGGL(k_flag_reduce, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, w.scan_part);
-            hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, w.scan_part, (uint64_t)nb2, &w.si->n_gen_items, (unsigned long long *)nullptr);
-            hipLaunchKernelGGL(k_flag_apply, dim3(nb2), dim3(256), 0, s, (const uint8_t *)w.gen_flag, n2, (const uint64_t *)w.scan_part, w.gen_list);
-        };
         if (deep_stream) {
             if ((rc = aux_ready(e)) != GCE_OK) return rc;
             HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand, the deep sides are on slow_list
@@ -993,12 +987,10 @@ static int gce_process_impl(gce_engine *e) {
             hipLaunchKernelGGL(k_score2, dim3(sc2_grid), dim3(256), 0, e->aux_stream, b, p, w);
             HIPCHK(hipEventRecord(e->aux_ev[1], e->aux_stream));
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (template + voter list of the deep sides: reads no score, no quality)
-            compact_gen();
             HIPCHK(hipStreamWaitEvent(s, e->aux_ev[1], 0));                                // the scores (and the rewritten qualities) stand
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);           // everything else on gen_list
         } else {
             hipLaunchKernelGGL(k_score2, dim3(sc2_grid), dim3(256), 0, s, b, p, w);       // the handed-on groups only
-            compact_gen();
             hipLaunchKernelGGL(k_deep_prepare, dim3(1024), dim3(256), 0, s, b, p, w);      // (before k_consensus_fast appends the sides IT cannot take: those are not deep)
             hipLaunchKernelGGL(k_consensus_fast, dim3(cf_grid), dim3(256), 0, s, b, p, w);
         }
@@ -1093,7 +1085,7 @@ static int gce_process_impl(gce_engine *e) {
             fprintf(stderr, "\n pre:"); for (int k = 0; k < 30; k++) fprintf(stderr, " %lld", e->h_si.pre[k]);
             fprintf(stderr, "\n other nonzero post words:"); for (int k = 30; k < GCE_STATS_WORDS; k++) if (e->h_si.post[k]) fprintf(stderr, " [%d]=%lld", k, e->h_si.post[k]);
             fprintf(stderr, "\n post_slot col 0..7 sums:"); for (int k = 0; k < 8; k++) { long long a = 0; for (int q = 0; q < GCE_PRE_SLOTS; q++) a += e->h_si.post_slot[q][k]; fprintf(stderr, " %lld", a); }
-            fprintf(stderr, "\n scalars: n_clustered %llu n_slow %u n_deep %u n_slow_pair %u n_gen %llu n_pf %llu n_pq %llu vote_weight %llu\n", e->h_si.n_clustered, e->h_si.n_slow, e->h_si.n_deep, e->h_si.n_slow_pair, e->h_si.n_gen_items, e->h_si.n_pf_items, e->h_si.n_pq_items, e->h_si.vote_weight);
+            fprintf(stderr, "\n scalars: n_clustered %llu n_slow %u n_deep %u n_slow_pair %u n_gen %llu n_pf %llu n_pq %llu vote_weight %llu\n", e->h_si.n_clustered, e->h_si.n_slow, e->h_si.n_deep, e->h_si.n_slow_pair, (unsigned long long)(e->h_si.hand_on >> 32), e->h_si.n_pf_items, e->h_si.n_pq_items, e->h_si.vote_weight);
         }
     }
 #endif

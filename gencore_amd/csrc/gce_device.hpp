@@ -64,8 +64,8 @@ struct StreamInfo {
     unsigned int n_slow;                 // group sides deferred to the generic consensus kernel
     unsigned long long prof[32];         // -DVB_PROF builds only: accumulated phase times of k_vote (tools/vote_prof.sh)
     unsigned int n_deep;                 // of those: deep sides prepared for k_vote_deep
-    unsigned int n_score;                // pair slots of the groups k_vote handed on: k_score2's list (round 5: a list appended to by the group's lane; a flag per slot before,
-                                         // cleared and scanned over all N slots every step)
+    unsigned long long hand_on;          // what k_vote hands on, ONE 64-bit counter bumped once per handed-on group: low half = pair slots on k_score2's list (score_list), high half = sides on
+                                         // gen_list (round 5: lists appended to by the group's lane; a flag per slot / per side before, cleared, scanned and compacted every step)
     unsigned int n_slow_pair;            // clusters deferred to the generic pairing kernel
     unsigned int n_slow_pair2;           // of those: left to the generic kernels by k_pairing_deep (pq_list)
     unsigned int pair_next, pair_next2;  // ... and of k_pairing_deep (LDS / device-memory instantiation)
@@ -76,7 +76,6 @@ struct StreamInfo {
     unsigned long long vote_weight;      // sum of the group weights: k_vote runs vote_weight / VB_W + 1 batches
     unsigned long long n_leaders;        // (cluster, scan block) runs of the clustering scan
     unsigned long long out_units;        // size of the compact output blobs in 16-byte units: bases << 32 | qualities
-    unsigned long long n_gen_items;      // group sides the lean consensus kernels handed to the full one
     unsigned long long n_pf_items;       // clusters the half-wave pairing kernel handed to the full-wave one
     unsigned long long n_pq_items;       // clusters the quarter-wave pairing kernel handed to the half-wave one
     unsigned long long n_p16_items;      // clusters of <= 16 reads: the quarter-wave pairing kernel's list

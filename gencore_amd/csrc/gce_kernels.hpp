@@ -59,9 +59,9 @@ struct Work {
                                          // it is appended to while the half-wave kernel still reads pq_list (the pairing tiers run side by side on two streams)
     uint8_t *p16_flag; uint32_t *p16_list;    // clusters of <= 16 reads, compacted: the quarter-wave kernel runs on full waves (k_pair_classes)
     void *deep_list;                       // DeepRec[] (gce_deep.hpp)
-    uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries the lean consensus kernels hand to the full one: flagged, then
-                                          // compacted into gen_list (appending through one shared counter costs ~12 ns per entry)
-    uint32_t *score_list;                 // pair slots of the groups whose sides were handed on (k_score2 scores only those; count: si->n_score)
+    uint8_t *gen_flag; uint32_t *gen_list;   // (group*2 + side) entries k_vote hands to the per-side kernels: appended to gen_list by the group's lane (one 64-bit atomic per group
+                                          // for this list and k_score2's: si->hand_on); gen_flag: 1 = handed on, 2 = finished by k_vote_deep
+    uint32_t *score_list;                 // pair slots of the groups whose sides were handed on (k_score2 scores only those; count: low half of si->hand_on)
     uint32_t *rp_left, *rp_right, *rp_merge, *rp_rmerge; const char **rp_umi; uint16_t *rp_umilen; uint8_t *rp_state; int32_t *rp_supp;
     int32_t *rp_nm;                       // [2 x groups] NM byte patched into the side's template (group.cpp:570), -1 = untouched
     uint32_t *rp_qsl, *rp_qsr;            // per group: copyQName source of the left / right result record
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_u32_apply(const uint32_t *in, uint32_t 
 __global__ __launch_bounds__(256) void k_score2(DevBatch b, DevParams p, Work w) {
     __shared__ uint8_t s_map[WAVES_PER_BLOCK][SC2_MAXU];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t n_list = w.si->n_score;
+    const uint32_t n_list = (uint32_t)w.si->hand_on;
     // a wave takes 64 entries of the list at a time (round 5: a wave per 64 SLOTS of the stream, 78 k blocks looking at flags that are nearly all zero, was 40 of the kernel's 57 us at cfg3)
     for (uint32_t base = (blockIdx.x * WAVES_PER_BLOCK + wv) * 64u; base < n_list; base += gridDim.x * WAVES_PER_BLOCK * 64u) {
     const uint32_t li = base + (uint32_t)lane;
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(256, 5) void k_consensus_fast(DevBatch b, DevParams
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     // the count only exists on the device: a capped grid strides over the list (a wave takes one or two entries when the list is
     // long, and leaves at once when it is short -- launching one block per POSSIBLE entry cost more than the work itself)
-    const uint32_t n = (uint32_t)w.si->n_gen_items;
+    const uint32_t n = (uint32_t)(w.si->hand_on >> 32);
     for (uint32_t idx = blockIdx.x * WAVES_PER_BLOCK + wv; idx < n; idx += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t e = w.gen_list[idx];
         consensus_fast_side(b, p, w, e >> 1, !(e & 1), s_res[wv], lane);

@@ -246,7 +246,12 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (deep) {                                                                    // both sides to the per-side kernels; k_score2 scores the group's pairs
             w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
             const uint32_t gb = gb_;
-            { const uint32_t at = atomicAdd(&w.si->n_score, np); for (uint32_t k = 0; k < np; k++) w.score_list[at + k] = gb + k; }
+            {   // one atomic per group: its pair slots go on k_score2's list, its two sides on gen_list
+                const unsigned long long o_ = atomicAdd(&w.si->hand_on, (2ull << 32) | (unsigned long long)np);
+                const uint32_t at = (uint32_t)o_, ga = (uint32_t)(o_ >> 32);
+                w.gen_list[ga] = 2u * gi; w.gen_list[ga + 1] = 2u * gi + 1u;
+                for (uint32_t k = 0; k < np; k++) w.score_list[at + k] = gb + k;
+            }
             // the DEEP sides (consensus_fast_side's test) go on slow_list here and now: k_deep_prepare starts right behind this kernel, beside k_score2
             // (a pass of k_consensus_fast over gen_list just to find them was 0.38 ms of cfg5's critical path)
             if ((np > 64u || (int)np > p.skip_low_complexity_thr) && !(np == 1u && w.gpr[gb] == NONE32)) {
@@ -712,7 +717,10 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         if (s_gflag[j] == 2) {                                                          // found out of scope on the way: the whole group goes on, untouched
             if (side == 0) {
                 w.gen_flag[2 * gi] = 1; w.gen_flag[2 * gi + 1] = 1;
-                const uint32_t np_ = s_gnp[j], at = atomicAdd(&w.si->n_score, np_);
+                const uint32_t np_ = s_gnp[j];
+                const unsigned long long o_ = atomicAdd(&w.si->hand_on, (2ull << 32) | (unsigned long long)np_);
+                const uint32_t at = (uint32_t)o_, ga = (uint32_t)(o_ >> 32);
+                w.gen_list[ga] = 2u * gi; w.gen_list[ga + 1] = 2u * gi + 1u;
                 for (uint32_t k = 0; k < np_; k++) w.score_list[at + k] = s_gbeg[j] + k;
             }
         } else if (s_gflag[j] == 0) {
