@@ -978,8 +978,11 @@ static int gce_process_impl(gce_engine *e) {
         // handed-on groups (k_score2: bandwidth) on a second HIP stream BESIDE the compaction, the hand-on of the deep sides and their template /
         // voter preparation (k_deep_prepare: a wave per side, latency) -- none of those reads a score or a quality; the votes wait for both.
         const bool deep_stream = ((double)N > 48.0 * (double)NG || getenv("GCE_FORCE_AUX_STREAM")) && !getenv("GCE_NO_AUX_STREAM");          // (reads per group / 2 = mean pairs per group)
-        const unsigned cf_grid = cdiv(2ull * NG, WAVES_PER_BLOCK) < 32768u ? cdiv(2ull * NG, WAVES_PER_BLOCK) : 32768u;
-        const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), 16384u);      // k_score2: waves stride over the list of handed-on pair slots (<= N / 2)
+        // both kernels stride over lists whose length only the device knows: on a stream of ordinary depth k_vote hands on a few percent of the groups, and a grid sized for
+        // "everything" spends its time starting empty blocks (k_consensus_fast: 32 k blocks for ~10 k sides were 20 of its 26 us at cfg3)
+        const unsigned cf_cap = deep_stream ? 32768u : 4096u, sc2_cap = deep_stream ? 16384u : 2048u;
+        const unsigned cf_grid = std::min<unsigned>(cdiv(2ull * NG, WAVES_PER_BLOCK), cf_cap);
+        const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), sc2_cap);      // k_score2: waves stride over the list of handed-on pair slots (<= N / 2)
         if (deep_stream) {
             if ((rc = aux_ready(e)) != GCE_OK) return rc;
             HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand, the deep sides are on slow_list
