@@ -963,7 +963,11 @@ static int gce_process_impl(gce_engine *e) {
         fill_many(s, {FillSeg{e->gen_flag.p, g1 * 2, 0u, 0u},
                       FillSeg{e->rp_nm.p, g1 * 8, 0xFFu, 0u},                                  // -1: NM untouched
                       FillSeg{e->rp_left.p, g1 * 4, 0xFFu, 0u}, FillSeg{e->rp_right.p, g1 * 4, 0xFFu, 0u}});   // NONE: a group no kernel voted on emits nothing (instead of stale read indices)
+#ifdef VB_XCD
+        const unsigned nbatch = (((unsigned)(e->h_si.vote_weight / VB_W) + 1u) + 7u) & ~7u;      // (vb_start is 0xFF-filled up to vb_cap: the extra blocks find no batch)
+#else
         const unsigned nbatch = (unsigned)(e->h_si.vote_weight / VB_W) + 1u;
+#endif
 #ifdef VB_STOP
         {   // experiment builds (tools/vote_stop.sh): time the truncated k_vote alone and stop -- it leaves garbage behind
             hipEvent_t a_, b_; (void)hipEventCreate(&a_); (void)hipEventCreate(&b_);

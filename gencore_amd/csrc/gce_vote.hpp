@@ -220,8 +220,13 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     static_assert(sizeof(s_tal) >= (3 * VB_MAXP + 6 * VB_SIDES) * 4 + VB_MAXP + 2 * VB_MAXP * sizeof(VTail), "P1 scratch and the reads' second halves must fit the tally space");
     // work index of a thread: rotated by the batch number, so that the single-wave phases (P0, P2, P5a, P6) and the half-empty ones
     // do not all land on the same SIMD of the CU (wave k of every workgroup runs on SIMD k)
+#ifdef VB_XCD              // experiment: workgroup i runs on XCD i mod 8 -- give every XCD a CONTIGUOUS eighth of the batches, so that neighbouring batches (whose reads share sectors) share an L2
+    const uint32_t per_x_ = gridDim.x >> 3, bid_ = (blockIdx.x & 7u) * per_x_ + (blockIdx.x >> 3);      // (the grid is a multiple of 8)
+#else
+    const uint32_t bid_ = blockIdx.x;
+#endif
     const int tid = (int)((threadIdx.x + ((blockIdx.x & (VB_T / 64 - 1)) << 6)) & (VB_T - 1)), lane = tid & 63;
-    const uint32_t g0 = w.vb_start[blockIdx.x];
+    const uint32_t g0 = w.vb_start[bid_];
     if (g0 == NONE32) return;
 #if defined(VB_PROF) && !defined(DV_PROF)
     unsigned long long t_prev_ = wall_clock64();
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         const uint32_t gi = g0 + (uint32_t)lane;
         const bool maybe = lane < VB_MAXG && gi < n_groups;                            // (the three loads side by side: whether the group belongs to the batch only decides who uses them)
         const uint32_t wb_ = maybe ? w.g_wbase[gi] : 0u, np_ = maybe ? w.g_np[gi] : 0u, gb_ = maybe ? w.g_begin[gi] : 0u;
-        bool in = maybe && wb_ < (blockIdx.x + 1u) * VB_W;
+        bool in = maybe && wb_ < (bid_ + 1u) * VB_W;
         uint32_t np = in ? np_ : 0u;
         const bool deep = in && (np > 32u || (int)np > p.skip_low_complexity_thr || !p.vote_ok);
         const unsigned long long im = __ballot(in);
