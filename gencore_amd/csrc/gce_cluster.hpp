@@ -300,9 +300,7 @@ __global__ __launch_bounds__(EV_T) void k_events(DevBatch b, DevParams p, Work w
 #pragma unroll
         for (int q = 0; q < SB_READS / 64; q++) {
             const int64_t idx = i0 + 64 * q + lane;
-            union { gce_core c; uint4 v[2]; } t2; t2.v[0] = make_uint4(0, 0, 0, 0); t2.v[1] = t2.v[0];
-            if (idx < end) { const uint4 *src = reinterpret_cast<const uint4 *>(b.core + idx); t2.v[0] = src[0]; t2.v[1] = src[1]; }
-            clq[q] = idx < end && d_classify(t2.c) == CLS_CLUSTERED;
+            clq[q] = idx < end && w.slot[idx] != NONE32;                    // k_cluster left NONE32 for every read that is not clustered: 4 bytes per read instead of its 32-byte key record
         }
 #pragma unroll
         for (int q = 0; q < SB_READS / 64; q++) {
