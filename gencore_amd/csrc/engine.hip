@@ -946,7 +946,7 @@ static int gce_process_impl(gce_engine *e) {
         NG = (uint32_t)e->h_si.n_groups;
     } else HIPCHK(hipEventRecord(e->ev[EV_PAIRING], s));
     const size_t g1 = NG ? NG : 1;
-    ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(score_list, n1 * 2 + 64);      /* (<= N / 2 pairs) */ ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
+    ENS(gen_list, g1 * 8); ENS(gen_flag, g1 * 2 + 64); ENS(score_list, n1 * 4 + 64);      /* one entry per pair SLOT: a pair may hold one read only (mate absent / far / on another contig), so slots <= N, not N / 2 */ ENS(rp_left, g1 * 4); ENS(rp_right, g1 * 4); ENS(rp_merge, g1 * 4); ENS(rp_rmerge, g1 * 4); ENS(rp_umi, g1 * 8);
     ENS(rp_umilen, g1 * 2); ENS(rp_state, g1); ENS(rp_supp, g1 * 4); ENS(rp_nm, g1 * 8); ENS(rp_qsl, g1 * 4); ENS(rp_qsr, g1 * 4);
     w.gen_list = e->gen_list.as<uint32_t>(); w.gen_flag = e->gen_flag.as<uint8_t>(); w.score_list = e->score_list.as<uint32_t>();
     w.rp_left = e->rp_left.as<uint32_t>(); w.rp_right = e->rp_right.as<uint32_t>();
@@ -986,7 +986,7 @@ static int gce_process_impl(gce_engine *e) {
         // "everything" spends its time starting empty blocks (k_consensus_fast: 32 k blocks for ~10 k sides were 20 of its 26 us at cfg3)
         const unsigned cf_cap = deep_stream ? 32768u : 4096u, sc2_cap = deep_stream ? 16384u : 2048u;
         const unsigned cf_grid = std::min<unsigned>(cdiv(2ull * NG, WAVES_PER_BLOCK), cf_cap);
-        const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), sc2_cap);      // k_score2: waves stride over the list of handed-on pair slots (<= N / 2)
+        const unsigned sc2_grid = std::min<unsigned>(cdiv(N, 2 * WAVES_PER_BLOCK * 64), sc2_cap);      // k_score2: waves stride over the list of handed-on pair slots (<= N)
         if (deep_stream) {
             if ((rc = aux_ready(e)) != GCE_OK) return rc;
             HIPCHK(hipEventRecord(e->aux_ev[0], s));                                       // k_vote is done: its slot flags stand, the deep sides are on slow_list

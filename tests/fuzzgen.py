@@ -95,7 +95,10 @@ def make_case(seed, n_mol=40, umi_mode=None, period=None, deep=None, exotic=Fals
             elif umi_mode == "colon":
                 name += ":" + ua + ("_" + ub if rng.random() < 0.5 else "")
             elif umi_mode == "duplex":
-                name += ":UMI_" + (ua + "_" + ub if strand == 0 else ub + "_" + ua)
+                du = ua + "_" + ub if strand == 0 else ub + "_" + ua
+                if rng.random() < 0.06:                     # odd shapes util.h's split sees differently (leading / doubled / trailing separator, one token, none): cluster.cpp:246-258
+                    du = rng.choice(["_" + du, ua + "__" + ub, du + "_", ua + "_", "_" + ua, "_", ua])
+                name += ":UMI_" + du
             mi_tag = ua if (umi_mode == "mi" and rng.random() < 0.85) else None      # MI:Z tag (bamutil.cpp:23-38); a pair without one falls back to its name
             qf = [rng.choice(QUALS) for _ in fseq]
             qr = [rng.choice(QUALS) for _ in rseq]

@@ -78,7 +78,7 @@ def test_oracle_matches_hand_derivation(oracle, name):
 
 
 def test_vectors_present():
-    assert len(CASES) >= 32
+    assert len(CASES) >= 34
 
 
 @pytest.mark.gpu
