@@ -72,6 +72,9 @@ write(dict(
     expected_status=0,
     expected=[out("x", 147, 500, "20M", R1[:3] + "N" + R1[4:], Q(37, 3) + [0] + Q(37, 16), 1, 1),
               out("x", 99, 480, "30M", R2[:23] + "N" + R2[24:], Q(30, 23) + [0, 30, 10] + Q(30, 4), 0, 1)],
+    # the order of the output set is not checked for this stream: it is NOT sorted (that is its point), the engine's output order (and the oracle's) is defined for streams
+    # whose mapped reads ascend, and the reference itself writes such a stream "unordered" (gencore.cpp:86-103: the watermark drain of :113-143 is out of scope)
+    skip_order_check="the stream is unsorted behind an unmapped read",
     expected_stats=dict(pre=stats(5, 110, 1, 0, 1, {1: 1}, unmapped=(2, 40), mism=(1, 1)),
                         post=stats(2, 50, 1, 0, 1, {1: 1}, sscs=1, mism=(1, 1)))))
 

@@ -103,6 +103,7 @@ def test_engine_matches_hand_derivation(built, name):
         eng.finish()
         rt = eng.output(batch)
         check(v, rt, batch)
-        assert not check_output_order(batch, rt.rows)
+        if not v.get("skip_order_check"):
+            assert not check_output_order(batch, rt.rows)
     finally:
         eng.close()
