@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -5 > gpurun_out/r06_c_quick_tests.txt
+bash tools/abn.sh "abx/head.so abx/lanecol.so abx/lanecol_noplan.so" 2>&1 | tee gpurun_out/r06_c_ab.txt
+cat gpurun_out/r06_c_quick_tests.txt
