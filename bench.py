@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--test-one-gpu", action="store_true", help="testing aid: every rank uses cuda:0 and torch.distributed runs over gloo, so the N > 1 code path (one stream cut into key ranges, ticks + flush events, Stats all-reduce) can be exercised on a 1-GPU box")
+    ap.add_argument("--nccl-world1", action="store_true", help="testing aid: with --gpus 1, run the N > 1 code path (key-range plan, global ticks + flush events, the Stats payload all-reduced) "
+                    "as a world of ONE rank over the nccl backend, so that the RCCL int64 all-reduce of the payload is loaded and executed on a 1-GPU box")
     ap.add_argument("--coverage-step", type=int, default=10000, help="Options::coverageStep of the depth statistics in the Stats merge (src/options.cpp:36)")
     ap.add_argument("--stats-merge", default="full", choices=["full", "counters"], help="what the ranks all-reduce after every step at N > 1: the whole Stats payload (counters + "
                     "histogram + per-contig depth bins + BED region counts, SURVEY 8e; gce_stats_payload_device) or the two counter blocks alone (rounds 1-4)")
@@ -142,9 +144,15 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.nccl_world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                      # --nccl-world1 without a launcher: a rendezvous of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.test_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -174,7 +182,7 @@ def main():
 
     # ------------------------------------------------------------------ workload (synthetic, generated on the GPU)
     stream_ctx = None
-    if world == 1:
+    if dist is None:
         data = synth.generate(workload, n_pairs=args.pairs, seed=0, device=dev, align=args.align, **over)
     else:
         per_gpu = args.pairs if args.pairs is not None else synth.CONFIGS[workload]["n_pairs"]
@@ -267,6 +275,24 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ms_per_step = elapsed * 1000.0 / args.steps
+    # what the N > 1 step does that the N = 1 step does not -- the Stats payload (k_depth over the rank's reads and records, two passes) and its all-reduce --
+    # timed ALONE behind the timed region (max over ranks), so that value(N) / value(1) can be read like for like: ms_per_step - merge_ms is the engine pass
+    merge_ms = None
+    if dist and args.stats_merge == "full":
+        def merge_only():
+            sp, words = stats_payload()
+            assert hip.hipMemcpyAsync(C.c_void_p(stats_dev.data_ptr()), sp, C.c_size_t(stats_dev.numel() * 8), 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            dist.all_reduce(stats_dev)
+        stats_keep = stats_dev.clone()
+        merge_only(); sync()
+        m0 = time.perf_counter()
+        for _ in range(args.steps):
+            merge_only()
+        sync()
+        mt = torch.tensor([time.perf_counter() - m0], dtype=torch.float64, device=dev)
+        dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        merge_ms = float(mt.item()) * 1000.0 / args.steps
+        stats_dev.copy_(stats_keep)                         # (the line reports the sums of the last timed step: ONE all-reduce of them)
     total_pairs = torch.tensor([n_pairs], dtype=torch.int64, device=dev)
     if dist:
         dist.all_reduce(total_pairs)
@@ -301,9 +327,14 @@ def main():
     tj = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % workload)       # one file per workload (tools/hbm_summary.py); cfg3's is also profiles/hbm_traffic.json
     if not os.path.exists(tj):
         tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from hbm_summary import csrc_sha16                    # sha256 over gencore_amd/csrc: a traffic file is quoted only for the sources it was measured on
+    src_hash, traffic_stale = csrc_sha16(), None
     if os.path.exists(tj) and args.pairs is None and world == 1:
         hj = json.load(open(tj))
-        if hj.get("workload") == workload:
+        if hj.get("workload") == workload and hj.get("csrc_sha16") != src_hash:
+            traffic_stale = "profiles/%s (%s) was measured on other sources (csrc_sha16 %s, tree %s): traffic dropped" % (os.path.basename(tj), hj.get("tag", "?"), hj.get("csrc_sha16"), src_hash)
+        elif hj.get("workload") == workload:
             kk = hj["kernels"]
             names = {"consensus": hj.get("consensus_kernels", []), "cluster": ["k_cluster"]}     # (consensus_kernels: k_vote + k_score2 + k_consensus_fast/_slow, and the deep kernels where they run)
             traffic = {k: sum(kk[n]["fetch_bytes_x2"] + kk[n]["write_bytes"] for n in v if n in kk) for k, v in names.items()}
@@ -312,7 +343,7 @@ def main():
                                          "cluster": "k_cluster (clustering scan)"}[dom],
                     achieved=round(kernels[dom]["achieved_gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(kernels[dom]["frac"], 5), traffic=(round(traffic[dom]) if traffic and traffic[dom] else None),
-                    traffic_source=("static: profiles/hbm_traffic*.json (%s), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not a measurement of this run" % hj.get("tag", "?")) if traffic else None,
+                    traffic_source=("static: profiles/hbm_traffic*.json (%s, csrc_sha16 %s = this tree), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not a measurement of this run" % (hj.get("tag", "?"), src_hash)) if traffic else traffic_stale,
                     algorithmic_bytes=round(kernels[dom]["algorithmic_bytes"]),
                     clustering_scan=dict(achieved=round(kernels["cluster"]["achieved_gbs"], 2), frac=round(kernels["cluster"]["frac"], 5),
                                          ms=round(kernels["cluster"]["ms"], 4), algorithmic_bytes=round(cluster_bytes),
@@ -322,10 +353,16 @@ def main():
                     cluster_formation=dict(what="everything that forms the clusters (SURVEY 8 A1-A3): k_cluster + tick scan + flush events + leader table + cluster/member lists, against the same 40 B/read; the bucket table is wiped by its users, no memset",
                                            ms=round(kernels["cluster_formation"]["ms"], 4), frac=round(kernels["cluster_formation"]["frac"], 5)),
                     phase_ms={k: round(v, 4) for k, v in phase_ms.items()}, mean_group_depth=round(d, 3), leader_runs=round(avg["n_leaders"]))
+    # LDS figures of the per-column vote (north_star: "LDS hit-rate for the per-column vote"): static like `traffic`, from the committed SQ / LDS counter passes
+    # (tools/lds_round.sh + lds_summary.py -> profiles/lds_<workload>.json), quoted only for the sources they were measured on
+    lj = os.path.join(ROOT, "profiles", "lds_%s.json" % workload)
+    if os.path.exists(lj) and args.pairs is None and world == 1:
+        ld = json.load(open(lj))
+        roofline["lds"] = ld["k_vote"] if ld.get("csrc_sha16") == src_hash else "profiles/%s was measured on other sources (csrc_sha16 %s, tree %s): dropped" % (os.path.basename(lj), ld.get("csrc_sha16"), src_hash)
 
     # ------------------------------------------------------------------ CPU baseline (oracle port) + parity of the timed entry points
     cpu, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and dist is None and not args.no_cpu_baseline:
         from oracle import oracle_py
         sample_pairs = min(args.cpu_sample_pairs, n_pairs)
         sd = synth.generate(workload, n_pairs=sample_pairs, seed=12345, device=dev, **over)
@@ -404,13 +441,19 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %d paired %d bp reads per GPU, %s, mean cluster depth %.1f pairs (UMI groups: %.1f), -s %d, %s, genome %.2f Gb%s" % (
                 workload, n_pairs, L, ("%d bp UMI" % data.info["umi_len"]) if data.info["umi_len"] else "no UMI", n_pairs / max(1, pre.get("clusters") or 1), d,
-                data.info["supporting_reads"], ("one stream cut into %d key ranges" % world) if world > 1 else "one stream",
+                data.info["supporting_reads"], ("one stream cut into %d key ranges" % world) if dist else "one stream",
                 data.info["genome_bases"] / 1e9, (", %d BED targets x 200 bp" % data.info["bed_targets"]) if data.info.get("bed_targets") else ""),
                 "pairs_per_gpu": n_pairs, "reads_per_gpu": n_reads, "records_out_per_gpu": last_res.get("n_out"),
                 "clusters": pre.get("clusters"), "multi_molecule_clusters": pre.get("multi_molecule_clusters"),
-                "parallelism": ("key-range shards x%d (cluster key (tid,left), global ticks + flush events), Stats all-reduce" % world) if world > 1 else "single GPU"},
+                "parallelism": ("key-range shards x%d (cluster key (tid,left), global ticks + flush events), Stats all-reduce" % world) if dist else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity,
         }
+        if dist:
+            out["step_includes"] = ("gce_process + the Stats merge (gce_stats_payload_device: k_depth over this rank's reads and records, then ONE %s all-reduce of the payload); "
+                                    "the N = 1 line times gce_process alone -- stats_merge_ms_per_step is the merge timed by itself behind the timed steps (max over ranks)"
+                                    % ("gloo" if args.test_one_gpu else "RCCL"))
+            out["stats_merge_ms_per_step"] = round(merge_ms, 4) if merge_ms is not None else None
+            out["backend"] = "gloo (--test-one-gpu)" if args.test_one_gpu else "nccl (RCCL)"
         # the whole stream's Stats: at N > 1 the blocks every rank holds after the all-reduce (sums over the key-range shards), at N = 1 the
         # engine's own -- the same stream cut into 1 or N ranges must give the same numbers (tests/test_bench_ranks.py)
         names = ("reads", "bases", "reads_unmapped", "bases_unmapped", "base_mismatches", "reads_with_mismatches", "clusters", "multi_molecule_clusters",
@@ -439,10 +482,18 @@ def main():
             out["stats_whole_stream"]["depth"] = depth_digest(host, payload_lay)
         if cpu:
             out["speedup_vs_cpu_port"] = round(value / cpu["value"], 2)
-        print(json.dumps(out))
+        line = json.dumps(out)
     lib.gce_destroy(eng)
     if dist:
         dist.destroy_process_group()
+    if dist:                                                # RCCL writes a version banner through C stdio, which a pipe buffers until exit: out with it now, so that
+        try:                                                # the JSON line is the LAST thing on stdout
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

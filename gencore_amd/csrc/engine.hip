@@ -1221,6 +1221,9 @@ int gce_stats_payload_device(gce_engine *e, int32_t step, int32_t n_regions, con
     const int fin = std::max(2 * GCE_STATS_WORDS, (int)n_regions);
     hipLaunchKernelGGL(k_payload_finish, dim3(cdiv(fin, 256)), dim3(256), 0, s, (const StreamInfo *)e->si.p, (const int32_t *)e->dp_where.p, n_regions, (const unsigned long long *)e->dp_bed.p, nreg, pay, nbins);
     HIPCHK(hipGetLastError());
+    // the payload is complete when the call returns: a caller that reads it on another stream -- RCCL on its own stream, a torch side stream -- needs no
+    // knowledge of this engine's stream.  One host wait per call (the kernels above take ~0.4 ms at cfg3); gce_stats_payload_sum / _read order themselves as before.
+    HIPCHK(hipStreamSynchronize(s));
     layout->stats_words = 2 * GCE_STATS_WORDS; layout->n_targets = nt; layout->n_bins = nbins; layout->n_regions = n_regions; layout->total_words = words; layout->bin_off = e->h_binoff.data();
     e->payload_words = words;
     *payload = (const int64_t *)pay;

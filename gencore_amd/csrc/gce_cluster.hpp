@@ -1,6 +1,6 @@
 // gce_cluster.hpp — cluster formation: Gencore::addToProperCluster, src/gencore.cpp:295-434.
 //
-//   k_cluster      THE CLUSTERING SCAN.  One pass over the 32-byte key records, 512 reads per block: class, cluster key
+//   k_cluster      THE CLUSTERING SCAN.  One pass over the 32-byte key records, SB_READS (1024) reads per block: class, cluster key
 //                  (gencore.cpp:295-312), the sortedness check (gencore.cpp:233-241), and block-level aggregation in LDS -- the first
 //                  read of every distinct key of the block is its LEADER, the others draw a block-local rank from the leader's counter.
 //                  Output per read: (leader record, rank in the leader's run) = 8 bytes.  The kernel touches NO stream-global state:
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(SB_T, 2048 / SB_T) void k_cluster(DevBatch b, DevPa
         for (int q = 0; q < SB_T / 64; q++) { const uint32_t c = s_wcnt[u][q]; inblock += q < wv ? c : 0u; front += c; }
         if (idx[u] < b.n) {
             if (cl[u]) {
-                w.slot[idx[u]] = (uint32_t)s_num[leader[u]] | lrank[u] << 16;                 // (leader of the block, rank in its run): 9 + 9 bits, the block is idx / 512
+                w.slot[idx[u]] = (uint32_t)s_num[leader[u]] | lrank[u] << 16;                 // (leader of the block, rank in its run): SB_OFF_BITS + SB_OFF_BITS bits (10 + 10 at SB_READS = 1024), the block is idx / SB_READS
                 if (leader[u] == id) {
                     union { LeadRec r; uint4 q; } o;
                     o.r.kw = kw[u]; o.r.info = (uint32_t)id | inblock << SB_OFF_BITS | (odd[u] ? LI_ODD : 0u); o.r.runlen = s_cnt[id];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_blk_scan(Work w, DevParams p) {
 }
 
 // one WAVE per flush event: find the read on which tick % period == 0 (gencore.cpp:319-322) -- the scan block by a 64-ary search over the
-// block bases, the read inside it by ballots over the classes of the block's 512 key records
+// block bases, the read inside it by ballots over the classes of the block's SB_READS key records
 #define EV_T 1024                                                     // 16 events per block: one global atomic per block for the segment count
 __global__ __launch_bounds__(EV_T) void k_events(DevBatch b, DevParams p, Work w) {
     __shared__ int s_a;

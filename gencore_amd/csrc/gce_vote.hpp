@@ -525,6 +525,10 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     //      pass A a few microseconds ago and come from the L2 -- in front of P2, behind the descriptors, they were a third dependent trip to HBM in P1 and
     //      ~1 GB of sectors fetched twice (0.2 ms of the kernel in a build without the compare).  Pass A does not need the forced columns: a bit of s_cmask is
     //      counted by whoever sets it first (atomicOr returns the word as it was).
+    //       This phase shares pass A's barrier interval: s_gflag[j] is read here while pass-A lanes of other waves may be setting a group's flag to 2, and both
+    //      bump s_cnt behind first-setter atomicOrs on s_cmask.  The race is benign BY CONSTRUCTION and must stay so: a flag only ever goes 0 -> 2, a group flagged 2 is
+    //      handed on untouched (P5a / P6 / P7 look at the flag again behind the barrier), so a stale 0 here only adds forced columns and counts to a side nobody votes on.
+    //      Nothing behind this phase may use s_cnt or s_cmask of a flagged group.
     if (tid < npairs) {
         const VOv ov = s_ov[tid];
         const int j = s_pg[tid];

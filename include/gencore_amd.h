@@ -293,7 +293,8 @@ int gce_depth_stats(gce_engine *e, int32_t coverage_step, int32_t n_regions, con
  * Every word is additive over key-range shards of one stream: N ranks merge it with one all-reduce(sum) over RCCL (bench.py), N engines of one process with one
  * add per engine (gce_run_bam_depth).  Depth bins as in gce_depth (1 + target_len / coverage_step per contig, contigs back to back; bin_off: host array of
  * n_targets + 1 entries owned by the engine); BED counts in the order the regions were given (a region whose contig is not in the header counts 0).
- * Valid until the next gce_process / gce_depth_stats / gce_stats_payload_device of this engine.  (Addition under ABI v3, round 5.) */
+ * Valid until the next gce_process / gce_depth_stats / gce_stats_payload_device of this engine.  (Addition under ABI v3, round 5.)
+ * The payload is COMPLETE when the call returns (the engine's stream is waited for): it may be read from any stream, e.g. by an RCCL all-reduce. */
 typedef struct gce_payload_layout {
     int32_t stats_words;          /* 2 * GCE_STATS_WORDS */
     int32_t n_targets;

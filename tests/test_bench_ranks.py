@@ -47,3 +47,17 @@ def test_driver_form_under_the_launcher(built):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
                         "bench.py", "--gpus", "4"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode != 0 and "--gpus 4 but the launcher started 2 ranks" in (p.stdout + p.stderr)
+
+
+def test_world_of_one_over_rccl_equals_one_engine(built):
+    """the N > 1 code path as a world of ONE rank over the nccl backend (= RCCL on ROCm): the key-range plan, global ticks + flush events and -- what no
+    gloo test reaches -- the RCCL int64 all-reduce of the Stats payload straight from device memory, loaded and executed on this one GPU"""
+    common = ["--workload", "cfg4s", "--scale", "0.02", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--pairs", "200000"]
+    one = run([sys.executable, "bench.py"] + common)
+    w1 = run([sys.executable, "bench.py", "--nccl-world1"] + common)
+    assert w1["n_gpus"] == 1 and w1["backend"].startswith("nccl") and w1["stats_merge_ms_per_step"] > 0
+    a, b = one["stats_whole_stream"], w1["stats_whole_stream"]
+    for blk in ("pre", "post"):
+        assert a[blk] == b[blk], (blk, a[blk], b[blk])
+    assert a["depth"] == b["depth"] and a["pre_hist_sum"] == b["pre_hist_sum"] and a["post_hist_sum"] == b["post_hist_sum"]
+    assert "all-reduce" in w1["step_includes"]

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -5 > gpurun_out/r06_c_quick_tests.txt
-bash tools/abn.sh "abx/head.so abx/lanecol.so abx/lanecol_noplan.so" 2>&1 | tee gpurun_out/r06_c_ab.txt
-cat gpurun_out/r06_c_quick_tests.txt
+timeout 300 python bench.py --nccl-world1 --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r06_d_bench_nccl_world1.json; python -c "
+import json; d=json.load(open('gpurun_out/r06_d_bench_nccl_world1.json')); print(d['ms_per_step'], d.get('stats_merge_ms_per_step'), d.get('backend'), d['roofline'].get('traffic_source'))"

@@ -7,8 +7,19 @@ wide coalesced reads (the x2 column); WRITE_SIZE and narrow access widths are un
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def csrc_sha16(root=None):
+    """sha256 over the engine sources (gencore_amd/csrc/*.hip|hpp|cpp, sorted by name): bench.py quotes a traffic file only when its hash is the tree's."""
+    root = root or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gencore_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(f for f in os.listdir(root) if f.endswith((".hip", ".hpp", ".cpp"))):
+        h.update(fn.encode()); h.update(open(os.path.join(root, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(d):
@@ -40,7 +51,7 @@ def main():
     cons = [k for k in rows if k in ("k_vote", "k_score2", "k_consensus_fast", "k_consensus_slow", "k_deep_prepare", "k_vote_deep")]
     # (tools/mb/fetch_calib.hip, profiles/r03_fetch_calibration.json: the x2 of FETCH_SIZE holds for streaming reads of every lane width incl. the vote's
     #  unaligned 8-byte loads; WRITE_SIZE is exact; the counter unit is 1024 bytes)
-    doc = {"note": note, "tag": dst.rsplit("/", 1)[-1], "workload": workload, "consensus_kernels": cons, "kernels": js}
+    doc = {"note": note, "tag": dst.rsplit("/", 1)[-1], "workload": workload, "csrc_sha16": csrc_sha16(), "consensus_kernels": cons, "kernels": js}
     json.dump(doc, open(dst.rsplit("/", 1)[0] + "/hbm_traffic_%s.json" % workload, "w"), indent=1)
     if workload == "cfg3":
         json.dump(doc, open(dst.rsplit("/", 1)[0] + "/hbm_traffic.json", "w"), indent=1)

@@ -41,6 +41,23 @@ def main():
                 100 * z.get("SQ_WAIT_INST_LDS", 0) / wc3, idx, y.get("SQ_LDS_BANK_CONFLICT", 0), y.get("SQ_LDS_ADDR_CONFLICT", 0),
                 100 * y.get("SQ_LDS_BANK_CONFLICT", 0) / idx if idx else 0.0, 100 * y.get("SQ_LDS_ADDR_CONFLICT", 0) / idx if idx else 0.0,
                 z.get("SQ_LDS_ATOMIC_RETURN", 0), z.get("SQ_LDS_UNALIGNED_STALL", 0)))
+    # the per-column vote's figures for bench.py's roofline.lds (static, stamped with the sources' hash)
+    import json, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hbm_summary import csrc_sha16
+    k = "k_vote" if "k_vote" in a else None
+    if k:
+        x, y, z = a[k], b[k], c[k]
+        idx = z.get("SQ_LDS_IDX_ACTIVE", 0) or 1.0
+        wc, wc3 = x.get("SQ_WAVE_CYCLES", 0) or 1.0, z.get("SQ_WAVE_CYCLES", 0) or 1.0
+        doc = {"tag": dst.rsplit("/", 1)[-1], "workload": wl, "note": note, "csrc_sha16": csrc_sha16(),
+               "k_vote": {"what": "k_vote, rocprofv3 --pmc SQ_* (three separate passes, static: not a measurement of this run)", "source": os.path.basename(out),
+                          "lds_bank_conflict_pct": round(100 * y.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 1), "lds_addr_conflict_pct": round(100 * y.get("SQ_LDS_ADDR_CONFLICT", 0) / idx, 1),
+                          "lds_conflict_free_pct": round(100 - 100 * y.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 1),
+                          "lds_active_pct_of_wave_cycles": round(100 * y.get("SQ_ACTIVE_INST_LDS", 0) / wc, 2), "wait_inst_lds_pct_of_wave_cycles": round(100 * z.get("SQ_WAIT_INST_LDS", 0) / wc3, 2),
+                          "valu_active_pct_of_wave_cycles": round(100 * y.get("SQ_ACTIVE_INST_VALU", 0) / wc, 2), "lds_insts_per_wave": round(x.get("SQ_INSTS_LDS", 0) / (x.get("SQ_WAVES", 0) or 1), 1),
+                          "valu_insts_per_wave": round(x.get("SQ_INSTS_VALU", 0) / (x.get("SQ_WAVES", 0) or 1), 1)}}
+        json.dump(doc, open(os.path.join(os.path.dirname(out), "lds_%s.json" % wl), "w"), indent=1)
     print(open(out).read())
 
 
