@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--stats-merge", default="full", choices=["full", "counters"], help="what the ranks all-reduce after every step at N > 1: the whole Stats payload (counters + "
                     "histogram + per-contig depth bins + BED region counts, SURVEY 8e; gce_stats_payload_device) or the two counter blocks alone (rounds 1-4)")
     ap.add_argument("--align", type=int, default=1, help="byte alignment of each read's seq/qual slice in the SoA blobs")
+    ap.add_argument("--layout", default="soa", choices=["soa", "record", "record64"], help="where a read's packed bases and qualities lie in HBM (gce_batch offsets are free-form): soa = two blobs "
+                    "(bases of all reads, qualities of all reads); record = ONE blob, a read's qualities right behind its bases as in a BAM record (bam1_t: seq, then qual) -- 225 contiguous "
+                    "bytes at 150 bp touch 4.5 sectors of 64 bytes where the two slices touch 5.5; record64 = the same with every record on a 64-byte boundary (256-byte stride at 150 bp: 4 sectors)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -206,8 +209,24 @@ def main():
         assert lib.gce_set_flush_events(eng, len(et), et.ctypes.data, ep.ctypes.data) == 0
 
     n_copies = args.steps + args.warmup
-    seqs = [padded_clone(t["seq"]) for _ in range(n_copies)]
-    quals = [padded_clone(t["qual"]) for _ in range(n_copies)]
+    if args.layout != "soa":
+        # one blob of records: [packed bases][qualities] per read; both base pointers of the batch are the blob's, the offsets tell the two apart
+        SBl, Ll = (data.info["read_len"] + 1) // 2, data.info["read_len"]
+        stride = SBl + Ll if args.layout == "record" else (SBl + Ll + 63) // 64 * 64
+        sstr, qstr = t["seq"].numel() // n_reads, t["qual"].numel() // n_reads
+        rec = torch.zeros(n_reads * stride + 64, dtype=torch.uint8, device=dev)
+        rv = rec[:n_reads * stride].view(n_reads, stride)
+        rv[:, :SBl] = t["seq"].view(n_reads, sstr)[:, :SBl]
+        rv[:, SBl:SBl + Ll] = t["qual"].view(n_reads, qstr)[:, :Ll]
+        t["seq_off"] = torch.arange(n_reads, dtype=torch.int64, device=dev) * stride
+        t["qual_off"] = t["seq_off"] + SBl
+        t["seq"] = t["qual"] = rec[:n_reads * stride]
+        seqs = [padded_clone(t["seq"]) for _ in range(n_copies)]
+        quals = seqs
+        del rec, rv
+    else:
+        seqs = [padded_clone(t["seq"]) for _ in range(n_copies)]
+        quals = [padded_clone(t["qual"]) for _ in range(n_copies)]
     t["qname"] = padded_clone(t["qname"])
 
     stats_dev = torch.zeros(2 * capi.GCE_STATS_WORDS, dtype=torch.int64, device=dev)

@@ -732,7 +732,7 @@ static int gce_process_impl(gce_engine *e) {
         // top quality reaches `moderate` is bound to reach baseScoreReq too: that voter scores s_moderate or s_high (or >= min + 4 inside a
         // matching mate overlap) and nobody scores below 0
         p.s_min_lb = mn;
-        p.vote_ok = mn >= 0 && mx + 4 <= 120 && p.moderate_q >= 0 && p.moderate_q <= 127 && p.base_score_req <= 100;
+        p.vote_ok = mn >= 0 && mx + 4 <= 120 && p.moderate_q >= 0 && p.moderate_q <= 127 && p.base_score_req <= 100 && p.q2s_swar_ok;   // (nested thresholds: k_vote's items index q2s_lut by the number of thresholds passed)
         p.vote_accept_by_qual = std::min(std::min(p.s_moderate, p.s_high), mn + 4) >= std::max(p.base_score_req, 1);
     }
     memcpy(p.prefix, e->prm.umi_prefix, 32); p.prefix[31] = 0; p.prefix_len = (int)strlen(p.prefix);

@@ -70,6 +70,9 @@ static_assert(VB_W + 32 <= 256, "pair indices of a batch are bytes");
 #ifndef VB_WPE
 #define VB_WPE 8
 #endif
+#ifndef VB_COLPAIR
+#define VB_COLPAIR 1          // pass-B items of TWO neighbouring contested columns of one voter (round 6); 0 = one column per item, two items per trip (rounds 2-5)
+#endif
 #ifndef VB_SMAX
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
 #endif
@@ -102,6 +105,11 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t c) {
     union { uint32_t u; vb_us2 v; } x, y, z; x.u = a; y.u = c; z.v = __builtin_elementwise_max(x.v, y.v); return z.u;
 }
 __device__ __forceinline__ uint64_t ld8_unaligned(const uint8_t *p_) { typedef uint64_t u64u __attribute__((aligned(1))); return *(const u64u *)p_; }
+#ifndef VB_LD16
+#define VB_LD16 1
+#endif
+typedef uint64_t vb_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vb_u64x2 vb_ld16(const uint8_t *p_) { typedef vb_u64x2 u128u __attribute__((aligned(1))); return *(const u128u *)p_; }   // one global_load_dwordx4
 // gather the top bit of each of the 4 bytes of x into bits 0..3
 __device__ __forceinline__ uint32_t msb4(uint32_t x) { return (((x >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu; }
 // one bit per nibble of an 8-byte packed-base word (memory order: byte k = columns 2k (high nibble), 2k+1 (low nibble)) -> 16-bit column mask
@@ -166,18 +174,32 @@ __device__ __forceinline__ int vb_find(const uint16_t *pre, int n, int it) {    
 // No bounds tests (each one was an exec-mask branch of its own around one LDS read, four per trip): pre[n] is the total -- larger than every item, as
 // is whatever follows it in the array (the next sides' prefixes, then the 0xFFFF the arrays are padded with: VB_PRE entries) -- so reading up to four
 // entries past n is harmless and never counted.
+#ifndef VB_FIND_ALIGNED
+#define VB_FIND_ALIGNED 1
+#endif
 #define VB_PRE (VB_SIDES + 8)
 __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base, int lane, int last) {
     last = max(last, 0);
     const int b0 = min(base, last), it = min(base + lane, last);
     const int pl = (int)pre[min(lane, n)];
     int s = __popcll(__ballot(pl <= b0)) - 1;
+#if VB_FIND_ALIGNED
+    // the four entries of the ALIGNED 8-byte group that holds pre[s + 1] (round 6: the walk read pre[s + 1 .. s + 4] -- an 8-byte LDS read on a 2-byte boundary three
+    // times out of four; SQ_LDS_UNALIGNED_STALL was a third of the kernel's LDS-active cycles).  The group's entries up to s are <= the item like pre[s] itself, so
+    // counting all four that are gives the place directly.
+    for (int g = (s + 1) >> 2;; g++) {
+        const uint2 w2 = *reinterpret_cast<const uint2 *>(pre + 4 * g);
+        const int c = ((int)(w2.x & 0xFFFFu) <= it) + ((int)(w2.x >> 16) <= it) + ((int)(w2.y & 0xFFFFu) <= it) + ((int)(w2.y >> 16) <= it);
+        if (c < 4) { s = 4 * g + c - 1; break; }
+    }
+#else
     for (;;) {
         const int a1 = (int)pre[s + 1], a2 = (int)pre[s + 2], a3 = (int)pre[s + 3], a4 = (int)pre[s + 4];
         const int c = (a1 <= it) + (a2 <= it) + (a3 <= it) + (a4 <= it);
         s += c;
         if (c < 4) break;
     }
+#endif
     return s;
 }
 
@@ -198,9 +220,9 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
     __shared__ __attribute__((aligned(16))) uint32_t s_tal[VB_CCAP][5][2];         // pass B: per contested column and bin {count | biased score sum << 6 | qual sum << 20, top qual}:
                                                                                    // <= 32 voters, biased scores <= 255, quals < 128 on this path => 6 + 14 + 12 bits, one atomic add per vote
     __shared__ uint8_t s_ccol[VB_RCAP], s_cq[VB_RCAP], s_cb[VB_RCAP];              // contested columns (side by side, ascending): column; voted qual, voted base
-    __shared__ uint16_t s_jpre[VB_PRE];                                      // pass B: first (voter, column) item of every side
+    __shared__ __attribute__((aligned(8))) uint16_t s_jpre[VB_PRE];                                      // pass B: first (voter, column) item of every side
     __shared__ uint32_t s_ggi[VB_MAXG], s_gbeg[VB_MAXG];
-    __shared__ uint16_t s_ipre[VB_PRE], s_cpre[VB_PRE];                            // (entries behind VB_SIDES: 0xFFFF, see vb_find_wave)
+    __shared__ __attribute__((aligned(8))) uint16_t s_ipre[VB_PRE], s_cpre[VB_PRE];                            // (entries behind VB_SIDES: 0xFFFF, see vb_find_wave)
     __shared__ uint8_t s_wbase[VB_SIDES][VB_COLS / 32];                            // place in the SIDE's contested-column list (<= VB_SMAX) of the first column of every 32-column word (P5b -> P7)
     __shared__ __attribute__((aligned(16))) uint16_t s_glp0[VB_MAXG];              // first pair of every group (unused entries: 0x7FFF)
     __shared__ uint8_t s_gnp[VB_MAXG], s_gflag[VB_MAXG];      // gflag: 1 = deep (handed on at once), 2 = odd / out of scope found later
@@ -480,10 +502,16 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
                 const VRead *r3 = vm ? rds + (__ffs((int)vm) - 1) : r0; vm &= vm ? vm - 1 : 0u;
                 const uint64_t so0 = r0->so, qo0 = r0->qo, so1 = r1->so, qo1 = r1->qo, so2 = r2->so, qo2 = r2->qo, so3 = r3->so, qo3 = r3->qo;
                 uint64_t sq[4], qa[4], qb[4];
+#if VB_LD16        // the 16 qualities of a voter's chunk in ONE load (round 6: eight vector memory instructions per step instead of twelve)
+                { const vb_u64x2 q0_ = vb_ld16(b.qual + qo0 + c16), q1_ = vb_ld16(b.qual + qo1 + c16), q2_ = vb_ld16(b.qual + qo2 + c16), q3_ = vb_ld16(b.qual + qo3 + c16);
+                  sq[0] = ld8_unaligned(b.seq + so0 + 8 * chunk); sq[1] = ld8_unaligned(b.seq + so1 + 8 * chunk); sq[2] = ld8_unaligned(b.seq + so2 + 8 * chunk); sq[3] = ld8_unaligned(b.seq + so3 + 8 * chunk);
+                  qa[0] = q0_.x; qb[0] = q0_.y; qa[1] = q1_.x; qb[1] = q1_.y; qa[2] = q2_.x; qb[2] = q2_.y; qa[3] = q3_.x; qb[3] = q3_.y; }
+#else
                 sq[0] = ld8_unaligned(b.seq + so0 + 8 * chunk); qa[0] = ld8_unaligned(b.qual + qo0 + c16); qb[0] = ld8_unaligned(b.qual + qo0 + c16 + 8);
                 sq[1] = ld8_unaligned(b.seq + so1 + 8 * chunk); qa[1] = ld8_unaligned(b.qual + qo1 + c16); qb[1] = ld8_unaligned(b.qual + qo1 + c16 + 8);
                 sq[2] = ld8_unaligned(b.seq + so2 + 8 * chunk); qa[2] = ld8_unaligned(b.qual + qo2 + c16); qb[2] = ld8_unaligned(b.qual + qo2 + c16 + 8);
                 sq[3] = ld8_unaligned(b.seq + so3 + 8 * chunk); qa[3] = ld8_unaligned(b.qual + qo3 + c16); qb[3] = ld8_unaligned(b.qual + qo3 + c16 + 8);
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     sor |= sq[k]; sand &= sq[k];
@@ -585,7 +613,11 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             pre = cnt;
             pre = wave_scan_incl(pre);                                                  // (dropping sides only lowers the prefixes of the others)
         }
+#if VB_COLPAIR
+        const int nit = act ? ((cnt + 1) >> 1) * (int)s_side[lane].nvot : 0;          // (voter, column pair) items
+#else
         const int nit = act ? cnt * (int)s_side[lane].nvot : 0;
+#endif
         int pre2 = nit;
         pre2 = wave_scan_incl(pre2);
         if (lane < VB_SIDES) { s_cpre[lane] = (uint16_t)(pre - cnt); s_jpre[lane] = (uint16_t)(pre2 - nit); }
@@ -620,6 +652,80 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
         __syncthreads();
         VB_TICK(5);
+#if VB_COLPAIR
+        // (c) one lane per (side, voter, PAIR of neighbouring contested columns of the side's list), column pairs fastest (round 6).  What an item pays before it can ask for
+        //     its bytes -- its side in the prefix, the division by the side's width, the voter, the voter's blob offsets and overlap window -- belongs to the VOTER, not to the
+        //     column: two columns share it (rounds 2-5: one column per item, 144 wave instructions per 64 votes of which ~50 are the vote itself; voter quads x one column, round 5,
+        //     shared only the side).  A side with an odd number of columns pads half an item per voter.  The byte loads of both columns are in flight together.
+        //     k_vote executes 7 % fewer VALU instructions (1.029 -> 0.954 G per launch at cfg3, profiles/r06_e_*).
+        struct Item { int ci, side, grp; int q[2], sb[2], mb[2], mq[2], mc[2], col[2]; bool on, on1, cst; bool inov[2]; };
+        auto prep = [&](int it, int s) -> Item {
+            Item x; x.on = it < j0 + njob; x.on1 = false; x.ci = 0; x.side = 0; x.grp = 0; x.cst = false;
+#pragma unroll
+            for (int u = 0; u < 2; u++) { x.q[u] = 0; x.sb[u] = 0; x.mb[u] = 0; x.mq[u] = 0; x.mc[u] = 0; x.col[u] = 0; x.inov[u] = false; }
+            if (!x.on) return x;
+            x.side = s & 1;
+            const int cb = (int)s_cpre[s], ncs = (int)s_cpre[s + 1] - cb, ncs2 = (ncs + 1) >> 1, local = it - (int)s_jpre[s];
+            const int kv = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ncs2)), c = 2 * (local - kv * ncs2);      // local / ncs2 (local < 512, ncs2 <= 16: the half keeps it exact)
+            x.ci = cb + c; x.on1 = c + 1 < ncs;
+            x.col[0] = s_ccol[x.ci]; x.col[1] = s_ccol[x.ci + (x.on1 ? 1 : 0)];
+            const VSide *sd = &s_side[s];
+            x.grp = sd->grp;
+            const int lp = s_vlist[x.side][(int)sd->lp0 + kv];
+            const VRead *r = &s_rd[x.side][lp];
+            const uint64_t so = r->so, qo = r->qo;
+            const VOv ov = s_ov[lp];
+            const int mystart = x.side ? ov.rs : ov.ls, matestart = x.side ? ov.ls : ov.rs;
+            x.cst = ov.fl & 1;
+            bool any_ov = false;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                x.inov[u] = (ov.fl & 2) && (unsigned)(x.col[u] - mystart) < (unsigned)ov.cmp;
+                any_ov |= x.inov[u];
+                x.sb[u] = b.seq[so + (x.col[u] >> 1)];
+                x.q[u] = b.qual[qo + x.col[u]];
+            }
+            if (any_ov) {                                                               // pair.cpp:132-168: the mate's base and quality on the same reference position
+                const VRead *mt = &s_rd[x.side ^ 1][lp];
+                const uint64_t mso = mt->so, mqo = mt->qo;
+#pragma unroll
+                for (int u = 0; u < 2; u++) if (x.inov[u]) {
+                    x.mc[u] = x.col[u] - mystart + matestart;
+                    x.mb[u] = b.seq[mso + (x.mc[u] >> 1)]; x.mq[u] = b.qual[mqo + x.mc[u]];
+                }
+            }
+            return x;
+        };
+        auto vote1 = [&](const Item &x, int u) {
+            int q = x.q[u];
+            const int nb = (x.col[u] & 1) ? (x.sb[u] & 0xF) : (x.sb[u] >> 4);
+            const int mn = (x.mc[u] & 1) ? (x.mb[u] & 0xF) : (x.mb[u] >> 4);
+            const bool match = x.inov[u] && nb == mn, mism = x.inov[u] && nb != mn;
+            const bool left_wins = x.side ? (x.mq[u] >= q) : (q >= x.mq[u]);            // `if(lq >= rq)`: the left read keeps a score
+            const int dq = max(0, q - x.mq[u]);
+            const int qlook = match ? (((q + x.mq[u]) / 2) & 0xFF) : mism ? dq : q;
+            const bool scored = !mism || (x.side == 0 ? left_wins : !left_wins);        // the mismatch loser scores 0
+            // Pair::qual2score (pair.cpp:77-86) by the NUMBER OF THRESHOLDS PASSED (they are nested on this path: vote_ok) into the four biased scores packed in q2s_lut.
+            // d_qual2score's nested selects compile to a select of ADDRESSES and one vector load from the kernel-argument segment: a third dependent trip to memory in every
+            // item (bytes -> score -> tally), 2.4 us of a batch's 9.6 us in this phase (-DVB_PROF, profiles/r06_*).
+            const int nthr = (qlook >= p.low_q) + (qlook >= p.moderate_q) + (qlook >= p.high_q);
+            int sc = (int)((p.q2s_lut >> (8 * nthr)) & 0xFFu) + (match ? 4 : mism ? -3 : 0);          // biased
+            sc = scored ? sc : p.score_bias;
+            sc = x.cst ? p.s_moderate + p.score_bias : sc;
+            q = mism ? dq : q;                                                          // the rewritten quality is what the vote sees
+            const int bin = (int)((uint32_t)(0x4777777377727107ull >> (nb * 4)) & 7u);        // A,C,G,T,N -> 0..4, anything else 7
+            if (bin == 7 || (q & 0x80)) s_gflag[x.grp] = 2;
+            else {
+                uint32_t *t2 = &s_tal[x.ci + u - c0][bin][0];
+                atomicAdd(t2, 1u | ((uint32_t)sc << 6) | ((uint32_t)q << 20)); atomicMax(t2 + 1, (uint32_t)q);
+            }
+        };
+        for (int itb = j0 + tid - lane; itb < j0 + njob; itb += VB_T) {                 // (wave-uniform trips: the side lookup is a wave operation)
+            const int sa = s0 + vb_find_wave(s_jpre + s0, s1 - s0, itb, lane, j0 + njob - 1);
+            const Item x0 = prep(itb + lane, sa);
+            if (x0.on) { vote1(x0, 0); if (x0.on1) vote1(x0, 1); }
+        }
+#else
         // (c) one lane per (side, voter, contested column), columns fastest.  Two items per trip: the byte loads of both are issued
         //     before either is used (an item is two dependent round trips otherwise: LDS lookups -> its bytes)
         struct Item { int ci, side, grp, q, sb, mb, mq, mc, col; bool on, inov, cst; };
@@ -675,6 +781,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             const Item x0 = prep(itb + lane, sa), x1 = prep(itb + lane + VB_T, sb2);
             vote(x0); vote(x1);
         }
+#endif
         __syncthreads();
         VB_TICK(6);
         // (d) one lane per column of the round: rule cascade + reference arbitration (group.cpp:394-501)

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 300 python bench.py --nccl-world1 --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r06_d_bench_nccl_world1.json; python -c "
-import json; d=json.load(open('gpurun_out/r06_d_bench_nccl_world1.json')); print(d['ms_per_step'], d.get('stats_merge_ms_per_step'), d.get('backend'), d['roofline'].get('traffic_source'))"
+timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -3 > gpurun_out/r06_l_quick_tests.txt
+bash tools/abn.sh "abx/cq.so abx/cq_ld16.so abx/cq_ld16_fa.so" 2>&1 | tee gpurun_out/r06_l_ab.txt
+cat gpurun_out/r06_l_quick_tests.txt
