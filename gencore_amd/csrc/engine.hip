@@ -1021,6 +1021,9 @@ static int gce_process_impl(gce_engine *e) {
         const double blocks = (double)hs.prof[15];
         fprintf(stderr, "k_vote phases, mean per block (100 MHz ticks -> us), %.0f blocks:", blocks);
         for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.2f;", nm[k], blocks ? hs.prof[k] / blocks / 100.0 : 0.0);
+#ifndef VB_COUNT
+        fprintf(stderr, " [of P2: (a) reads vs class %.2f; (b) sides' states %.2f; the rest = order, prefixes, barrier]", blocks ? hs.prof[11] / blocks / 100.0 : 0.0, blocks ? hs.prof[12] / blocks / 100.0 : 0.0);
+#endif
         fprintf(stderr, "\n");
 #ifdef VB_COUNT
         fprintf(stderr, "k_vote columns in the full vote: %.0f, one base only: %.0f, of those unchanged: %.0f\n", (double)hs.prof[11], (double)hs.prof[12], (double)hs.prof[13]);

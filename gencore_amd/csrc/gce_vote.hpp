@@ -126,6 +126,14 @@ __device__ __forceinline__ uint64_t nib_acgtn(uint64_t v) {
     return (one | four) & 0x1111111111111111ull;
 }
 
+// d_ref_nib (gce_device.hpp) through a pointer that is known to be global memory
+__device__ __forceinline__ int d_ref_nib_g(uint64_t ref, int64_t pos) {
+    typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;
+    const int bq = ((gptr_u8)ref)[pos >> 1];
+    const int code = (pos & 1) ? (bq >> 4) : (bq & 0xF);
+    return (int)((0x42810u >> (4 * (code < 5 ? code : 5))) & 0xFu);
+}
+
 // weights + batch starts: exclusive scan of the group weights (k_u64_reduce / k_u64_partials in front), first group of every batch
 __global__ __launch_bounds__(256) void k_vote_batches(Work w, const unsigned long long *n_ptr, const uint64_t *part) {
     __shared__ uint64_t s_w[4];
@@ -209,6 +217,11 @@ __device__ __forceinline__ int vb_find_wave(const uint16_t *pre, int n, int base
 #define VB_TICK(k) do { if ((k) >= VB_STOP) return; } while (0)
 #else
 #define VB_TICK(k) do { } while (0)
+#endif
+#if defined(VB_PROF) && !defined(DV_PROF) && !defined(VB_COUNT)
+#define VB_SUBTICK(k) VB_TICK(k)            // clocks inside a phase (slots 11.. of StreamInfo.prof; the phase's own slot then holds the rest)
+#else
+#define VB_SUBTICK(k) do { } while (0)
 #endif
 #define gb_ gb_
 __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8))) void k_vote(DevBatch b, DevParams p, Work w, uint32_t n_groups) {
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         }
     }
     __syncthreads();
+    VB_SUBTICK(11);                                 // (-DVB_PROF: P2a alone)
     // (b) lane = (group, side)
     if (tid < 64) {
         const int j = lane >> 1, side = lane & 1;
@@ -425,6 +439,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
                 }
             }
         }
+        VB_SUBTICK(12);                             // (-DVB_PROF: P2b up to the sides' states)
         if (lane < VB_SIDES) s_cnt[lane] = 0u;
         // a group goes on as a whole (all shuffles on wave-uniform paths)
         const int other_gen = __shfl_xor((int)to_gen, 1);                              // (unconditional: `a || shfl(..)` would shuffle in a divergent branch)
@@ -794,7 +809,7 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             int ref4 = 0;
             if (sd.ref) {                                                               // group.cpp:430-439
                 const int ro = sd.o_nc == 1 ? (col < cig_len(sd.o_c0) ? col : -1) : d_ref_offset(b.cigar + b.cigar_off[sd.result], sd.o_nc, col);
-                if (ro >= 0 && (int64_t)sd.o_pos + ro < sd.ref_len) ref4 = d_ref_nib((const uint8_t *)sd.ref, (int64_t)sd.o_pos + ro);
+                if (ro >= 0 && (int64_t)sd.o_pos + ro < sd.ref_len) ref4 = d_ref_nib_g(sd.ref, (int64_t)sd.o_pos + ro);      // (a GLOBAL load: the pointer comes out of LDS as an integer, and a generic one is a flat_load)
             }
             const int out_base = d_nib(b.seq + s_rd[s & 1][sd.lp0 + sd.tmpl].so, col);
             Tally5 t; t.total = 0;

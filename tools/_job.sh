@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -3 > gpurun_out/r06_l_quick_tests.txt
-bash tools/abn.sh "abx/cq.so abx/cq_ld16.so abx/cq_ld16_fa.so" 2>&1 | tee gpurun_out/r06_l_ab.txt
-cat gpurun_out/r06_l_quick_tests.txt
+timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -3 > gpurun_out/r06_n_quick_tests.txt
+bash tools/abn.sh "abx/cq_ld16_fa.so abx/p2reg_g.so abx/dpf.so" 2>&1 | tee gpurun_out/r06_n_ab.txt
+cat gpurun_out/r06_n_quick_tests.txt
