@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -3 > gpurun_out/r06_n_quick_tests.txt
-bash tools/abn.sh "abx/cq_ld16_fa.so abx/p2reg_g.so abx/dpf.so" 2>&1 | tee gpurun_out/r06_n_ab.txt
-cat gpurun_out/r06_n_quick_tests.txt
+timeout 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r06_o_gpu_suite.log; cat gpurun_out/r06_o_gpu_suite.log
+GCE_RAW_TIMING=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "gce_process (device" | head -3
+GCE_RAW_TIMING=1 timeout 600 python tools/bam_bench.py --pairs 4000000 --shards 4 --c-caller 2>&1 | grep "gce_process (device\|^{" | tail -8 | cut -c1-400
