@@ -221,7 +221,14 @@ __device__ __forceinline__ int d_ref_nib(const uint8_t *ref, int64_t pos) {
 }
 
 // Pair::qual2score (pair.cpp:77-86)
+// (round 6) With nested thresholds (q2s_swar_ok: low <= moderate <= high <= 127, every sane configuration) the NUMBER of thresholds passed indexes the four scores packed in
+// q2s_lut -- pure ALU.  The nested selects below compile to a select of ADDRESSES into the kernel-argument segment and one vector load from it: a dependent trip to
+// memory per score wherever a kernel scores base by base (k_vote's items until round 6, k_score2's overlap units, the bytewise paths of the deep kernels).
 __device__ __forceinline__ int d_qual2score(const DevParams &p, int q) {
+    if (p.q2s_swar_ok) {
+        const int nthr = (q >= p.low_q) + (q >= p.moderate_q) + (q >= p.high_q);
+        return (int)((p.q2s_lut >> (8 * nthr)) & 0xFFu) - p.score_bias;
+    }
     return q >= p.high_q ? p.s_high : q >= p.moderate_q ? p.s_moderate : q >= p.low_q ? p.s_low : p.s_bad;
 }
 

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r06_o_gpu_suite.log; cat gpurun_out/r06_o_gpu_suite.log
-GCE_RAW_TIMING=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "gce_process (device" | head -3
-GCE_RAW_TIMING=1 timeout 600 python tools/bam_bench.py --pairs 4000000 --shards 4 --c-caller 2>&1 | grep "gce_process (device\|^{" | tail -8 | cut -c1-400
+timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke or deep" 2>&1 | tail -3 > gpurun_out/r06_p_quick_tests.txt
+bash tools/abn.sh "abx/base.so abx/q2sg.so" --workload cfg5 2>&1 | tee gpurun_out/r06_p_ab_cfg5.txt
+bash tools/abn.sh "abx/base.so abx/q2sg.so" 2>&1 | tee gpurun_out/r06_p_ab_cfg3.txt
+cat gpurun_out/r06_p_quick_tests.txt
