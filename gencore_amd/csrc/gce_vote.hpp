@@ -70,8 +70,15 @@ static_assert(VB_W + 32 <= 256, "pair indices of a batch are bytes");
 #ifndef VB_WPE
 #define VB_WPE 8
 #endif
+#ifndef VB_TPLANE
+#define VB_TPLANE 1             // tallies as ten planes of VB_CCAP dwords (add / max word of every bin), a pair item's columns half a side apart: consecutive lanes -> consecutive banks
+#endif
 #ifndef VB_COLPAIR
 #define VB_COLPAIR 1          // pass-B items of TWO neighbouring contested columns of one voter (round 6); 0 = one column per item, two items per trip (rounds 2-5)
+#endif
+#if !VB_COLPAIR
+#undef VB_TPLANE
+#define VB_TPLANE 0
 #endif
 #ifndef VB_SMAX
 #define VB_SMAX 32         // a side with more contested columns than this hands its group on
@@ -664,7 +671,17 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         const unsigned long long nofit_ = ~__ballot(fits_);
         const int s1 = nofit_ ? __ffsll((long long)nofit_) - 1 : 64;                            // first side that does not fit (prefixes ascend: every later one does not either); VB_SIDES if all do
         const int c0 = s_cpre[s0], ncol = (int)s_cpre[s1] - c0, j0 = s_jpre[s0], njob = (int)s_jpre[s1] - j0;
+#if VB_TPLANE
+        {
+            uint32_t *tp_ = &s_tal[0][0][0];
+            for (int c = tid; c < ncol; c += VB_T) {
+#pragma unroll
+                for (int pl = 0; pl < 10; pl++) tp_[pl * VB_CCAP + c] = 0u;
+            }
+        }
+#else
         for (int k = tid; k < ncol * 5; k += VB_T) *(uint2 *)(&s_tal[0][0][0] + 2 * k) = make_uint2(0, 0);
+#endif
         __syncthreads();
         VB_TICK(5);
 #if VB_COLPAIR
@@ -673,17 +690,23 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
         //     column: two columns share it (rounds 2-5: one column per item, 144 wave instructions per 64 votes of which ~50 are the vote itself; voter quads x one column, round 5,
         //     shared only the side).  A side with an odd number of columns pads half an item per voter.  The byte loads of both columns are in flight together.
         //     k_vote executes 7 % fewer VALU instructions (1.029 -> 0.954 G per launch at cfg3, profiles/r06_e_*).
-        struct Item { int ci, side, grp; int q[2], sb[2], mb[2], mq[2], mc[2], col[2]; bool on, on1, cst; bool inov[2]; };
+        struct Item { int ci, d1, side, grp; int q[2], sb[2], mb[2], mq[2], mc[2], col[2]; bool on, on1, cst; bool inov[2]; };      // (d1: the second column's distance in the list)
         auto prep = [&](int it, int s) -> Item {
-            Item x; x.on = it < j0 + njob; x.on1 = false; x.ci = 0; x.side = 0; x.grp = 0; x.cst = false;
+            Item x; x.on = it < j0 + njob; x.on1 = false; x.ci = 0; x.d1 = 0; x.side = 0; x.grp = 0; x.cst = false;
 #pragma unroll
             for (int u = 0; u < 2; u++) { x.q[u] = 0; x.sb[u] = 0; x.mb[u] = 0; x.mq[u] = 0; x.mc[u] = 0; x.col[u] = 0; x.inov[u] = false; }
             if (!x.on) return x;
             x.side = s & 1;
             const int cb = (int)s_cpre[s], ncs = (int)s_cpre[s + 1] - cb, ncs2 = (ncs + 1) >> 1, local = it - (int)s_jpre[s];
+#if VB_TPLANE
+            const int kv = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ncs2)), c = local - kv * ncs2;            // local / ncs2 (local < 512, ncs2 <= 16: the half keeps it exact)
+            x.ci = cb + c; x.on1 = c + ncs2 < ncs; x.d1 = x.on1 ? ncs2 : 0;                                                  // the item's columns: c and c + half the side's width
+            x.col[0] = s_ccol[x.ci]; x.col[1] = s_ccol[x.ci + x.d1];
+#else
             const int kv = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)ncs2)), c = 2 * (local - kv * ncs2);      // local / ncs2 (local < 512, ncs2 <= 16: the half keeps it exact)
-            x.ci = cb + c; x.on1 = c + 1 < ncs;
-            x.col[0] = s_ccol[x.ci]; x.col[1] = s_ccol[x.ci + (x.on1 ? 1 : 0)];
+            x.ci = cb + c; x.on1 = c + 1 < ncs; x.d1 = x.on1 ? 1 : 0;
+            x.col[0] = s_ccol[x.ci]; x.col[1] = s_ccol[x.ci + x.d1];
+#endif
             const VSide *sd = &s_side[s];
             x.grp = sd->grp;
             const int lp = s_vlist[x.side][(int)sd->lp0 + kv];
@@ -731,8 +754,13 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             const int bin = (int)((uint32_t)(0x4777777377727107ull >> (nb * 4)) & 7u);        // A,C,G,T,N -> 0..4, anything else 7
             if (bin == 7 || (q & 0x80)) s_gflag[x.grp] = 2;
             else {
-                uint32_t *t2 = &s_tal[x.ci + u - c0][bin][0];
+#if VB_TPLANE
+                uint32_t *t2 = &s_tal[0][0][0] + (2 * bin) * VB_CCAP + (x.ci + (u ? x.d1 : 0) - c0);
+                atomicAdd(t2, 1u | ((uint32_t)sc << 6) | ((uint32_t)q << 20)); atomicMax(t2 + VB_CCAP, (uint32_t)q);
+#else
+                uint32_t *t2 = &s_tal[x.ci + (u ? x.d1 : 0) - c0][bin][0];
                 atomicAdd(t2, 1u | ((uint32_t)sc << 6) | ((uint32_t)q << 20)); atomicMax(t2 + 1, (uint32_t)q);
+#endif
             }
         };
         for (int itb = j0 + tid - lane; itb < j0 + njob; itb += VB_T) {                 // (wave-uniform trips: the side lookup is a wave operation)
@@ -815,7 +843,12 @@ __global__ __launch_bounds__(VB_T) __attribute__((amdgpu_waves_per_eu(VB_WPE, 8)
             Tally5 t; t.total = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
+#if VB_TPLANE
+                const uint32_t *tp_ = &s_tal[0][0][0] + (2 * k) * VB_CCAP + (ci - c0);
+                const uint2 v2 = make_uint2(tp_[0], tp_[VB_CCAP]);
+#else
                 const uint2 v2 = *(const uint2 *)(&s_tal[ci - c0][k][0]);
+#endif
                 t.cnt[k] = (int)(v2.x & 63u); t.ss[k] = (int)((v2.x >> 6) & 0x3FFFu) - t.cnt[k] * p.score_bias; t.qs[k] = (int)(v2.x >> 20); t.tq[k] = (int)v2.y;
                 t.total += t.ss[k];
             }

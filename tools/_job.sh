@@ -1,5 +1,4 @@
-cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh r06_z > gpurun_out/r06_z_profile_round.log 2>&1
-bash tools/lds_round.sh r06_z >> gpurun_out/r06_z_profile_round.log 2>&1
-tail -3 gpurun_out/r06_z_profile_round.log | cut -c1-300
-du -sh gpurun_out
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -x -q -k "hand_derived or fuzz_stream or quirk or exotic or smoke" 2>&1 | tail -3 > gpurun_out/r06_r_quick_tests.txt
+bash tools/abn.sh "abx/q2sg.so abx/tplane.so" 2>&1 | tee gpurun_out/r06_r_ab.txt
+cat gpurun_out/r06_r_quick_tests.txt
