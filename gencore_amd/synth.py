@@ -107,7 +107,7 @@ class SynthData:
         return [(r.cpu().numpy(), n) for r, n in self.reference]
 
 
-def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, align=1, shard=None, flush_period=10000, **over):
+def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 21, align=1, shard=None, flush_period=10000, legacy_shard=False, **over):
     """align: start every read's seq / qual slice on a multiple of `align` bytes (the gce_batch offsets are free-form;
     an aligned layout lets the kernels' dword accesses stay inside cache lines).
     shard=(rank, world): plan the WHOLE stream (molecules, pairs, the sorted order of all reads: cheap), cut it into `world` ranges
@@ -162,92 +162,150 @@ def generate(name="cfg2", n_pairs=None, seed=0, device="cpu", chunk_reads=1 << 2
     U = int(cfg["umi"])
     Utot = 2 * U if cfg["duplex"] else U
 
-    # ---------------------------------------------------------------- duplicates (pairs)
-    pid = torch.arange(P, **i64)
-    mol = torch.repeat_interleave(mid, depth)
-    p_tid, p_start, p_ins = m_tid[mol], m_start[mol], ins[mol]
-    if cfg["duplex"]:
-        strand = rnd_u(seed, 4, pid, 2)
-    else:
-        strand = m_strand[mol]
-    # alignment variant per read: 0 = LM (97%), 1 = leading S, 2 = trailing S (2%), 3 = I, 4 = D (1%)
-    def variant(stream):
-        r = rnd_u(seed, stream, pid, 1000)
-        kind = torch.zeros(P, **i64)
-        kind = torch.where(r >= 970, 1 + (r & 1), kind)
-        kind = torch.where(r >= 990, 3 + (r & 1), kind)
-        k = torch.where((kind == 1) | (kind == 2), 3 + rnd_u(seed, stream + 1, pid, 8), 1 + rnd_u(seed, stream + 1, pid, 3))
-        k = torch.where(kind == 0, torch.zeros_like(k), k)
-        a = 20 + rnd_u(seed, stream + 2, pid, L - 60)       # split point for I/D
-        return kind, k, a
-    fk, fklen, fa = variant(20)
-    rk, rklen, ra = variant(30)
-    f_pos = p_start + torch.where(fk == 1, fklen, torch.zeros_like(fklen))
-    r0 = p_start + p_ins - L
-    r_pos = r0 + torch.where(rk == 1, rklen, torch.zeros_like(rklen))
+    # ---------------------------------------------------------------- duplicates (pairs): everything about a pair is a pure function of its GLOBAL id
+    cdepth = torch.cumsum(depth, 0)                          # pair id -> molecule: the first molecule whose cumulative depth exceeds it
 
     def ref_span(kind, k):
         return torch.where(kind == 0, torch.full_like(k, L), torch.where((kind == 1) | (kind == 2), L - k, torch.where(kind == 3, L - k, L + k)))
-    f_end = f_pos + ref_span(fk, fklen)
-    r_end = r_pos + ref_span(rk, rklen)
-    tlen = torch.maximum(f_end, r_end) - torch.minimum(f_pos, r_pos)
-    f_is_left = f_pos <= r_pos
-    f_isize = torch.where(f_is_left, tlen, -tlen)
-    r_isize = -f_isize
 
-    # ---------------------------------------------------------------- reads = 2 per pair, sorted by (tid, pos)
-    N = 2 * P
-    rd_pair = torch.cat([pid, pid])
-    rd_rev = torch.cat([torch.zeros(P, **i64), torch.ones(P, **i64)])
-    rd_pos = torch.cat([f_pos, r_pos])
-    rd_tid = torch.cat([p_tid, p_tid])
-    # tie order inside one (tid,pos): a scrambled pair id, like an aligner's arbitrary order
-    key = (rd_tid << 40) | rd_pos
-    tie = rnd_u(seed, 5, rd_pair * 2 + rd_rev, 1 << 20)
-    order = torch.argsort(tie, stable=True)
-    order = order[torch.argsort(key[order], stable=True)]
-    rd_pair, rd_rev = rd_pair[order], rd_rev[order]
-    del order, tie, rd_pos, rd_tid
+    def pair_level(ids, light=False):
+        """pair-level fields of the pairs `ids` (ascending global pair ids); light: only (tid, forward position, reverse position)"""
+        mol_ = torch.searchsorted(cdepth, ids, right=True)
+        p_tid_, p_start_, p_ins_ = m_tid[mol_], m_start[mol_], ins[mol_]
+        # alignment variant per read: 0 = LM (97%), 1 = leading S, 2 = trailing S (2%), 3 = I, 4 = D (1%)
+        def variant(stream):
+            r = rnd_u(seed, stream, ids, 1000)
+            kind = torch.zeros_like(ids)
+            kind = torch.where(r >= 970, 1 + (r & 1), kind)
+            kind = torch.where(r >= 990, 3 + (r & 1), kind)
+            k = torch.where((kind == 1) | (kind == 2), 3 + rnd_u(seed, stream + 1, ids, 8), 1 + rnd_u(seed, stream + 1, ids, 3))
+            k = torch.where(kind == 0, torch.zeros_like(k), k)
+            a = None if light else 20 + rnd_u(seed, stream + 2, ids, L - 60)       # split point for I/D
+            return kind, k, a
+        fk_, fklen_, fa_ = variant(20)
+        rk_, rklen_, ra_ = variant(30)
+        f_pos_ = p_start_ + torch.where(fk_ == 1, fklen_, torch.zeros_like(fklen_))
+        r0_ = p_start_ + p_ins_ - L
+        r_pos_ = r0_ + torch.where(rk_ == 1, rklen_, torch.zeros_like(rklen_))
+        if light:
+            return p_tid_, f_pos_, r_pos_
+        strand_ = rnd_u(seed, 4, ids, 2) if cfg["duplex"] else m_strand[mol_]
+        f_end = f_pos_ + ref_span(fk_, fklen_)
+        r_end = r_pos_ + ref_span(rk_, rklen_)
+        tlen = torch.maximum(f_end, r_end) - torch.minimum(f_pos_, r_pos_)
+        f_isize_ = torch.where(f_pos_ <= r_pos_, tlen, -tlen)
+        return dict(pid=ids, mol=mol_, p_tid=p_tid_, p_start=p_start_, p_ins=p_ins_, strand=strand_, fk=fk_, fklen=fklen_, fa=fa_, rk=rk_, rklen=rklen_, ra=ra_,
+                    f_pos=f_pos_, r_pos=r_pos_, r0=r0_, f_isize=f_isize_, r_isize=-f_isize_)
+
+    lean = shard is not None and not legacy_shard and cfg.get("shard_mode", "range") == "range"
     stream_context = global_index = None
     n_pairs_stream = P
-    if shard is not None:
+    if lean:
+        # Key-range shard WITHOUT the whole stream at pair level in memory (round 6; the legacy path below holds ~25 int64 arrays of all pairs: 48 GB and 2 s at 8 x 10 M pairs):
+        # the stream is walked in chunks of pairs for (tid, forward position, reverse position) alone -- 9 bytes per pair kept --, ONE stable sort of the reads' packed
+        # (tid, pos, tie) keys gives the stream order (the legacy path's two stable argsorts order by exactly that: key, then tie, then forward-before-reverse and pair id),
+        # and everything else is computed for this rank's pairs only.  The records are byte-identical (tests/test_host_logic.py).
         rank, world = shard
-        # every read of this generator reaches the cluster map, so a read's global tick is its place in the stream (gencore.cpp:319);
-        # flush events = the reads on which tick % period == 0 (gencore.cpp:321-322)
-        evi = torch.arange(flush_period - 1, N, flush_period, **i64) if N >= flush_period else torch.zeros(0, **i64)
-        ev_pair, ev_rev = rd_pair[evi], rd_rev[evi]
-        ev_pos = torch.where(ev_rev == 1, r_pos[ev_pair], f_pos[ev_pair])
-        ev_tid = p_tid[ev_pair]
-        # cluster key of a pair: (tid, left) with left = the leftmost of the two mates (the read with isize < 0 follows its mate,
-        # gencore.cpp:301-303); key ranges with equal pair counts
-        kp = (p_tid << 40) | torch.minimum(f_pos, r_pos)
-        if cfg.get("shard_mode", "range") == "lpt":
-            # ultra-deep hotspots: whole clusters dealt to the least loaded rank, heaviest first, weight = depth^2
-            uk, inv, cnt = torch.unique(kp, return_inverse=True, return_counts=True)
-            cn = cnt.cpu().numpy().astype(np.float64)
-            load, owner = np.zeros(world), np.zeros(len(cn), np.int64)
-            for c in np.argsort(-cn ** 2, kind="stable"):
-                r = int(np.argmin(load)); owner[c] = r; load[r] += cn[c] ** 2
-            mine_p = torch.from_numpy(owner).to(dev)[inv] == rank
-            del uk, inv, cnt
-        else:
-            srt = torch.sort(kp).values
-            cuts = srt[torch.tensor([min(P - 1, (P * r) // world) for r in range(1, world)], **i64)] if world > 1 else srt[:0]
-            mine_p = torch.searchsorted(cuts, kp, right=True) == rank
-            del srt
-        del kp
-        sel = torch.nonzero(mine_p[rd_pair]).squeeze(1)              # my reads, in stream order
+        assert max(contigs) < (1 << 28) and ncont < 32
+        CH = 1 << 23
+        t8 = torch.empty(P, dtype=torch.uint8, device=dev); fp32 = torch.empty(P, dtype=torch.int32, device=dev); rp32 = torch.empty(P, dtype=torch.int32, device=dev)
+        for a0 in range(0, P, CH):
+            ids = torch.arange(a0, min(P, a0 + CH), **i64)
+            tt, ff, rr = pair_level(ids, light=True)
+            t8[a0:a0 + ids.numel()] = tt.to(torch.uint8); fp32[a0:a0 + ids.numel()] = ff.to(torch.int32); rp32[a0:a0 + ids.numel()] = rr.to(torch.int32)
+            del ids, tt, ff, rr
+        N_all = 2 * P
+        key2 = torch.empty(N_all, **i64)
+        for a0 in range(0, P, CH):
+            b0 = min(P, a0 + CH)
+            ids = torch.arange(a0, b0, **i64)
+            tid_c = t8[a0:b0].to(torch.int64) << 28
+            key2[a0:b0] = ((tid_c | fp32[a0:b0].to(torch.int64)) << 20) | rnd_u(seed, 5, ids * 2, 1 << 20)
+            key2[P + a0:P + b0] = ((tid_c | rp32[a0:b0].to(torch.int64)) << 20) | rnd_u(seed, 5, ids * 2 + 1, 1 << 20)
+            del ids, tid_c
+        order = torch.sort(key2, stable=True).indices        # original index = rev * P + pair: ties of (key, tie) keep forward reads first, then the pair id
+        del key2
+        is_rev_all = order >= P
+        rd_pair_all = order - is_rev_all.to(torch.int64) * P
+        del order
+        evi = torch.arange(flush_period - 1, N_all, flush_period, **i64) if N_all >= flush_period else torch.zeros(0, **i64)
+        ev_pair, ev_rev = rd_pair_all[evi], is_rev_all[evi]
+        ev_pos = torch.where(ev_rev, rp32[ev_pair], fp32[ev_pair]).to(torch.int64)
+        ev_tid = t8[ev_pair].to(torch.int64)
+        kp = (t8.to(torch.int64) << 40) | torch.minimum(fp32, rp32).to(torch.int64)
+        srt = torch.sort(kp).values
+        cuts = srt[torch.tensor([min(P - 1, (P * r) // world) for r in range(1, world)], **i64)] if world > 1 else srt[:0]
+        del srt
+        mine_p = torch.searchsorted(cuts, kp, right=True) == rank
+        del kp, t8, fp32, rp32
+        sel = torch.nonzero(mine_p[rd_pair_all]).squeeze(1)          # my reads, in stream order
         loc = torch.cumsum(mine_p.to(torch.int64), 0) - 1            # global pair id -> local pair id
-        rd_pair, rd_rev = loc[rd_pair[sel]], rd_rev[sel]
+        rd_pair, rd_rev = loc[rd_pair_all[sel]], is_rev_all[sel].to(torch.int64)
+        del rd_pair_all, is_rev_all, loc
         global_index = sel
         stream_context = dict(tick=(sel + 1).contiguous(), ev_tid=ev_tid.to(torch.int32).cpu().numpy(), ev_pos=ev_pos.to(torch.int32).cpu().numpy())
-        # pair-level arrays restricted to my pairs; `pid` keeps the GLOBAL ids: they key the per-base / per-name random streams
-        pid, mol, p_tid, p_start, p_ins, strand = pid[mine_p], mol[mine_p], p_tid[mine_p], p_start[mine_p], p_ins[mine_p], strand[mine_p]
-        fk, fklen, fa, rk, rklen, ra = fk[mine_p], fklen[mine_p], fa[mine_p], rk[mine_p], rklen[mine_p], ra[mine_p]
-        f_pos, r_pos, r0, f_isize, r_isize = f_pos[mine_p], r_pos[mine_p], r0[mine_p], f_isize[mine_p], r_isize[mine_p]
-        P = int(pid.numel())
-        N = int(sel.numel())
-        del mine_p, loc, sel
+        d_ = pair_level(torch.nonzero(mine_p).squeeze(1))
+        del mine_p
+        P = int(d_["pid"].numel()); N = int(sel.numel())
+    else:
+        d_ = pair_level(torch.arange(P, **i64))
+    pid, mol, p_tid, p_start, p_ins, strand = d_["pid"], d_["mol"], d_["p_tid"], d_["p_start"], d_["p_ins"], d_["strand"]
+    fk, fklen, fa, rk, rklen, ra = d_["fk"], d_["fklen"], d_["fa"], d_["rk"], d_["rklen"], d_["ra"]
+    f_pos, r_pos, r0, f_isize, r_isize = d_["f_pos"], d_["r_pos"], d_["r0"], d_["f_isize"], d_["r_isize"]
+    del d_
+
+    # ---------------------------------------------------------------- reads = 2 per pair, sorted by (tid, pos)
+    if not lean:
+        N = 2 * P
+        rd_pair = torch.cat([pid, pid])
+        rd_rev = torch.cat([torch.zeros(P, **i64), torch.ones(P, **i64)])
+        rd_pos = torch.cat([f_pos, r_pos])
+        rd_tid = torch.cat([p_tid, p_tid])
+        # tie order inside one (tid,pos): a scrambled pair id, like an aligner's arbitrary order
+        key = (rd_tid << 40) | rd_pos
+        tie = rnd_u(seed, 5, rd_pair * 2 + rd_rev, 1 << 20)
+        order = torch.argsort(tie, stable=True)
+        order = order[torch.argsort(key[order], stable=True)]
+        rd_pair, rd_rev = rd_pair[order], rd_rev[order]
+        del order, tie, rd_pos, rd_tid
+        if shard is not None:
+            rank, world = shard
+            # every read of this generator reaches the cluster map, so a read's global tick is its place in the stream (gencore.cpp:319);
+            # flush events = the reads on which tick % period == 0 (gencore.cpp:321-322)
+            evi = torch.arange(flush_period - 1, N, flush_period, **i64) if N >= flush_period else torch.zeros(0, **i64)
+            ev_pair, ev_rev = rd_pair[evi], rd_rev[evi]
+            ev_pos = torch.where(ev_rev == 1, r_pos[ev_pair], f_pos[ev_pair])
+            ev_tid = p_tid[ev_pair]
+            # cluster key of a pair: (tid, left) with left = the leftmost of the two mates (the read with isize < 0 follows its mate,
+            # gencore.cpp:301-303); key ranges with equal pair counts
+            kp = (p_tid << 40) | torch.minimum(f_pos, r_pos)
+            if cfg.get("shard_mode", "range") == "lpt":
+                # ultra-deep hotspots: whole clusters dealt to the least loaded rank, heaviest first, weight = depth^2 (SURVEY 8e)
+                uk, inv, cnt = torch.unique(kp, return_inverse=True, return_counts=True)
+                cn = cnt.cpu().numpy().astype(np.float64)
+                load, owner = np.zeros(world), np.zeros(len(cn), np.int64)
+                for c in np.argsort(-cn ** 2, kind="stable"):
+                    r = int(np.argmin(load)); owner[c] = r; load[r] += cn[c] ** 2
+                mine_p = torch.from_numpy(owner).to(dev)[inv] == rank
+                del uk, inv, cnt
+            else:
+                srt = torch.sort(kp).values
+                cuts = srt[torch.tensor([min(P - 1, (P * r) // world) for r in range(1, world)], **i64)] if world > 1 else srt[:0]
+                mine_p = torch.searchsorted(cuts, kp, right=True) == rank
+                del srt
+            del kp
+            sel = torch.nonzero(mine_p[rd_pair]).squeeze(1)              # my reads, in stream order
+            loc = torch.cumsum(mine_p.to(torch.int64), 0) - 1            # global pair id -> local pair id
+            rd_pair, rd_rev = loc[rd_pair[sel]], rd_rev[sel]
+            global_index = sel
+            stream_context = dict(tick=(sel + 1).contiguous(), ev_tid=ev_tid.to(torch.int32).cpu().numpy(), ev_pos=ev_pos.to(torch.int32).cpu().numpy())
+            # pair-level arrays restricted to my pairs; `pid` keeps the GLOBAL ids: they key the per-base / per-name random streams
+            pid, mol, p_tid, p_start, p_ins, strand = pid[mine_p], mol[mine_p], p_tid[mine_p], p_start[mine_p], p_ins[mine_p], strand[mine_p]
+            fk, fklen, fa, rk, rklen, ra = fk[mine_p], fklen[mine_p], fa[mine_p], rk[mine_p], rklen[mine_p], ra[mine_p]
+            f_pos, r_pos, r0, f_isize, r_isize = f_pos[mine_p], r_pos[mine_p], r0[mine_p], f_isize[mine_p], r_isize[mine_p]
+            P = int(pid.numel())
+            N = int(sel.numel())
+            del mine_p, loc, sel
     isrev = rd_rev == 1
     pos = torch.where(isrev, r_pos[rd_pair], f_pos[rd_pair])
     mpos = torch.where(isrev, f_pos[rd_pair], r_pos[rd_pair])

@@ -191,3 +191,20 @@ def test_result_table_round_trip(oracle, seed):
     if len(rows["src"]) > 1:
         swapped["src"] = rows["src"][::-1].copy()
         assert check_output_order(batch, swapped)
+
+
+def test_key_range_shards_planned_lean_equal_the_legacy_plan():
+    """synth.generate(shard=...) plans a key-range shard without holding the whole stream at pair level (round 6): the rank's records, its global ticks, the stream's
+    flush events and the reads' places in the stream are those of the legacy plan, and a world of one is the unsharded stream"""
+    import torch
+    from gencore_amd import synth
+    for name, kw in (("cfg3", dict(n_pairs=12000, scale=0.005)), ("cfg4s", dict(n_pairs=8000, scale=0.003))):
+        base = synth.generate(name, seed=5, **kw)
+        w1 = synth.generate(name, seed=5, shard=(0, 1), **kw)
+        assert all(torch.equal(base.t[k], w1.t[k]) for k in base.t)
+        for rank in range(3):
+            a = synth.generate(name, seed=5, shard=(rank, 3), legacy_shard=True, **kw)
+            b = synth.generate(name, seed=5, shard=(rank, 3), **kw)
+            assert all(torch.equal(a.t[k], b.t[k]) for k in a.t), (name, rank)
+            assert torch.equal(a.stream_context["tick"], b.stream_context["tick"]) and torch.equal(a.global_index, b.global_index)
+            assert (a.stream_context["ev_tid"] == b.stream_context["ev_tid"]).all() and (a.stream_context["ev_pos"] == b.stream_context["ev_pos"]).all()
