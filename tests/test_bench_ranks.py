@@ -61,3 +61,13 @@ def test_world_of_one_over_rccl_equals_one_engine(built):
         assert a[blk] == b[blk], (blk, a[blk], b[blk])
     assert a["depth"] == b["depth"] and a["pre_hist_sum"] == b["pre_hist_sum"] and a["post_hist_sum"] == b["post_hist_sum"]
     assert "all-reduce" in w1["step_includes"]
+
+
+def test_record_layouts_in_device_memory_give_the_same_stream_statistics(built):
+    """bench.py --layout record / record64: ONE device blob, both base pointers of the batch the same buffer (gce_submit_device, zero copy) -- the engine must
+    give the Stats blocks, histogram sums, depth and BED digests of the two-blob layout (the record-level parity of free-form offsets: test_gpu_parity.py)"""
+    common = ["--workload", "cfg3", "--scale", "0.02", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--pairs", "200000"]
+    base = run([sys.executable, "bench.py"] + common)["stats_whole_stream"]
+    for lay in ("record", "record64"):
+        got = run([sys.executable, "bench.py", "--layout", lay] + common)["stats_whole_stream"]
+        assert got == base, lay

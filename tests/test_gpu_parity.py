@@ -46,6 +46,30 @@ def test_blob_offsets_beyond_4gb(built):
     assert np.array_equal(got_far.out_flag, got.out_flag)
 
 
+@pytest.mark.parametrize("seed,kw", [(33, {}), (107, dict(n_mol=60, umi_mode="duplex", period=7))])
+def test_record_layout_one_blob_for_bases_and_qualities(built, seed, kw):
+    """gce_batch offsets are free-form: ONE blob with a read's qualities right behind its packed bases (a BAM record's order; bench.py --layout record) and in REVERSED
+    read order must give what the two-blob layout gives -- both base pointers of the batch are the same buffer, only the offsets tell bases from qualities."""
+    batch, over, reference, contig_len = fuzzgen.make_case(seed, **kw)
+    params = fuzzgen.make_params(over, contig_len)
+    lq = batch.core["l_qseq"].astype(np.int64)
+    sb = (lq + 1) // 2
+    rec_len = sb + lq + 3                                    # three pad bytes between records: nothing may depend on neighbours
+    order = np.arange(batch.n)[::-1]                        # records laid out back to front
+    start = np.zeros(batch.n, np.int64); start[order] = np.cumsum(rec_len[order]) - rec_len[order]
+    blob = np.full(int(rec_len.sum()) + 64, 0x5A, np.uint8)
+    for i in range(batch.n):
+        so, qo = int(batch.seq_off[i]), int(batch.qual_off[i])
+        blob[start[i]:start[i] + sb[i]] = batch.seq[so:so + sb[i]]
+        blob[start[i] + sb[i]:start[i] + sb[i] + lq[i]] = batch.qual[qo:qo + lq[i]]
+    rec = batch.copy()
+    rec.seq = blob; rec.qual = blob.copy()                  # (the host path uploads either blob: two copies of the same bytes; the oracle gets its own as well)
+    rec.seq_off = start.astype(np.uint64); rec.qual_off = (start + sb).astype(np.uint64)
+    got_rec, _ = run_both(rec, params, reference)
+    got, _ = run_both(batch, params, reference)
+    assert np.array_equal(got_rec.out_flag, got.out_flag)
+
+
 @pytest.mark.parametrize("seed,umi_mode,period", [(100, "duplex", 10000), (101, "duplex", 11), (102, "prefix", 5), (103, "colon", 3),
                                                     (104, "none", 2), (105, "duplex", 1), (106, "prefix", 10000)])
 def test_fuzz_umi_modes(built, seed, umi_mode, period):
